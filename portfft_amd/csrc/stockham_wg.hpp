@@ -1,0 +1,293 @@
+// Work-group tier: one (or several) whole FFT(s) per work-group, Stockham autosort passes through LDS.
+//
+// Role in the reference: workgroup_impl + wg_dft + the subgroup/workitem tiers below it
+// (/root/reference/src/portfft/dispatcher/workgroup_dispatcher.hpp:94-281,
+//  /root/reference/src/portfft/common/workgroup.hpp:319-346, common/subgroup.hpp:271-291).
+// The reference runs a Bailey 4-step (n x m) with 64-lane work-groups, cross-lane shuffles for the sub-FFTs and a
+// scalar transposing store.  This design is different on purpose (MI355X-first):
+//   * N = R0*R1*...  (radices up to 16, compile-time) -> one Stockham pass per radix; every pass reads its R inputs
+//     at stride N/R (lane-contiguous: conflict-free ds_read_b64/b128, coalesced global loads) and writes the
+//     autosorted positions, so the last pass leaves natural order and stores straight to HBM, lane-contiguous.
+//   * pass 0 reads HBM directly, the last pass writes HBM directly: data crosses LDS (passes-1) times.
+//   * twiddles W_{Ns*R}^{t*q} depend only on (lane, butterfly slot), never on the batch: a persistent work-group
+//     loads them once from the HBM table into VGPRs and reuses them for every FFT it processes.
+//   * 256-thread work-groups (4 wave64), 16 points per lane at N=4096; LDS = N complex (+pad) per FFT in flight.
+#pragma once
+#include <utility>
+
+#include "butterflies.hpp"
+
+namespace pfa {
+
+template <int... Rs>
+struct radix_list {
+  static constexpr int count = sizeof...(Rs);
+  static constexpr int r[sizeof...(Rs)] = {Rs...};
+  static constexpr int n = (Rs * ... * 1);
+  /// product of the radices before pass p (the Stockham stride Ns of pass p)
+  static constexpr int ns(int p) {
+    int s = 1;
+    for (int i = 0; i < p; ++i) s *= r[i];
+    return s;
+  }
+  /// offset (in complex elements) of pass p's twiddles in the plan's table; pass 0 has none.
+  static constexpr int tw_off(int p) {
+    int o = 0;
+    for (int i = 1; i < p; ++i) o += ns(i) * (r[i] - 1);
+    return o;
+  }
+  static constexpr int tw_total = tw_off(sizeof...(Rs));
+};
+
+enum : int { TW_GLOBAL = 0, TW_REGS = 1 };
+
+/// Compile-time description of one work-group kernel variant.
+///  T       float or double
+///  Seq     radix_list<...>
+///  WG      threads per work-group
+///  FPW     FFTs processed concurrently by one work-group (threads per FFT = WG / FPW)
+///  PADS    LDS padding: one extra PADW complex elements every 2^PADS elements (PADS = 0 disables)
+///  TWM     TW_GLOBAL: twiddles re-read from the table (L1/L2 resident) at every use
+///          TW_REGS  : twiddles loaded once per work-group lifetime into VGPRs
+///  OCC     waves per SIMD to keep resident (bounds the VGPR budget: 512 / OCC)
+template <typename T_, typename Seq_, int WG_, int FPW_, int PADS_, int PADW_, int TWM_, int OCC_ = 1, int AUX_ = 0>
+struct wg_cfg {
+  using T = T_;
+  using Seq = Seq_;
+  static constexpr int WG = WG_;
+  static constexpr int FPW = FPW_;
+  static constexpr int TPF = WG_ / FPW_;
+  static constexpr int N = Seq_::n;
+  static constexpr int PADS = PADS_;
+  static constexpr int PADW = PADW_;
+  static constexpr int TWM = TWM_;
+  static constexpr int OCC = OCC_;  // minimum waves per SIMD the register allocator must leave room for
+  static constexpr int AUX = AUX_;  // cache-policy bits of the HBM accesses (0 default, 2 = nt streaming)
+  static constexpr int NP = Seq_::count;
+  static constexpr int pad(int i) { return PADS_ == 0 ? i : i + ((i >> PADS_) * PADW_); }
+  static constexpr int LDS_PER_FFT = pad(N - 1) + 1 + (PADS_ == 0 ? 0 : PADW_);
+  static constexpr int LDS_ELEMS = NP > 1 ? LDS_PER_FFT * FPW_ : 0;
+  static constexpr size_t LDS_BYTES = size_t(LDS_ELEMS) * sizeof(cx<T_>);
+  /// butterflies each lane performs in pass p
+  static constexpr int bpt(int p) { return (N / Seq_::r[p] + TPF - 1) / TPF; }
+  static constexpr int twr_off(int p) {
+    int o = 0;
+    for (int i = 1; i < p; ++i) o += bpt(i) * (Seq_::r[i] - 1);
+    return o;
+  }
+  static constexpr int TWR_TOTAL = twr_off(NP) > 0 ? twr_off(NP) : 1;
+};
+
+template <typename Cfg>
+PFA_DEV int lds_pad(int i) {
+  if constexpr (Cfg::PADS == 0) {
+    return i;
+  } else {
+    return i + ((i >> Cfg::PADS) * Cfg::PADW);
+  }
+}
+
+/// pad(a + k*unit) == pad(a) + k*pad_step(unit) holds for every k when `unit` is a multiple of the padding period,
+/// or when `a` is a multiple of the period and k*unit stays below it (pass 0 of a power-of-two plan).  With a
+/// linear step the R LDS accesses of a butterfly share ONE address VGPR and differ only in the immediate offset.
+template <typename Cfg>
+constexpr bool pad_is_linear(int unit, int count, int a_multiple_of) {
+  if (Cfg::PADS == 0) return true;
+  const int period = 1 << Cfg::PADS;
+  if (unit % period == 0) return true;
+  return (a_multiple_of % period == 0) && (unit * (count - 1) < period);
+}
+template <typename Cfg>
+constexpr int pad_step(int unit) {
+  if (Cfg::PADS == 0) return unit;
+  const int period = 1 << Cfg::PADS;
+  return unit % period == 0 ? unit + (unit >> Cfg::PADS) * Cfg::PADW : unit;
+}
+
+/// Raw 16- or 8-byte buffer access: one 32-bit lane offset VGPR (voff) serves every access of a butterfly, the
+/// butterfly's stride goes into the scalar offset (soff), and the hardware range check drops out-of-range lanes.
+using buf_b64_t = decltype(__builtin_amdgcn_raw_buffer_load_b64(std::declval<__amdgpu_buffer_rsrc_t>(), 0u, 0u, 0));
+using buf_b128_t = decltype(__builtin_amdgcn_raw_buffer_load_b128(std::declval<__amdgpu_buffer_rsrc_t>(), 0u, 0u, 0));
+static_assert(sizeof(buf_b64_t) == 8 && sizeof(buf_b128_t) == 16, "unexpected raw buffer builtin types");
+
+template <typename T, int AUX>
+PFA_DEV cx<T> buf_load(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff) {
+  if constexpr (sizeof(T) == 4) {
+    return __builtin_bit_cast(cx<T>, __builtin_amdgcn_raw_buffer_load_b64(rsrc, voff, soff, AUX));
+  } else {
+    return __builtin_bit_cast(cx<T>, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff, AUX));
+  }
+}
+template <typename T, int AUX>
+PFA_DEV void buf_store(cx<T> v, __amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff) {
+  if constexpr (sizeof(T) == 4) {
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(buf_b64_t, v), rsrc, voff, soff, AUX);
+  } else {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(buf_b128_t, v), rsrc, voff, soff, AUX);
+  }
+}
+
+/// Addressing of one work-group's FFTs for the PACKED layout (reference: detail::layout::PACKED,
+/// enums.hpp:47-50).  The FPW FFTs of group g are contiguous: the descriptor covers exactly the FFTs of the group
+/// that exist (ragged last group: missing FFTs read zeros and their stores are dropped by the range check).
+template <typename T, int N, int FPW, int AUX>
+struct packed_io {
+  __amdgpu_buffer_rsrc_t rin, rout;
+  PFA_DEV packed_io(const cx<T>* in, cx<T>* out, long long g, long long nfft) {
+    const long long first = g * FPW;
+    const long long left = nfft - first;
+    const unsigned bytes = static_cast<unsigned>((left < FPW ? left : FPW) * N * sizeof(cx<T>));
+    rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<cx<T>*>(in + first * N), 0, bytes, 0x00020000);
+    rout = __builtin_amdgcn_make_buffer_rsrc(out + first * N, 0, bytes, 0x00020000);
+  }
+  /// byte offset of element j of the group's f-th FFT
+  static PFA_DEV unsigned lane_off(unsigned f, unsigned j) { return (f * N + j) * sizeof(cx<T>); }
+  /// uniform byte offset of k elements
+  static constexpr unsigned step(int k) { return k * sizeof(cx<T>); }
+  PFA_DEV cx<T> load(unsigned voff, unsigned soff) const { return buf_load<T, AUX>(rin, voff, soff); }
+  PFA_DEV void store(cx<T> v, unsigned voff, unsigned soff) const { buf_store<T, AUX>(v, rout, voff, soff); }
+};
+
+template <typename Cfg, bool BWD, int P, typename IO>
+PFA_DEV void wg_pass(const IO& io, unsigned f, cx<typename Cfg::T>* lds, int tid,
+                     const cx<typename Cfg::T>* __restrict__ tw, const cx<typename Cfg::T> (&twr)[Cfg::TWR_TOTAL],
+                     typename Cfg::T scale) {
+  using T = typename Cfg::T;
+  using Seq = typename Cfg::Seq;
+  constexpr int R = Seq::r[P];
+  constexpr int N = Cfg::N;
+  constexpr int NB = N / R;
+  constexpr int Ns = Seq::ns(P);
+  constexpr int BPT = Cfg::bpt(P);
+  constexpr bool ragged = (NB % Cfg::TPF) != 0;
+  constexpr bool first = P == 0;
+  constexpr bool last = P == Cfg::NP - 1;
+
+  cx<T> v[BPT][R];
+  // ---- gather the R inputs of each butterfly (stride NB: lane-contiguous) ----
+  sfor<0, BPT>([&](auto i_) PFA_LAMBDA {
+    constexpr int i = decltype(i_)::value;
+    const unsigned j = tid + i * Cfg::TPF;
+    if (!ragged || j < NB) {
+      if constexpr (first) {
+        sfor<0, R>([&](auto t_) PFA_LAMBDA {
+          constexpr int t = decltype(t_)::value;
+          cx<T> x = io.load(IO::lane_off(f, j), IO::step(t * NB));
+          if constexpr (BWD) x.im = -x.im;
+          v[i][t] = x;
+        });
+      } else if constexpr (pad_is_linear<Cfg>(NB, R, 1)) {
+        const cx<T>* p = lds + lds_pad<Cfg>(j);
+        sfor<0, R>([&](auto t_) PFA_LAMBDA {
+          constexpr int t = decltype(t_)::value;
+          v[i][t] = p[t * pad_step<Cfg>(NB)];
+        });
+      } else {
+        sfor<0, R>([&](auto t_) PFA_LAMBDA {
+          constexpr int t = decltype(t_)::value;
+          v[i][t] = lds[lds_pad<Cfg>(j + t * NB)];
+        });
+      }
+    }
+  });
+  // the LDS image is free for the next writer once every lane has its inputs in registers
+  if constexpr (!first) __syncthreads();
+  // ---- twiddle, butterfly, scatter ----
+  sfor<0, BPT>([&](auto i_) PFA_LAMBDA {
+    constexpr int i = decltype(i_)::value;
+    const unsigned j = tid + i * Cfg::TPF;
+    if (!ragged || j < NB) {
+      const unsigned q = j % Ns;
+      if constexpr (!first) {
+        sfor<1, R>([&](auto t_) PFA_LAMBDA {
+          constexpr int t = decltype(t_)::value;
+          cx<T> w;
+          if constexpr (Cfg::TWM == TW_REGS) {
+            w = twr[Cfg::twr_off(P) + i * (R - 1) + (t - 1)];
+          } else {
+            w = (tw + Seq::tw_off(P) + (t - 1) * Ns)[q];
+          }
+          v[i][t] = cmul(v[i][t], w);
+        });
+      }
+      dft<R>(v[i]);
+      const unsigned base = (j / Ns) * (Ns * R) + q;
+      if constexpr (last) {
+        sfor<0, R>([&](auto u_) PFA_LAMBDA {
+          constexpr int u = decltype(u_)::value;
+          cx<T> y = v[i][u];
+          if constexpr (BWD) y.im = -y.im;
+          y.re *= scale;
+          y.im *= scale;
+          io.store(y, IO::lane_off(f, base), IO::step(u * Ns));
+        });
+      } else if constexpr (pad_is_linear<Cfg>(Ns, R, Ns * R)) {
+        cx<T>* p = lds + lds_pad<Cfg>(base);
+        sfor<0, R>([&](auto u_) PFA_LAMBDA {
+          constexpr int u = decltype(u_)::value;
+          p[u * pad_step<Cfg>(Ns)] = v[i][u];
+        });
+      } else {
+        sfor<0, R>([&](auto u_) PFA_LAMBDA {
+          constexpr int u = decltype(u_)::value;
+          lds[lds_pad<Cfg>(base + u * Ns)] = v[i][u];
+        });
+      }
+    }
+  });
+  if constexpr (!last) __syncthreads();
+}
+
+template <typename Cfg, bool BWD, int P, typename IO>
+PFA_DEV void wg_passes(const IO& io, unsigned f, cx<typename Cfg::T>* lds, int tid,
+                       const cx<typename Cfg::T>* __restrict__ tw, const cx<typename Cfg::T> (&twr)[Cfg::TWR_TOTAL],
+                       typename Cfg::T scale) {
+  if constexpr (P < Cfg::NP) {
+    wg_pass<Cfg, BWD, P>(io, f, lds, tid, tw, twr, scale);
+    wg_passes<Cfg, BWD, P + 1>(io, f, lds, tid, tw, twr, scale);
+  }
+}
+
+/// Persistent work-group kernel: work-group g handles FFT groups g, g+G, ...  (FPW FFTs per group).
+template <typename Cfg, bool BWD>
+__global__ __launch_bounds__(Cfg::WG, Cfg::OCC) void stockham_wg_kernel(const cx<typename Cfg::T>* __restrict__ in,
+                                                              cx<typename Cfg::T>* __restrict__ out,
+                                                              const cx<typename Cfg::T>* __restrict__ tw,
+                                                              long long nfft, typename Cfg::T scale) {
+  using T = typename Cfg::T;
+  using Seq = typename Cfg::Seq;
+  extern __shared__ __attribute__((aligned(16))) char pfa_smem[];
+  const int f = threadIdx.x / Cfg::TPF;
+  const int tid = threadIdx.x % Cfg::TPF;
+  cx<T>* lds = reinterpret_cast<cx<T>*>(pfa_smem) + f * Cfg::LDS_PER_FFT;
+
+  cx<T> twr[Cfg::TWR_TOTAL];
+  if constexpr (Cfg::TWM == TW_REGS) {
+    sfor<1, Cfg::NP>([&](auto p_) PFA_LAMBDA {
+      constexpr int p = decltype(p_)::value;
+      constexpr int R = Seq::r[p];
+      constexpr int Ns = Seq::ns(p);
+      sfor<0, Cfg::bpt(p)>([&](auto i_) PFA_LAMBDA {
+        constexpr int i = decltype(i_)::value;
+        const int q = (tid + i * Cfg::TPF) % Ns;
+        sfor<1, R>([&](auto t_) PFA_LAMBDA {
+          constexpr int t = decltype(t_)::value;
+          twr[Cfg::twr_off(p) + i * (R - 1) + (t - 1)] = tw[Seq::tw_off(p) + (t - 1) * Ns + q];
+        });
+      });
+    });
+  }
+
+  const long long ngroups = (nfft + Cfg::FPW - 1) / Cfg::FPW;
+  for (long long g = blockIdx.x; g < ngroups; g += gridDim.x) {
+    const packed_io<T, Cfg::N, Cfg::FPW, Cfg::AUX> io(in, out, g, nfft);
+    const cx<T>* twp = tw;
+    if constexpr (Cfg::TWM == TW_GLOBAL) {
+      // keep the table reads inside the loop (L1/L2 hits) instead of letting LICM pin them in VGPRs
+      asm volatile("" : "+s"(twp));
+    }
+    wg_passes<Cfg, BWD, 0>(io, f, lds, tid, twp, twr, scale);
+  }
+}
+
+}  // namespace pfa
