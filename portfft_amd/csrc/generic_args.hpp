@@ -1,0 +1,41 @@
+// Launch-time arguments of the generic LDS tier (plain C++: shared by the host planner and the device kernel).
+#pragma once
+
+namespace pfa {
+
+constexpr int GENERIC_MAX_PASSES = 12;
+constexpr int GENERIC_WG = 256;
+
+/// Launch-time description of one generic stage.  Offsets and strides are in complex elements; `step` is the
+/// scalar step between consecutive complex elements of an array (2 interleaved, 1 split).
+struct generic_args {
+  const void* in_re;
+  const void* in_im;
+  void* out_re;
+  void* out_im;
+  int in_step, out_step;
+  long long in_stride, out_stride;
+  /// FFT number t lives at (t / inner_count) * dist_outer + (t % inner_count) * dist_inner
+  long long in_dist_inner, in_dist_outer, out_dist_inner, out_dist_outer;
+  long long inner_count, total_count;
+  int n, n_passes;
+  int radix[GENERIC_MAX_PASSES];
+  int tw_off[GENERIC_MAX_PASSES];
+  const void* tw;
+  int fpw;                   // FFTs staged together by one work-group
+  int in_f_fast, out_f_fast; // 1: consecutive lanes walk FFTs (batch-fastest), 0: consecutive lanes walk elements
+  int conj_in, conj_out;
+  double scale;
+  /// optional store modifier: output element k of the FFT with inner index c is multiplied by W_M^{k*c},
+  /// W_M^m = hi[m >> shift] * lo[m & ((1<<shift)-1)]  (two small tables instead of an M-entry one)
+  const void* stw_lo;
+  const void* stw_hi;
+  int stw_shift;
+};
+
+/// radices the generic kernel can run; the planner factorises lengths into these (plan.cpp: choose_radices)
+#define PFA_GENERIC_RADICES(X) \
+  X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16) X(17) X(19) X(23) X(29) X(31)
+
+
+}  // namespace pfa

@@ -1,0 +1,37 @@
+// Registry of the pre-compiled gfx950 kernels (host-visible interface of kernels_f32.hip / kernels_f64.hip).
+//
+// The reference JIT-specialises its kernels at commit time through SYCL specialization constants
+// (/root/reference/src/portfft/committed_descriptor_impl.hpp:448-573).  Here every variant is an offline-compiled
+// template instantiation; commit only looks the variant up.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstddef>
+
+#include "generic_args.hpp"
+
+namespace pfa {
+
+/// One specialised work-group kernel: packed, interleaved FFTs of a fixed length.
+struct spec_kernel {
+  int precision;  // PFFT_PRECISION_*
+  int n;
+  int wg;   // threads per work-group
+  int fpw;  // FFTs per work-group
+  size_t lds_bytes;
+  int n_radices;
+  int radices[8];
+  int tw_total;  // complex entries of the twiddle table the kernel expects (layout: radix_list::tw_off)
+  const void* fn[2];  // kernel symbols, [0] forward, [1] backward (for occupancy queries / attributes)
+  hipError_t (*launch)(hipStream_t stream, unsigned grid, const void* in, void* out, const void* tw, long long nfft,
+                       double scale, int backward);
+};
+
+const spec_kernel* spec_kernels_f32(int* count);
+const spec_kernel* spec_kernels_f64(int* count);
+
+hipError_t launch_generic_f32(hipStream_t stream, unsigned grid, size_t lds_bytes, const generic_args& args);
+hipError_t launch_generic_f64(hipStream_t stream, unsigned grid, size_t lds_bytes, const generic_args& args);
+const void* generic_kernel_symbol(int precision);
+
+}  // namespace pfa

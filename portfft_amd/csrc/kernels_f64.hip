@@ -1,0 +1,34 @@
+// fp64 kernel instantiations for gfx950 (see kernels_f32.hip for the parameter legend).
+#include "kernels_impl.hpp"
+
+namespace pfa {
+
+namespace {
+using d = double;
+constexpr int NT = 2;
+const spec_kernel g_spec_f64[] = {
+    make_spec_entry<wg_cfg<d, radix_list<16, 16>, 256, 16, 4, 1, TW_GLOBAL, 2, NT>>(),       // 256
+    make_spec_entry<wg_cfg<d, radix_list<8, 8, 8>, 256, 4, 4, 1, TW_GLOBAL, 2, NT>>(),       // 512
+    make_spec_entry<wg_cfg<d, radix_list<16, 8, 8>, 256, 4, 4, 1, TW_GLOBAL, 2, NT>>(),      // 1024
+    make_spec_entry<wg_cfg<d, radix_list<16, 16, 8>, 256, 2, 4, 1, TW_GLOBAL, 2, NT>>(),     // 2048
+    make_spec_entry<wg_cfg<d, radix_list<16, 16, 16>, 256, 1, 4, 1, TW_GLOBAL, 2, NT>>(),    // 4096
+    make_spec_entry<wg_cfg<d, radix_list<16, 16, 16, 2>, 512, 1, 4, 1, TW_GLOBAL, 2, NT>>(), // 8192
+};
+}  // namespace
+
+const spec_kernel* spec_kernels_f64(int* count) {
+  *count = static_cast<int>(sizeof(g_spec_f64) / sizeof(g_spec_f64[0]));
+  return g_spec_f64;
+}
+
+hipError_t launch_generic_f64(hipStream_t stream, unsigned grid, size_t lds_bytes, const generic_args& args) {
+  hipLaunchKernelGGL(generic_fft_kernel<double>, dim3(grid), dim3(GENERIC_WG), lds_bytes, stream, args);
+  return hipGetLastError();
+}
+
+const void* generic_kernel_symbol(int precision) {
+  return precision == PFFT_PRECISION_F64 ? reinterpret_cast<const void*>(&generic_fft_kernel<double>)
+                                         : reinterpret_cast<const void*>(&generic_fft_kernel<float>);
+}
+
+}  // namespace pfa

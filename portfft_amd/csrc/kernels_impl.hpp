@@ -1,0 +1,44 @@
+// Shared body of kernels_f32.hip / kernels_f64.hip: turns wg_cfg<...> variants into registry entries.
+#pragma once
+#include "../../include/portfft_amd.h"
+#include "generic_kernel.hpp"
+#include "kernels.hpp"
+#include "stockham_wg.hpp"
+
+namespace pfa {
+
+template <typename Cfg>
+hipError_t launch_spec(hipStream_t stream, unsigned grid, const void* in, void* out, const void* tw, long long nfft,
+                       double scale, int backward) {
+  using T = typename Cfg::T;
+  const auto* i = static_cast<const cx<T>*>(in);
+  auto* o = static_cast<cx<T>*>(out);
+  const auto* t = static_cast<const cx<T>*>(tw);
+  if (backward) {
+    hipLaunchKernelGGL((stockham_wg_kernel<Cfg, true>), dim3(grid), dim3(Cfg::WG), Cfg::LDS_BYTES, stream, i, o, t,
+                       nfft, static_cast<T>(scale));
+  } else {
+    hipLaunchKernelGGL((stockham_wg_kernel<Cfg, false>), dim3(grid), dim3(Cfg::WG), Cfg::LDS_BYTES, stream, i, o, t,
+                       nfft, static_cast<T>(scale));
+  }
+  return hipGetLastError();
+}
+
+template <typename Cfg>
+spec_kernel make_spec_entry() {
+  spec_kernel k{};
+  k.precision = sizeof(typename Cfg::T) == 8 ? PFFT_PRECISION_F64 : PFFT_PRECISION_F32;
+  k.n = Cfg::N;
+  k.wg = Cfg::WG;
+  k.fpw = Cfg::FPW;
+  k.lds_bytes = Cfg::LDS_BYTES;
+  k.n_radices = Cfg::NP;
+  for (int i = 0; i < Cfg::NP; ++i) k.radices[i] = Cfg::Seq::r[i];
+  k.tw_total = Cfg::Seq::tw_total;
+  k.fn[0] = reinterpret_cast<const void*>(&stockham_wg_kernel<Cfg, false>);
+  k.fn[1] = reinterpret_cast<const void*>(&stockham_wg_kernel<Cfg, true>);
+  k.launch = &launch_spec<Cfg>;
+  return k;
+}
+
+}  // namespace pfa

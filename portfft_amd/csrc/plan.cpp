@@ -1,0 +1,558 @@
+// Planner + executor behind pfft_plan_create / pfft_execute (the committed_descriptor of the reference).
+//
+// Mirrors the role of /root/reference/src/portfft/committed_descriptor_impl.hpp:
+//   ctor + prepare_implementation (:210-313, :716-768)      -> plan_t::plan_t / plan_1d
+//   calculate_twiddles (:430-434, per-level dispatchers)     -> twiddle_table (host long double -> device)
+//   allocate_scratch_and_precompute_scan (:579-708)          -> scratch for the GLOBAL tier
+//   dispatch_direction / dispatch_dimensions (:852-950)      -> build_direction: the stage list of one direction
+//   run_kernel (:1088-1111)                                  -> run_stage
+// The structure is our own: a plan is two flat lists of kernel launches ("stages"), one per direction, resolved at
+// commit time; execute only binds the user pointers and enqueues them on the plan's stream.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <memory>
+#include <vector>
+
+#include "descriptor.hpp"
+#include "kernels.hpp"
+
+namespace pfa {
+
+namespace {
+
+void hip_check(hipError_t e, const char* what) {
+  if (e != hipSuccess) fail(PFFT_HIP_ERROR, what, ": ", hipGetErrorString(e));
+}
+
+enum buffer_id { BUF_IN = 0, BUF_OUT = 1, BUF_SCRATCH = 2 };
+
+/// Addressing of the FFTs of one stage, in complex elements relative to the stage's buffer.
+/// FFT t starts at offset + (t / inner_count) * dist_outer + (t % inner_count) * dist_inner.
+struct addressing {
+  long long offset = 0;
+  long long stride = 1;
+  long long dist_inner = 0;
+  long long dist_outer = 0;
+};
+
+struct stage {
+  bool generic = false;
+  const spec_kernel* spec = nullptr;
+  int in_buf = BUF_IN, out_buf = BUF_OUT;
+  long long count = 0;  // number of FFTs
+  unsigned grid = 1;
+  // spec
+  long long in_offset = 0, out_offset = 0;
+  const void* tw = nullptr;
+  double scale = 1.0;
+  int backward = 0;
+  // generic
+  generic_args ga{};
+  addressing in_addr, out_addr;
+  size_t lds_bytes = 0;
+  // info
+  int n = 0;
+};
+
+const double PI_L = 3.14159265358979323846264338327950288;
+
+template <typename T>
+std::vector<T> host_twiddles(const std::vector<int>& radices) {
+  // table layout shared by every kernel: pass p >= 1 with stride Ns = r0*...*r(p-1) owns (r_p - 1) * Ns entries,
+  // entry [(t-1)*Ns + q] = W_{Ns*r_p}^{t*q}.  Computed in long double, rounded once.
+  std::vector<T> tw;
+  long long ns = 1;
+  for (size_t p = 0; p < radices.size(); ++p) {
+    const int r = radices[p];
+    if (p >= 1) {
+      for (int t = 1; t < r; ++t) {
+        for (long long q = 0; q < ns; ++q) {
+          const long double a = -2.0L * static_cast<long double>(PI_L) * static_cast<long double>(t * q) /
+                                static_cast<long double>(ns * r);
+          tw.push_back(static_cast<T>(cosl(a)));
+          tw.push_back(static_cast<T>(sinl(a)));
+        }
+      }
+    }
+    ns *= r;
+  }
+  if (tw.empty()) {
+    tw.push_back(T(1));
+    tw.push_back(T(0));
+  }
+  return tw;
+}
+
+std::vector<int> tw_offsets(const std::vector<int>& radices) {
+  std::vector<int> off(radices.size(), 0);
+  long long ns = 1;
+  int o = 0;
+  for (size_t p = 0; p < radices.size(); ++p) {
+    off[p] = o;
+    if (p >= 1) o += static_cast<int>(ns) * (radices[p] - 1);
+    ns *= radices[p];
+  }
+  return off;
+}
+
+bool generic_radix_ok(int r) {
+  switch (r) {
+#define PFA_OK(x) case x:
+    PFA_GENERIC_RADICES(PFA_OK)
+#undef PFA_OK
+    return true;
+    default:
+      return false;
+  }
+}
+
+/// Factorise n into radices the generic kernel implements; largest radices first (fewest LDS passes).
+/// Returns an empty vector when n has a prime factor that is not a supported radix.
+std::vector<int> choose_radices(long long n) {
+  std::vector<int> r;
+  if (n == 1) return {1};
+  long long rem = n;
+  while (rem > 1) {
+    int best = 0;
+    for (int c = 16; c >= 2; --c) {
+      if (rem % c == 0) {
+        best = c;
+        break;
+      }
+    }
+    if (best == 0) {
+      for (int c : {17, 19, 23, 29, 31}) {
+        if (rem % c == 0) best = c;
+      }
+    }
+    if (best == 0 || !generic_radix_ok(best)) return {};
+    // avoid a trailing tiny radix: 16 * 2 -> 8 * 4
+    r.push_back(best);
+    rem /= best;
+  }
+  if (r.size() >= 2 && r.back() == 2 && r[r.size() - 2] == 16) {
+    r[r.size() - 2] = 8;
+    r.back() = 4;
+  }
+  if (static_cast<int>(r.size()) > GENERIC_MAX_PASSES) return {};
+  return r;
+}
+
+}  // namespace
+
+struct plan_t {
+  pfft_desc_t desc{};
+  hipStream_t stream = nullptr;
+  int device = 0;
+  int n_cus = 0;
+  size_t max_lds = 0;
+  std::vector<stage> stages[2];
+  std::vector<void*> device_allocs;
+  void* scratch = nullptr;
+  size_t scratch_bytes = 0;
+  size_t twiddle_bytes = 0;
+  pfft_plan_info_t info{};
+
+  int scalar_bytes() const { return desc.precision == PFFT_PRECISION_F64 ? 8 : 4; }
+  size_t elem_bytes() const { return 2 * static_cast<size_t>(scalar_bytes()); }
+
+  ~plan_t() {
+    if (stream != nullptr || !device_allocs.empty()) (void)hipStreamSynchronize(stream);
+    for (void* p : device_allocs) (void)hipFree(p);
+  }
+
+  void* upload(const void* host, size_t bytes) {
+    void* d = nullptr;
+    hip_check(hipMalloc(&d, bytes), "hipMalloc(twiddles)");
+    device_allocs.push_back(d);
+    hip_check(hipMemcpy(d, host, bytes, hipMemcpyHostToDevice), "hipMemcpy(twiddles)");
+    twiddle_bytes += bytes;
+    return d;
+  }
+
+  void* upload_twiddles(const std::vector<int>& radices) {
+    if (desc.precision == PFFT_PRECISION_F64) {
+      auto t = host_twiddles<double>(radices);
+      return upload(t.data(), t.size() * sizeof(double));
+    }
+    auto t = host_twiddles<float>(radices);
+    return upload(t.data(), t.size() * sizeof(float));
+  }
+
+  /// W_M^m split in two tables (see generic_args::stw_*)
+  void upload_store_twiddles(long long M, int shift, const void** lo, const void** hi) {
+    const long long nlo = 1ll << shift;
+    const long long nhi = (M + nlo - 1) / nlo + 1;
+    auto fill = [&](auto tag, long long count, long long mult) {
+      using T = decltype(tag);
+      std::vector<T> v(static_cast<size_t>(2 * count));
+      for (long long i = 0; i < count; ++i) {
+        const long double a = -2.0L * static_cast<long double>(PI_L) * static_cast<long double>((i * mult) % M) /
+                              static_cast<long double>(M);
+        v[static_cast<size_t>(2 * i)] = static_cast<T>(cosl(a));
+        v[static_cast<size_t>(2 * i + 1)] = static_cast<T>(sinl(a));
+      }
+      return upload(v.data(), v.size() * sizeof(T));
+    };
+    if (desc.precision == PFFT_PRECISION_F64) {
+      *lo = fill(double{}, nlo, 1);
+      *hi = fill(double{}, nhi, nlo);
+    } else {
+      *lo = fill(float{}, nlo, 1);
+      *hi = fill(float{}, nhi, nlo);
+    }
+  }
+
+  const spec_kernel* find_spec(long long n) const {
+    int count = 0;
+    const spec_kernel* k =
+        desc.precision == PFFT_PRECISION_F64 ? spec_kernels_f64(&count) : spec_kernels_f32(&count);
+    for (int i = 0; i < count; ++i) {
+      if (k[i].n == n && k[i].lds_bytes <= max_lds) return &k[i];
+    }
+    return nullptr;
+  }
+
+  /// largest length the generic tier can hold (two LDS images)
+  long long generic_max_n() const { return static_cast<long long>(max_lds / (2 * elem_bytes())); }
+
+  unsigned persistent_grid(const void* fn, int wg, size_t lds, long long groups) {
+    int per_cu = 0;
+    hip_check(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, wg, lds), "occupancy query");
+    per_cu = std::max(per_cu, 1);
+    const long long resident = static_cast<long long>(per_cu) * n_cus;
+    // two waves of work-groups: keeps the tail short while the per-work-group set-up (twiddles) stays amortised
+    return static_cast<unsigned>(std::max<long long>(1, std::min<long long>(groups, 2 * resident)));
+  }
+
+  stage make_spec_stage(const spec_kernel* k, long long count, int in_buf, long long in_off, int out_buf,
+                        long long out_off, double scale, int backward) {
+    stage s;
+    s.generic = false;
+    s.spec = k;
+    s.n = k->n;
+    s.in_buf = in_buf;
+    s.out_buf = out_buf;
+    s.in_offset = in_off;
+    s.out_offset = out_off;
+    s.count = count;
+    s.scale = scale;
+    s.backward = backward;
+    s.tw = upload_twiddles(std::vector<int>(k->radices, k->radices + k->n_radices));
+    for (int d = 0; d < 2; ++d) {
+      if (k->lds_bytes > 48 * 1024) {
+        hip_check(hipFuncSetAttribute(k->fn[d], hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      static_cast<int>(k->lds_bytes)),
+                  "hipFuncSetAttribute");
+      }
+    }
+    s.grid = persistent_grid(k->fn[backward], k->wg, k->lds_bytes, (count + k->fpw - 1) / k->fpw);
+    return s;
+  }
+
+  stage make_generic_stage(long long n, long long count, long long inner_count, int in_buf, const addressing& ia,
+                           int out_buf, const addressing& oa, double scale, int conj_in, int conj_out) {
+    const std::vector<int> radices = choose_radices(n);
+    if (radices.empty()) {
+      fail(PFFT_UNSUPPORTED_CONFIGURATION, "FFT size ", n, " : Large Prime sized FFT currently is unsupported");
+    }
+    stage s;
+    s.generic = true;
+    s.n = static_cast<int>(n);
+    s.in_buf = in_buf;
+    s.out_buf = out_buf;
+    s.count = count;
+    s.in_addr = ia;
+    s.out_addr = oa;
+    generic_args& g = s.ga;
+    g.n = static_cast<int>(n);
+    g.n_passes = (n == 1) ? 0 : static_cast<int>(radices.size());
+    const std::vector<int> offs = tw_offsets(radices);
+    for (int p = 0; p < g.n_passes; ++p) {
+      g.radix[p] = radices[static_cast<size_t>(p)];
+      g.tw_off[p] = offs[static_cast<size_t>(p)];
+    }
+    g.tw = upload_twiddles(radices);
+    g.in_stride = ia.stride;
+    g.out_stride = oa.stride;
+    g.in_dist_inner = ia.dist_inner;
+    g.in_dist_outer = ia.dist_outer;
+    g.out_dist_inner = oa.dist_inner;
+    g.out_dist_outer = oa.dist_outer;
+    g.inner_count = std::max<long long>(inner_count, 1);
+    g.total_count = count;
+    g.conj_in = conj_in;
+    g.conj_out = conj_out;
+    g.scale = scale;
+    g.stw_lo = nullptr;
+    g.stw_hi = nullptr;
+    g.stw_shift = 0;
+    // FFTs per work-group: fill ~64 KiB of LDS (two images), at least one FFT, at most what the stage has
+    const size_t per_fft = 2 * static_cast<size_t>(n) * elem_bytes();
+    long long fpw = std::max<long long>(1, static_cast<long long>((64 * 1024) / per_fft));
+    fpw = std::min<long long>(fpw, std::max<long long>(1, count));
+    fpw = std::min<long long>(fpw, 256);
+    g.fpw = static_cast<int>(fpw);
+    s.lds_bytes = per_fft * static_cast<size_t>(fpw);
+    if (s.lds_bytes > max_lds) {
+      fail(PFFT_OUT_OF_LOCAL_MEMORY, "FFT size ", n, " needs ", s.lds_bytes, " bytes of LDS, device has ", max_lds);
+    }
+    // lane order: walk whichever index is contiguous in memory
+    g.in_f_fast = (fpw > 1 && ia.dist_inner < ia.stride) ? 1 : 0;
+    g.out_f_fast = (fpw > 1 && oa.dist_inner < oa.stride) ? 1 : 0;
+    const void* fn = generic_kernel_symbol(desc.precision);
+    if (s.lds_bytes > 48 * 1024) {
+      hip_check(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(max_lds)),
+                "hipFuncSetAttribute");
+    }
+    s.grid = persistent_grid(fn, GENERIC_WG, s.lds_bytes, (count + fpw - 1) / fpw);
+    return s;
+  }
+
+  /// Plan `count` 1-D FFTs of length n.  Returns the tier used.
+  int plan_1d(std::vector<stage>& out, long long n, long long count, long long inner_count, int in_buf,
+              const addressing& ia, int out_buf, const addressing& oa, bool packed_io, double scale, int backward,
+              pfft_dim_info_t* info) {
+    const bool interleaved = desc.complex_storage == PFFT_INTERLEAVED_COMPLEX;
+    if (info != nullptr) {
+      info->length = static_cast<uint64_t>(n);
+      info->n_factors = 0;
+    }
+    auto record = [&](int tier, const std::vector<int>& factors, int wg, int fpw, size_t lds) {
+      if (info == nullptr) return;
+      info->tier = tier;
+      info->n_factors = static_cast<int>(std::min<size_t>(factors.size(), PFFT_MAX_FACTORS));
+      for (int i = 0; i < info->n_factors; ++i) info->factors[i] = factors[static_cast<size_t>(i)];
+      info->workgroup_size = wg;
+      info->ffts_per_workgroup = fpw;
+      info->lds_bytes = lds;
+    };
+    if (packed_io && interleaved) {
+      if (const spec_kernel* k = find_spec(n)) {
+        out.push_back(make_spec_stage(k, count, in_buf, ia.offset, out_buf, oa.offset, scale, backward));
+        record(k->n_radices == 1 ? PFFT_TIER_REGISTER : PFFT_TIER_WORKGROUP,
+               std::vector<int>(k->radices, k->radices + k->n_radices), k->wg, k->fpw, k->lds_bytes);
+        return PFFT_TIER_WORKGROUP;
+      }
+    }
+    if (n <= generic_max_n()) {
+      stage s = make_generic_stage(n, count, inner_count, in_buf, ia, out_buf, oa, scale, backward, backward);
+      record(PFFT_TIER_GENERIC, std::vector<int>(s.ga.radix, s.ga.radix + s.ga.n_passes), GENERIC_WG, s.ga.fpw,
+             s.lds_bytes);
+      out.push_back(s);
+      return PFFT_TIER_GENERIC;
+    }
+    // ---- GLOBAL tier: N = N1 * N2 through HBM scratch (four-step) ----
+    // Like the reference (committed_descriptor_impl.hpp:757-764) only for 1-D packed data.
+    if (!packed_io || desc.rank != 1) {
+      fail(PFFT_UNSUPPORTED_CONFIGURATION, "FFT size ", n,
+           " needs the multi-kernel (global) implementation, which is only supported for 1-D transforms in the "
+           "default (packed) layout");
+    }
+    const long long gmax = generic_max_n();
+    long long n1 = 0;
+    // most balanced split whose two lengths both run on the generic tier
+    for (long long c = static_cast<long long>(std::sqrt(static_cast<double>(n))); c >= 2; --c) {
+      if (n % c == 0 && n / c <= gmax && !choose_radices(c).empty() && !choose_radices(n / c).empty()) {
+        n1 = c;
+        break;
+      }
+    }
+    if (n1 == 0) {
+      fail(PFFT_UNSUPPORTED_CONFIGURATION, "FFT size ", n, " cannot be split into two factors that fit local memory",
+           " (large prime factors are not supported)");
+    }
+    const long long n2 = n / n1;
+    const size_t need = static_cast<size_t>(count) * static_cast<size_t>(n) * elem_bytes();
+    scratch_bytes = std::max(scratch_bytes, need);
+    // stage A: for every batch b and column c: length-n1 FFT over rows (stride n2), x W_n^{k1*c}, same layout out
+    addressing a_in{ia.offset, n2, 1, n};
+    addressing a_out{0, n2, 1, n};
+    stage sa = make_generic_stage(n1, count * n2, n2, in_buf, a_in, BUF_SCRATCH, a_out, 1.0, backward, 0);
+    int shift = 0;
+    while ((1ll << (2 * shift)) < n) ++shift;
+    upload_store_twiddles(n, shift, &sa.ga.stw_lo, &sa.ga.stw_hi);
+    sa.ga.stw_shift = shift;
+    out.push_back(sa);
+    // stage B: for every batch b and row k1: length-n2 FFT (contiguous), output X[k1 + n1*k2]
+    addressing b_in{0, 1, n2, n};
+    addressing b_out{oa.offset, n1, 1, n};
+    stage sb = make_generic_stage(n2, count * n1, n1, BUF_SCRATCH, b_in, out_buf, b_out, scale, 0, backward);
+    out.push_back(sb);
+    record(PFFT_TIER_GLOBAL, {static_cast<int>(n1), static_cast<int>(n2)}, GENERIC_WG, sb.ga.fpw,
+           std::max(sa.lds_bytes, sb.lds_bytes));
+    return PFFT_TIER_GLOBAL;
+  }
+
+  void build_direction(int direction) {
+    std::vector<stage>& st = stages[direction];
+    const int inv = direction == PFFT_FORWARD ? PFFT_BACKWARD : PFFT_FORWARD;
+    const view_t vin = view_of(desc, direction), vout = view_of(desc, inv);
+    const bool packed = layout_of(desc, direction) == PFFT_LAYOUT_PACKED && layout_of(desc, inv) == PFFT_LAYOUT_PACKED;
+    const double scale = direction == PFFT_FORWARD ? desc.forward_scale : desc.backward_scale;
+    const int backward = direction == PFFT_BACKWARD ? 1 : 0;
+    const long long B = static_cast<long long>(desc.number_of_transforms);
+    const int rank = desc.rank;
+    const long long total = static_cast<long long>(flattened_length(desc));
+    const bool record = direction == PFFT_FORWARD;
+    if (rank == 1) {
+      const long long n = static_cast<long long>(desc.lengths[0]);
+      addressing ia{static_cast<long long>(vin.offset), static_cast<long long>(vin.strides[0]),
+                    static_cast<long long>(vin.distance), 0};
+      addressing oa{static_cast<long long>(vout.offset), static_cast<long long>(vout.strides[0]),
+                    static_cast<long long>(vout.distance), 0};
+      plan_1d(st, n, B, B, BUF_IN, ia, BUF_OUT, oa, packed, scale, backward, record ? &info.dims[0] : nullptr);
+      return;
+    }
+    // N-D, packed (validated): contiguous dimension first, then every outer dimension in place on the output,
+    // as strided FFTs (reference: dispatch_dimensions, committed_descriptor_impl.hpp:923-948; there one launch per
+    // (batch, outer index), here one launch per dimension).
+    const long long last = static_cast<long long>(desc.lengths[rank - 1]);
+    {
+      addressing ia{static_cast<long long>(vin.offset), 1, last, 0};
+      addressing oa{static_cast<long long>(vout.offset), 1, last, 0};
+      const long long count = B * (total / last);
+      plan_1d(st, last, count, count, BUF_IN, ia, BUF_OUT, oa, true, scale, backward,
+              record ? &info.dims[rank - 1] : nullptr);
+    }
+    long long inner = last;
+    for (int i = rank - 2; i >= 0; --i) {
+      const long long n = static_cast<long long>(desc.lengths[i]);
+      const long long outer_count = B * (total / (inner * n));
+      addressing a{static_cast<long long>(vout.offset), inner, 1, inner * n};
+      plan_1d(st, n, outer_count * inner, inner, BUF_OUT, a, BUF_OUT, a, false, 1.0, backward,
+              record ? &info.dims[i] : nullptr);
+      inner *= n;
+    }
+  }
+
+  plan_t(const pfft_desc_t& d, hipStream_t s) : desc(d), stream(s) {
+    validate(desc);
+    hip_check(hipGetDevice(&device), "hipGetDevice");
+    hipDeviceProp_t prop;
+    hip_check(hipGetDeviceProperties(&prop, device), "hipGetDeviceProperties");
+    n_cus = prop.multiProcessorCount;
+    max_lds = prop.sharedMemPerBlock;
+    info.rank = desc.rank;
+    info.n_compute_units = n_cus;
+    build_direction(PFFT_FORWARD);
+    build_direction(PFFT_BACKWARD);
+    if (scratch_bytes > 0) {
+      hip_check(hipMalloc(&scratch, scratch_bytes), "hipMalloc(scratch)");
+      device_allocs.push_back(scratch);
+    }
+    info.twiddle_bytes = twiddle_bytes;
+    info.scratch_bytes = scratch_bytes;
+  }
+
+  void run_stage(const stage& s, const void* in_re, const void* in_im, void* out_re, void* out_im) {
+    const size_t sb = static_cast<size_t>(scalar_bytes());
+    const bool split = desc.complex_storage == PFFT_SPLIT_COMPLEX;
+    // resolve buffers: user buffers follow the descriptor's storage, scratch is always interleaved
+    auto base_re = [&](int buf, bool is_in) -> const char* {
+      if (buf == BUF_SCRATCH) return static_cast<const char*>(scratch);
+      if (buf == BUF_IN) return static_cast<const char*>(in_re);
+      (void)is_in;
+      return static_cast<const char*>(out_re);
+    };
+    auto base_im = [&](int buf) -> const char* {
+      if (buf == BUF_SCRATCH) return static_cast<const char*>(scratch) + sb;
+      if (buf == BUF_IN) return split ? static_cast<const char*>(in_im) : static_cast<const char*>(in_re) + sb;
+      return split ? static_cast<const char*>(out_im) : static_cast<const char*>(out_re) + sb;
+    };
+    auto step_of = [&](int buf) { return (buf == BUF_SCRATCH || !split) ? 2 : 1; };
+    if (!s.generic) {
+      const char* i = base_re(s.in_buf, true) + static_cast<size_t>(s.in_offset) * elem_bytes();
+      char* o = const_cast<char*>(base_re(s.out_buf, false)) + static_cast<size_t>(s.out_offset) * elem_bytes();
+      hip_check(s.spec->launch(stream, s.grid, i, o, s.tw, s.count, s.scale, s.backward), "kernel launch");
+      return;
+    }
+    generic_args g = s.ga;
+    g.in_step = step_of(s.in_buf);
+    g.out_step = step_of(s.out_buf);
+    g.in_re = base_re(s.in_buf, true) + static_cast<size_t>(s.in_addr.offset) * sb * static_cast<size_t>(g.in_step);
+    g.in_im = base_im(s.in_buf) + static_cast<size_t>(s.in_addr.offset) * sb * static_cast<size_t>(g.in_step);
+    g.out_re = const_cast<char*>(base_re(s.out_buf, false)) +
+               static_cast<size_t>(s.out_addr.offset) * sb * static_cast<size_t>(g.out_step);
+    g.out_im = const_cast<char*>(base_im(s.out_buf)) +
+               static_cast<size_t>(s.out_addr.offset) * sb * static_cast<size_t>(g.out_step);
+    const hipError_t e = desc.precision == PFFT_PRECISION_F64 ? launch_generic_f64(stream, s.grid, s.lds_bytes, g)
+                                                              : launch_generic_f32(stream, s.grid, s.lds_bytes, g);
+    hip_check(e, "kernel launch");
+  }
+
+  void execute(int direction, const void* in_re, const void* in_im, void* out_re, void* out_im) {
+    if (direction != PFFT_FORWARD && direction != PFFT_BACKWARD) {
+      fail(PFFT_INVALID_CONFIGURATION, "Invalid direction ", direction);
+    }
+    if (in_re == nullptr || out_re == nullptr) fail(PFFT_INVALID_CONFIGURATION, "null data pointer");
+    for (const stage& s : stages[direction]) run_stage(s, in_re, in_im, out_re, out_im);
+  }
+};
+
+}  // namespace pfa
+
+struct pfft_plan_t {
+  std::unique_ptr<pfa::plan_t> impl;
+};
+
+extern "C" {
+
+pfft_status pfft_plan_create(const pfft_desc_t* desc, void* hip_stream, pfft_plan_t** plan) {
+  return pfa::guarded([&] {
+    if (desc == nullptr || plan == nullptr) pfa::fail(PFFT_INVALID_CONFIGURATION, "null argument");
+    *plan = nullptr;
+    auto p = std::make_unique<pfft_plan_t>();
+    p->impl = std::make_unique<pfa::plan_t>(*desc, static_cast<hipStream_t>(hip_stream));
+    *plan = p.release();
+  });
+}
+
+pfft_status pfft_plan_destroy(pfft_plan_t* plan) {
+  return pfa::guarded([&] { delete plan; });
+}
+
+pfft_status pfft_plan_get_info(const pfft_plan_t* plan, pfft_plan_info_t* info) {
+  return pfa::guarded([&] {
+    if (plan == nullptr || info == nullptr) pfa::fail(PFFT_INVALID_CONFIGURATION, "null argument");
+    *info = plan->impl->info;
+  });
+}
+
+pfft_status pfft_execute(pfft_plan_t* plan, int32_t direction, const void* in, void* out) {
+  return pfa::guarded([&] {
+    if (plan == nullptr) pfa::fail(PFFT_INVALID_CONFIGURATION, "null plan");
+    if (plan->impl->desc.complex_storage != PFFT_INTERLEAVED_COMPLEX) {
+      // committed_descriptor_impl.hpp:862-871
+      pfa::fail(PFFT_INVALID_CONFIGURATION,
+                "To use interleaved data layout, the descriptor.complex_storage must be INTERLEAVED_COMPLEX");
+    }
+    plan->impl->execute(direction, in, nullptr, out, nullptr);
+  });
+}
+
+pfft_status pfft_execute_split(pfft_plan_t* plan, int32_t direction, const void* in_real, const void* in_imag,
+                               void* out_real, void* out_imag) {
+  return pfa::guarded([&] {
+    if (plan == nullptr) pfa::fail(PFFT_INVALID_CONFIGURATION, "null plan");
+    if (plan->impl->desc.complex_storage != PFFT_SPLIT_COMPLEX) {
+      pfa::fail(PFFT_INVALID_CONFIGURATION,
+                "To use split data layout, the descriptor.complex_storage must be SPLIT_COMPLEX");
+    }
+    if (in_imag == nullptr || out_imag == nullptr) pfa::fail(PFFT_INVALID_CONFIGURATION, "null imaginary pointer");
+    plan->impl->execute(direction, in_real, in_imag, out_real, out_imag);
+  });
+}
+
+pfft_status pfft_plan_wait(pfft_plan_t* plan) {
+  return pfa::guarded([&] {
+    if (plan == nullptr) pfa::fail(PFFT_INVALID_CONFIGURATION, "null plan");
+    const hipError_t e = hipStreamSynchronize(plan->impl->stream);
+    if (e != hipSuccess) pfa::fail(PFFT_HIP_ERROR, "hipStreamSynchronize: ", hipGetErrorString(e));
+  });
+}
+
+}  // extern "C"

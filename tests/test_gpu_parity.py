@@ -1,0 +1,328 @@
+"""Parity of the HIP path (through the C ABI) with the oracle, the golden vectors and NumPy.  Needs an MI355X.
+
+Tolerance: relative L2 error per transform <= helpers.REL_L2_TOL (2e-6 fp32, 5e-15 fp64) against the double
+precision result -- far inside the 1e-4 bar of BASELINE.json -- plus the reference's own per-element rule
+2*eps*N*log2(N) (fft_test_utils.hpp:461-464).  The size / batch / layout grid follows
+test/unit_test/instantiate_fft_tests.hpp.
+"""
+import numpy as np
+import pytest
+
+import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+F, B = 0, 1
+
+
+def _pf():
+    import portfft_amd as pf
+    return pf
+
+
+def _check(got, ref, n, dtype, what):
+    got = np.asarray(got)
+    ref = np.asarray(ref)
+    tol = H.REL_L2_TOL[np.dtype(dtype)]
+    for b in range(got.shape[0]):
+        e = H.rel_l2(got[b], ref[b])
+        assert e <= tol, (what, "batch", b, "rel-L2", e)
+    assert H.check_reference_rule(got.astype(dtype), ref.astype(dtype), n), what
+
+
+def _golden_cases(golden):
+    out = []
+    for k in golden["fft"].files:
+        if k.endswith("_in"):
+            prec, b, dims = k[:-3].split("_")
+            out.append((k[:-3], prec, int(b[1:]), [int(x) for x in dims.split("x")]))
+    return out
+
+
+def test_golden_vectors_forward_and_backward(golden, oracle):
+    """committed fixtures (reference test generator): GPU == fixture, and GPU == oracle on the same inputs"""
+    import gpu_utils as G
+    pf = _pf()
+    for key, prec, batch, dims in _golden_cases(golden):
+        x = golden["fft"][key + "_in"]
+        y = golden["fft"][key + "_out"]
+        n = int(np.prod(dims))
+        d = G.make_descriptor(dims, prec, batch=batch)
+        out = G.run(d, pf.direction.FORWARD, x.ravel()).reshape(y.shape)
+        _check(out, y, n, x.dtype, key + " fwd vs golden")
+        od = oracle.make_desc(dims, prec, batch=batch)
+        oref = oracle.compute(od, F, x.ravel(), threads=4).reshape(y.shape)
+        _check(out, oref, n, x.dtype, key + " fwd vs oracle")
+        back = G.run(d, pf.direction.BACKWARD, y.ravel()).reshape(x.shape)
+        _check(back, x.astype(np.complex128) * n, n, x.dtype, key + " bwd vs golden")
+
+
+def test_config1_in_place(golden):
+    """BASELINE config 1: fp32 N=64 batch=1 in-place forward"""
+    import gpu_utils as G
+    pf = _pf()
+    x = golden["fft"]["f32_b1_64_in"]
+    y = golden["fft"]["f32_b1_64_out"]
+    d = G.make_descriptor([64], "f32", placement=0)
+    out = G.run(d, pf.direction.FORWARD, x.ravel())
+    assert H.rel_l2(out, y.ravel()) <= 1e-6
+
+
+SIZES_BATCHES = [
+    ([1, 2, 3, 4, 8], [1, 3, 33000]),            # workItemTest
+    ([16, 32], [1, 3, 555]),                     # workItemOrSubgroupTest
+    ([64, 96, 128], [1, 3, 555]),                # SubgroupTest
+    ([256, 512, 1024], [1, 131]),                # SubgroupOrWorkgroupTest
+    ([1536], [1, 131]),
+    ([2048, 3072, 4096], [1, 3]),                # WorkgroupTest
+    ([8192, 16384], [1, 128]),                   # WorkgroupOrGlobal
+]
+# (placement, input layout, output layout): all_valid_placement_layouts (instantiate_fft_tests.hpp:37-46)
+PLACEMENT_LAYOUTS = [(0, "P", "P"), (0, "BI", "BI"), (1, "P", "P"), (1, "P", "BI"), (1, "BI", "BI"), (1, "BI", "P")]
+
+
+def _layout_desc(G, n, prec, batch, place, lin, lout, direction, storage):
+    """descriptor whose input domain has layout lin and output domain lout for `direction`"""
+    kw = {}
+    fwd_l, bwd_l = (lin, lout) if direction == F else (lout, lin)
+    if fwd_l == "BI":
+        kw.update(fwd_strides=[batch], fwd_distance=1)
+    if bwd_l == "BI":
+        kw.update(bwd_strides=[batch], bwd_distance=1)
+    return G.make_descriptor([n], prec, batch=batch, storage=storage, placement=place, **kw)
+
+
+@pytest.mark.parametrize("prec", ["f32", "f64"])
+def test_reference_size_grid_all_layouts(prec, oracle):
+    import gpu_utils as G
+    pf = _pf()
+    dtype = np.complex64 if prec == "f32" else np.complex128
+    for sizes, batches in SIZES_BATCHES:
+        for n in sizes:
+            for batch in batches:
+                x, y = H.gen_fourier_data(batch, [n], dtype)
+                big = n * batch > 2_000_000
+                for place, lin, lout in PLACEMENT_LAYOUTS:
+                    if big and (lin, lout) != ("P", "P"):
+                        continue
+                    if n >= 8192 and (lin, lout) != ("P", "P"):
+                        continue  # all_valid_global_placement_layouts: packed only
+                    for storage in (0, 1):
+                        if storage == 1 and (batch > 200 or n > 4096):
+                            continue
+                        d = _layout_desc(G, n, prec, batch, place, lin, lout, F, storage)
+                        got, _ = G.transform_packed(d, pf.direction.FORWARD, x)
+                        _check(got, y, n, dtype, ("fwd", prec, n, batch, place, lin, lout, storage))
+    # oracle cross-check on a few mid sizes (seeded inputs, same data on both sides)
+    for n, batch in [(64, 3), (1024, 3), (4096, 3), (8192, 1)]:
+        x, _ = H.gen_fourier_data(batch, [n], dtype, seed=3)
+        d = G.make_descriptor([n], prec, batch=batch)
+        got, _ = G.transform_packed(d, pf.direction.FORWARD, x)
+        ref = oracle.compute(oracle.make_desc([n], prec, batch=batch), F, x.ravel(), threads=4).reshape(x.shape)
+        _check(got, ref, n, dtype, ("oracle", prec, n))
+
+
+@pytest.mark.parametrize("prec", ["f32", "f64"])
+def test_backward_grid(prec):
+    """BackwardTest / BackwardGlobalTest (instantiate_fft_tests.hpp:160-173): unnormalised backward"""
+    import gpu_utils as G
+    pf = _pf()
+    dtype = np.complex64 if prec == "f32" else np.complex128
+    for n in (8, 9, 16, 32, 64, 4096, 32768, 65536):
+        for batch in (1, 3):
+            x, y = H.gen_fourier_data(batch, [n], dtype)
+            layouts = PLACEMENT_LAYOUTS if n <= 4096 else [(0, "P", "P"), (1, "P", "P")]
+            for place, lin, lout in layouts:
+                for storage in (0, 1):
+                    d = _layout_desc(G, n, prec, batch, place, lin, lout, B, storage)
+                    got, _ = G.transform_packed(d, pf.direction.BACKWARD, y)
+                    _check(got, x.astype(np.complex128) * n, n, dtype, ("bwd", prec, n, batch, place, lin, lout))
+
+
+@pytest.mark.parametrize("prec", ["f32", "f64"])
+def test_global_sizes(prec, oracle):
+    """GlobalTest 32768/65536/131072 and the odd composites 9800/15360/68640 (instantiate_fft_tests.hpp:147-157)"""
+    import gpu_utils as G
+    pf = _pf()
+    dtype = np.complex64 if prec == "f32" else np.complex128
+    for n, batches in [(32768, (1, 3)), (65536, (1, 3)), (131072, (1, 3)), (9800, (3,)), (15360, (3,)), (68640, (3,))]:
+        for batch in batches:
+            x, y = H.gen_fourier_data(batch, [n], dtype)
+            for place in (0, 1):
+                d = G.make_descriptor([n], prec, batch=batch, placement=place)
+                got, _ = G.transform_packed(d, pf.direction.FORWARD, x)
+                _check(got, y, n, dtype, ("global", prec, n, batch, place))
+    x, _ = H.gen_fourier_data(1, [32768], dtype, seed=11)
+    got, _ = G.transform_packed(G.make_descriptor([32768], prec), pf.direction.FORWARD, x)
+    ref = oracle.compute(oracle.make_desc([32768], prec), F, x.ravel()).reshape(x.shape)
+    _check(got, ref, 32768, dtype, "global vs oracle")
+
+
+@pytest.mark.parametrize("prec", ["f32", "f64"])
+def test_multidimensional(prec, oracle):
+    """MultidimensionalTest (instantiate_fft_tests.hpp:176-182), both directions, both storages"""
+    import gpu_utils as G
+    pf = _pf()
+    dtype = np.complex64 if prec == "f32" else np.complex128
+    for dims in ([2, 4], [4, 2], [16, 512], [64, 2048], [2, 3, 6], [2, 3, 2, 3]):
+        n = int(np.prod(dims))
+        for batch in (1, 3):
+            x, y = H.gen_fourier_data(batch, dims, dtype)
+            for place in (0, 1):
+                for storage in (0, 1):
+                    d = G.make_descriptor(dims, prec, batch=batch, storage=storage, placement=place)
+                    got, _ = G.transform_packed(d, pf.direction.FORWARD, x)
+                    _check(got.reshape(batch, -1), y.reshape(batch, -1), n, dtype, ("nd fwd", dims, batch, place))
+                    back, _ = G.transform_packed(d, pf.direction.BACKWARD, y)
+                    _check(back.reshape(batch, -1), x.reshape(batch, -1).astype(np.complex128) * n, n, dtype,
+                           ("nd bwd", dims, batch, place))
+    x, _ = H.gen_fourier_data(2, [16, 512], dtype, seed=2)
+    got, _ = G.transform_packed(G.make_descriptor([16, 512], prec, batch=2), pf.direction.FORWARD, x)
+    ref = oracle.compute(oracle.make_desc([16, 512], prec, batch=2), F, x.ravel(), threads=4).reshape(x.shape)
+    _check(got.reshape(2, -1), ref.reshape(2, -1), 16 * 512, dtype, "nd vs oracle")
+
+
+def test_offsets():
+    """Offsets* suites (instantiate_fft_tests.hpp:187-218): data starts at an offset; everything before the
+    output offset must stay untouched"""
+    import gpu_utils as G
+    pf = _pf()
+    dtype = np.complex64
+    for (fo, bo) in [(8, 8), (67, 67), (0, 2049), (2049, 0), (2047, 2049)]:
+        for direction in (F, B):
+            for place, lin, lout in ([(1, "P", "P"), (1, "P", "BI"), (1, "BI", "BI"), (1, "BI", "P")] +
+                                     ([(0, "P", "P"), (0, "BI", "BI")] if fo == bo else [])):
+                x, y = H.gen_fourier_data(33, [2048], dtype)
+                d = _layout_desc(G, 2048, "f32", 33, place, lin, lout, direction, 0)
+                d.forward_offset, d.backward_offset = fo, bo
+                src, ref = (x, y) if direction == F else (y, x.astype(np.complex128) * 2048)
+                got, raw = G.transform_packed(d, pf.direction(direction), src)
+                _check(got, ref, 2048, dtype, ("offsets", fo, bo, direction, place, lin, lout))
+                out_off = bo if direction == F else fo
+                if place == 1:
+                    assert np.all(raw[:out_off] == H.PADDING_VALUE), "padding before the offset was written"
+    # OffsetsWIErrorRegressionTest / OffsetsMDErrorRegressionTest
+    x, y = H.gen_fourier_data(33000, [8], dtype)
+    d = G.make_descriptor([8], batch=33000, fwd_offset=2047, bwd_offset=2049)
+    got, _ = G.transform_packed(d, pf.direction.FORWARD, x)
+    _check(got, y, 8, dtype, "offsets wi")
+    x, y = H.gen_fourier_data(2, [4, 4], dtype)
+    d = G.make_descriptor([4, 4], batch=2, fwd_offset=2, bwd_offset=0)
+    got, _ = G.transform_packed(d, pf.direction.FORWARD, x)
+    _check(got.reshape(2, -1), y.reshape(2, -1), 16, dtype, "offsets md")
+    x, y = H.gen_fourier_data(33, [16, 512], dtype)
+    for place in (0, 1):
+        d = G.make_descriptor([16, 512], batch=33, placement=place, fwd_offset=67, bwd_offset=67)
+        got, _ = G.transform_packed(d, pf.direction.FORWARD, x)
+        _check(got.reshape(33, -1), y.reshape(33, -1), 8192, dtype, "offsets nd")
+
+
+def test_scales():
+    """FwdScaledFFTTest / BwdScaledFFTTest (instantiate_fft_tests.hpp:221-235)"""
+    import gpu_utils as G
+    pf = _pf()
+    for prec, dtype in (("f32", np.complex64), ("f64", np.complex128)):
+        for dims in ([9], [16], [64], [512], [4096], [16, 512]):
+            n = int(np.prod(dims))
+            x, y = H.gen_fourier_data(3, dims, dtype)
+            for s in (-1.0, 2.0):
+                d = G.make_descriptor(dims, prec, batch=3, fwd_scale=s)
+                got, _ = G.transform_packed(d, pf.direction.FORWARD, x)
+                _check(got.reshape(3, -1), (y * s).reshape(3, -1), n, dtype, ("fwd scale", dims, s))
+                d = G.make_descriptor(dims, prec, batch=3, bwd_scale=s)
+                got, _ = G.transform_packed(d, pf.direction.BACKWARD, y)
+                _check(got.reshape(3, -1), (x.astype(np.complex128) * n * s).reshape(3, -1), n, dtype,
+                       ("bwd scale", dims, s))
+
+
+def _default_dist(lengths, strides):
+    return int(np.prod([l * s for l, s in zip(lengths, strides)]))
+
+
+def test_strided_layouts():
+    """strided / UNPACKED suites (instantiate_fft_tests.hpp:237-319), both directions, both storages"""
+    import gpu_utils as G
+    pf = _pf()
+    dtype = np.complex64
+    cases = ([(c, (1, 3, 3300), 1) for c in H.STRIDED_OOP_CASES] +
+             [(c, (1, 10, 33), 1) for c in H.STRIDED_OOP_BATCH_INTERLEAVED_LIKE] +
+             [(c, (1, 3, 3300), 0) for c in H.STRIDED_IP_CASES] +
+             [(([3], [66], [66], 2, 2), (1, 3, 33), 0), (([6], [40], [40], 1, 1), (1, 3, 33), 0),
+              (([75], [66], [66], 2, 2), (1, 3, 33), 0), (([96], [40], [40], 1, 1), (1, 3, 33), 0),
+              (([8], [2], [2], 2, 2), (1,), 1), (([8], [1], [1], 1, 1), (1,), 0),
+              (([4], [4], [4], 3, 3), (4,), 1), (([85], [13], [13], 12, 12), (13,), 0)])
+    for (lengths, fs, bs, fd, bd), batches, place in cases:
+        n = lengths[0]
+        fd = _default_dist(lengths, fs) if fd is None else fd
+        bd = _default_dist(lengths, bs) if bd is None else bd
+        for batch in batches:
+            x, y = H.gen_fourier_data(batch, lengths, dtype)
+            for storage in (0, 1):
+                d = G.make_descriptor(lengths, "f32", batch=batch, storage=storage, placement=place, fwd_strides=fs,
+                                      bwd_strides=bs, fwd_distance=fd, bwd_distance=bd)
+                got, _ = G.transform_packed(d, pf.direction.FORWARD, x)
+                _check(got, y, n, dtype, ("strided fwd", lengths, fs, bs, fd, bd, batch, storage))
+                got, _ = G.transform_packed(d, pf.direction.BACKWARD, y)
+                _check(got, x.astype(np.complex128) * n, n, dtype, ("strided bwd", lengths, fs, bs, fd, bd, batch))
+
+
+def test_error_behaviour_and_plan_info():
+    import gpu_utils as G
+    pf = _pf()
+    torch = G.torch_mod()
+    d = G.make_descriptor([4096], batch=4)
+    plan = d.commit()
+    info = plan.info()
+    assert info.dims[0].tier == 1 and list(info.dims[0].factors[:3]) == [16, 16, 16]
+    x = torch.zeros(4 * 4096, dtype=torch.complex64, device="cuda")
+    with pytest.raises(pf.invalid_configuration):  # committed_descriptor_impl.hpp:862-871
+        plan.compute_forward(x.real.contiguous(), x.imag.contiguous(), x.real.contiguous(), x.imag.contiguous())
+    ds = G.make_descriptor([64], storage=1)
+    with pytest.raises(pf.invalid_configuration):
+        ds.commit().compute_forward(x, x)
+    for case in H.INVALID_CASES[:4]:
+        from test_host_api import _pf_desc
+        with pytest.raises(pf.invalid_configuration):
+            _pf_desc(case).commit()
+    with pytest.raises(pf.unsupported_configuration):
+        G.make_descriptor([4099]).commit()  # large prime
+    assert G.make_descriptor([1 << 20], "f64", batch=2).commit().info().dims[0].tier == 3
+
+
+def test_full_size_config2_properties():
+    """BASELINE config 2 at full size (fp32 N=4096 batch=65536, 2 GiB in / 2 GiB out): sampled batches against
+    NumPy, Parseval on every batch, forward->backward round trip, linearity."""
+    import gpu_utils as G
+    pf = _pf()
+    torch = G.torch_mod()
+    n, batch = 4096, 65536
+    g = torch.Generator(device="cuda").manual_seed(0)
+    x = torch.empty(batch * n, dtype=torch.complex64, device="cuda")
+    torch.view_as_real(x).uniform_(-1, 1, generator=g)
+    y = torch.empty_like(x)
+    d = G.make_descriptor([n], batch=batch)
+    plan = d.commit()
+    plan.compute_forward(x, y).wait()
+    xs, ys = x.view(batch, n), y.view(batch, n)
+    for b in [0, 1, 4095, 32768, 65535] + list(np.random.default_rng(0).integers(0, batch, 27)):
+        ref = np.fft.fft(xs[b].cpu().numpy().astype(np.complex128))
+        assert H.rel_l2(ys[b].cpu().numpy(), ref) <= 2e-6, b
+    # Parseval, every batch
+    ex = (xs.abs().double() ** 2).sum(dim=1)
+    ey = (ys.abs().double() ** 2).sum(dim=1)
+    assert float(((ey / (n * ex)) - 1).abs().max()) < 1e-5
+    # round trip: backward(forward(x)) == N x
+    z = torch.empty_like(x)
+    plan.compute_backward(y, z).wait()
+    err = (z.view(batch, n) / n - xs).abs().double().pow(2).sum(dim=1).sqrt() / ex.sqrt()
+    assert float(err.max()) < 2e-6
+    # linearity: F(2x + w) == 2 F(x) + F(w)
+    w = torch.empty_like(x)
+    torch.view_as_real(w).uniform_(-1, 1, generator=g)
+    plan.compute_forward(w, z).wait()          # z = F(w)
+    w.add_(x, alpha=2.0)                       # w = 2x + w
+    x2 = torch.empty_like(x)
+    plan.compute_forward(w, x2).wait()         # x2 = F(2x + w)
+    lin = (x2 - 2 * y - z).view(batch, n).abs().double().pow(2).sum(dim=1).sqrt()
+    nrm = x2.view(batch, n).abs().double().pow(2).sum(dim=1).sqrt()
+    assert float((lin / nrm).max()) < 2e-6
