@@ -77,7 +77,18 @@ SYMBOLS = {
 }
 
 
+def _share_hip_runtime_with_torch():
+    """PyTorch-ROCm wheels bundle their own libamdhip64.so.7.  Two HIP runtimes in one process cannot both own the
+    GPU, so when torch is installed it is imported first: libportfft_amd.so's DT_NEEDED libamdhip64.so.7 then
+    resolves to the runtime torch already loaded (same SONAME) and streams / device pointers are shared."""
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
+
+
 def _load():
+    _share_hip_runtime_with_torch()
     if not os.path.exists(LIB_PATH):
         raise ImportError(
             "portfft_amd: %s is missing -- build it with `make -C portfft_amd/csrc` (or __graft_entry__.build()); "

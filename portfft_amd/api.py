@@ -200,6 +200,11 @@ def _ptr(x):
     return int(x)
 
 
+def _is_complex(x):
+    f = getattr(x, "is_complex", None)
+    return bool(f()) if callable(f) else False
+
+
 class committed_descriptor:
     """portfft::committed_descriptor<Scalar, Domain> (committed_descriptor.hpp:46-315)."""
 
@@ -223,7 +228,7 @@ class committed_descriptor:
         n = len(args)
         if n == 1:  # in-place interleaved (committed_descriptor.hpp:171-176, 215-218)
             _check(lib.pfft_execute(self._plan, int(dir), _ptr(args[0]), _ptr(args[0])))
-        elif n == 2 and self.params.complex_storage == complex_storage.SPLIT_COMPLEX:
+        elif n == 2 and self.params.complex_storage == complex_storage.SPLIT_COMPLEX and not _is_complex(args[0]):
             # in-place split (committed_descriptor.hpp:186-192, 228-232)
             _check(lib.pfft_execute_split(self._plan, int(dir), _ptr(args[0]), _ptr(args[1]), _ptr(args[0]),
                                           _ptr(args[1])))
