@@ -1,0 +1,170 @@
+#!/usr/bin/env python3
+"""Headline benchmark: BASELINE.json configs[1] -- fp32 C2C 1-D forward, N=4096, batch=65536 per GPU,
+out-of-place, inputs resident in HBM.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+A step is one pass of the hot path (one compute_forward over the whole batch).  Batches shard over GPUs with no
+data-path collective (weak scaling: every rank owns 65536 transforms); RCCL is used only for the barrier and the
+max-over-ranks of the elapsed time.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (ROOT, os.path.join(ROOT, "tests")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+N = 4096
+BATCH_PER_GPU = 65536
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+
+
+def cpu_baseline(sample_seconds=12.0):
+    """The oracle (CPU restatement of the reference algorithm, kind 'port') timed on this host's cores on a bounded
+    sample of the same workload: fp32 N=4096 forward, batch sized to take about `sample_seconds`."""
+    import numpy as np
+    import oracle_binding as ob
+
+    cores = max(1, min(os.cpu_count() or 1, ob.lib().pfo_max_threads()))
+    rng = np.random.Generator(np.random.SFC64(0))
+
+    def run(batch):
+        x = (rng.uniform(-1, 1, (batch, N)) + 1j * rng.uniform(-1, 1, (batch, N))).astype(np.complex64).ravel()
+        d = ob.make_desc([N], "f32", batch=batch)
+        t0 = time.perf_counter()
+        ob.compute(d, ob.FORWARD, x, threads=cores)
+        return time.perf_counter() - t0
+
+    probe = 16 * cores
+    run(probe)  # warm-up (page faults, twiddle cache)
+    t = run(probe)
+    batch = int(max(probe, min(65536, probe * sample_seconds / max(t, 1e-6))))
+    batch -= batch % cores
+    reps, total = 0, 0.0
+    while total < sample_seconds and reps < 64:  # many-core hosts finish the whole batch in ~2 s: repeat it
+        total += run(batch)
+        reps += 1
+    gflops = 5.0 * N * math.log2(N) * batch * reps / total / 1e9
+    return {"value": round(gflops, 3), "unit": "GFLOP/s", "cores": cores, "kind": "port",
+            "sample": "oracle/ (reference algorithm restated in C, OpenMP over transforms), fp32 C2C forward N=%d, "
+                      "batch=%d of the 65536 x %d passes, %.1f s" % (N, batch, reps, total)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import portfft_amd as pf
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    distributed = world > 1
+    if distributed:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+    if args.gpus != world and rank == 0 and distributed:
+        print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
+
+    dev = torch.device("cuda", torch.cuda.current_device())
+    # synthetic inputs resident in HBM: uniform(-1, 1) real and imaginary parts, two buffers rotated per step
+    gen = torch.Generator(device=dev).manual_seed(1234 + rank)
+    inputs = []
+    for _ in range(2):
+        x = torch.empty(BATCH_PER_GPU * N, dtype=torch.complex64, device=dev)
+        torch.view_as_real(x).uniform_(-1, 1, generator=gen)
+        inputs.append(x)
+    out = torch.empty(BATCH_PER_GPU * N, dtype=torch.complex64, device=dev)
+
+    desc = pf.descriptor([N], "f32")
+    desc.number_of_transforms = BATCH_PER_GPU
+    plan = desc.commit()  # torch's current stream: the torch.cuda.Event timers below see the kernels
+
+    def barrier():
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for w in range(args.warmup):
+        plan.compute_forward(inputs[w % 2], out)
+    barrier()
+    starts = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    stops = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        starts[k].record()
+        plan.compute_forward(inputs[k % 2], out)
+        stops[k].record()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    barrier()
+    if distributed:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    kernel_ms = [s.elapsed_time(e) for s, e in zip(starts, stops)]
+    avg_kernel_ms = sum(kernel_ms) / len(kernel_ms)
+
+    # parity spot check of the timed output (last step's input) against NumPy on 4 transforms
+    import numpy as np
+    last_in = inputs[(args.steps - 1) % 2].view(BATCH_PER_GPU, N)
+    worst = 0.0
+    for b in (0, 777, 40000, BATCH_PER_GPU - 1):
+        ref = np.fft.fft(last_in[b].cpu().numpy().astype(np.complex128))
+        got = out.view(BATCH_PER_GPU, N)[b].cpu().numpy()
+        worst = max(worst, float(np.linalg.norm(got - ref) / np.linalg.norm(ref)))
+    assert worst < 1e-4, "parity check failed: rel-L2 %g" % worst
+
+    if rank == 0:
+        flops_per_step = 5.0 * N * math.log2(N) * BATCH_PER_GPU * world
+        ms_per_step = elapsed / args.steps * 1e3
+        gflops = flops_per_step / (elapsed / args.steps) / 1e9
+        alg_bytes = 2.0 * N * BATCH_PER_GPU * 8  # per launch: every element read once + written once
+        achieved = alg_bytes / (avg_kernel_ms * 1e-3) / 1e9
+        result = {
+            "metric": "GFLOP/s (5Nlog2N) + achieved-HBM% for fp32 C2C 1D, 1/2/4/8 GPUs",
+            "value": round(gflops, 1),
+            "unit": "GFLOP/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 5),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: fp32 C2C 1D forward N=4096 batch=65536 per GPU, out-of-place, "
+                                   "interleaved, inputs resident in HBM", "n": N, "batch_per_gpu": BATCH_PER_GPU,
+                       "global_batch": BATCH_PER_GPU * world, "sharding": "batches, no data-path collective",
+                       "parity_rel_l2_vs_numpy": worst},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "kernel": "stockham_wg_kernel<f32, 16x16x16, wg256>", "kernel_ms": round(avg_kernel_ms, 5),
+                         "algorithmic_bytes_per_launch": alg_bytes},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(result))
+    if distributed:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

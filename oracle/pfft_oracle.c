@@ -259,7 +259,30 @@ int32_t pfo_prepare_implementation(int64_t fft_size, int32_t scalar_bytes, int32
  * ------------------------------------------------------------------------------------------------------------- */
 
 /* scripts/generate_twiddles.py:60-92: exact values on the axes, otherwise libm cos/sin of -2*pi*i/size in double */
+static double static_twiddle_compute(int32_t n, int32_t k, int32_t imag);
+/* the reference holds the values in a 65 x 65 constexpr table (common/twiddle.hpp:25-155); cache them the same way */
+static double g_tw_table[2][65][65];
+static int g_tw_ready = 0;
+static void static_twiddle_init(void) {
+  if (g_tw_ready) return;
+#pragma omp critical(pfo_tw_init)
+  {
+    if (!g_tw_ready) {
+      for (int n = 0; n < 65; ++n)
+        for (int k = 0; k < 65; ++k) {
+          g_tw_table[0][n][k] = static_twiddle_compute(n, k, 0);
+          g_tw_table[1][n][k] = static_twiddle_compute(n, k, 1);
+        }
+      g_tw_ready = 1;
+    }
+  }
+}
 double pfo_static_twiddle(int32_t n, int32_t k, int32_t imag) {
+  if (n < 0 || n > 64 || k < 0 || k > 64) return static_twiddle_compute(n, k, imag);
+  if (!g_tw_ready) static_twiddle_init();
+  return g_tw_table[imag ? 1 : 0][n][k];
+}
+static double static_twiddle_compute(int32_t n, int32_t k, int32_t imag) {
   if (n <= 0 || k < 0 || k >= n) return 0.0; /* zero padding of the table */
   if (k == 0) return imag ? 0.0 : 1.0;
   if (2 * k == n) return imag ? 0.0 : -1.0;
@@ -539,7 +562,7 @@ int32_t pfo_dft_1d(int32_t is_double, int64_t n, int32_t direction, int32_t forc
     double* by = (double*)malloc(sizeof(double) * 2 * (size_t)n);
     const double* i = (const double*)in;
     double* o = (double*)out;
-    one_transform_f64(i, i + 1, 2, o, o + 1, 2, n, 1, 1, backward, &impl, sg_size, 1.0, 0, bx, by);
+    one_transform_f64(i, i + 1, 2, o, o + 1, 2, n, 1, 1, backward, &impl, sg_size, 1.0, 0, bx, by, NULL);
     free(bx);
     free(by);
   } else {
@@ -547,7 +570,7 @@ int32_t pfo_dft_1d(int32_t is_double, int64_t n, int32_t direction, int32_t forc
     float* by = (float*)malloc(sizeof(float) * 2 * (size_t)n);
     const float* i = (const float*)in;
     float* o = (float*)out;
-    one_transform_f32(i, i + 1, 2, o, o + 1, 2, n, 1, 1, backward, &impl, sg_size, 1.0f, 0, bx, by);
+    one_transform_f32(i, i + 1, 2, o, o + 1, 2, n, 1, 1, backward, &impl, sg_size, 1.0f, 0, bx, by, NULL);
     free(bx);
     free(by);
   }
@@ -593,11 +616,23 @@ int32_t pfo_compute(const pfft_desc_t* d, int32_t direction, const void* in, voi
   const uint64_t last_len = d->lengths[rank - 1];
   const uint64_t outer_size = total / last_len;
   if (n_threads <= 0) n_threads = 1;
+  static_twiddle_init();
 
   /* element pointers: interleaved -> step 2 through one array; split -> step 1 through two arrays */
   const int step = split ? 1 : 2;
 #define RE_PTR(T, base, base_im, idx) (split ? ((T*)(base) + (idx)) : ((T*)(base) + 2 * (idx)))
 #define IM_PTR(T, base, base_im, idx) (split ? ((T*)(base_im) + (idx)) : ((T*)(base) + 2 * (idx) + 1))
+
+  /* commit-time twiddles, one set per dimension */
+  tables_f32 tabs32[PFFT_MAX_RANK];
+  tables_f64 tabs64[PFFT_MAX_RANK];
+  for (int i = 0; i < rank; ++i) {
+    if (is_double) {
+      make_tables_f64(&impls[i], &tabs64[i]);
+    } else {
+      make_tables_f32(&impls[i], &tabs32[i]);
+    }
+  }
 
   /* last dimension: number_of_transforms * outer_size transforms, input layout -> output layout (:923-925).
    * For rank 1 the user strides/distances apply; for rank > 1 the layout is PACKED. */
@@ -627,12 +662,12 @@ int32_t pfo_compute(const pfft_desc_t* d, int32_t direction, const void* in, voi
           one_transform_f64(RE_PTR(const double, in, in_imag, ib), IM_PTR(const double, in, in_imag, ib), step,
                             RE_PTR(double, out, out_imag, ob), IM_PTR(double, out, out_imag, ob), step, n,
                             (int64_t)istr, (int64_t)ostr, backward, &impls[rank - 1], sg_size, (double)scale_d,
-                            apply_scale, (double*)bx, (double*)by);
+                            apply_scale, (double*)bx, (double*)by, &tabs64[rank - 1]);
         } else {
           one_transform_f32(RE_PTR(const float, in, in_imag, ib), IM_PTR(const float, in, in_imag, ib), step,
                             RE_PTR(float, out, out_imag, ob), IM_PTR(float, out, out_imag, ob), step, n,
                             (int64_t)istr, (int64_t)ostr, backward, &impls[rank - 1], sg_size, (float)scale_d,
-                            apply_scale, (float*)bx, (float*)by);
+                            apply_scale, (float*)bx, (float*)by, &tabs32[rank - 1]);
         }
       }
       free(bx);
@@ -660,12 +695,12 @@ int32_t pfo_compute(const pfft_desc_t* d, int32_t direction, const void* in, voi
           one_transform_f64(RE_PTR(const double, out, out_imag, base), IM_PTR(const double, out, out_imag, base), step,
                             RE_PTR(double, out, out_imag, base), IM_PTR(double, out, out_imag, base), step, n,
                             (int64_t)cur_inner, (int64_t)cur_inner, backward, &impls[i], sg_size, 1.0, 0, (double*)bx,
-                            (double*)by);
+                            (double*)by, &tabs64[i]);
         } else {
           one_transform_f32(RE_PTR(const float, out, out_imag, base), IM_PTR(const float, out, out_imag, base), step,
                             RE_PTR(float, out, out_imag, base), IM_PTR(float, out, out_imag, base), step, n,
                             (int64_t)cur_inner, (int64_t)cur_inner, backward, &impls[i], sg_size, 1.0f, 0, (float*)bx,
-                            (float*)by);
+                            (float*)by, &tabs32[i]);
         }
       }
       free(bx);
@@ -675,5 +710,12 @@ int32_t pfo_compute(const pfft_desc_t* d, int32_t direction, const void* in, voi
   }
 #undef RE_PTR
 #undef IM_PTR
+  for (int i = 0; i < rank; ++i) {
+    if (is_double) {
+      free_tables_f64(&tabs64[i]);
+    } else {
+      free_tables_f32(&tabs32[i]);
+    }
+  }
   return PFFT_OK;
 }
