@@ -68,19 +68,17 @@ def main():
     import torch
     import portfft_amd as pf
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    from portfft_amd.sharding import env_world, process_group, shard_range
+
+    world, rank, local_rank = env_world()
     distributed = world > 1
-    if distributed:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    else:
-        torch.cuda.set_device(0)
-    if args.gpus != world and rank == 0 and distributed:
+    torch.cuda.set_device(local_rank if distributed else 0)
+    pg = process_group("nccl", torch.device("cuda", torch.cuda.current_device()))
+    if args.gpus != world and rank == 0:
         print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
+    # weak scaling: the global batch is BATCH_PER_GPU * world transforms, sharded contiguously
+    lo, hi = shard_range(BATCH_PER_GPU * world, world, rank)
+    assert hi - lo == BATCH_PER_GPU
 
     dev = torch.device("cuda", torch.cuda.current_device())
     # synthetic inputs resident in HBM: uniform(-1, 1) real and imaginary parts, two buffers rotated per step
@@ -96,10 +94,7 @@ def main():
     desc.number_of_transforms = BATCH_PER_GPU
     plan = desc.commit()  # torch's current stream: the torch.cuda.Event timers below see the kernels
 
-    def barrier():
-        if distributed:
-            dist.barrier()
-        torch.cuda.synchronize()
+    barrier = pg.barrier
 
     for w in range(args.warmup):
         plan.compute_forward(inputs[w % 2], out)
@@ -114,10 +109,7 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     barrier()
-    if distributed:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = pg.max(elapsed)
     kernel_ms = [s.elapsed_time(e) for s, e in zip(starts, stops)]
     avg_kernel_ms = sum(kernel_ms) / len(kernel_ms)
 
@@ -162,8 +154,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline()
         print(json.dumps(result))
-    if distributed:
-        dist.destroy_process_group()
+    pg.close()
 
 
 if __name__ == "__main__":
