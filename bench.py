@@ -26,6 +26,23 @@ BATCH_PER_GPU = 65536
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 
 
+def pmc_traffic():
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE x2 on gfx950 +
+    WRITE_SIZE, see tools/summarize_pmc.py and profiles/r*_pmc_traffic.json); None when no summary is committed.
+    PMC counters cannot be collected from inside this process, so the figure comes from the same command run under
+    rocprofv3 --pmc and is reported with its provenance."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
+    if not files:
+        return None, None
+    try:
+        with open(files[-1]) as f:
+            d = json.load(f)
+        return float(d["traffic_bytes_per_launch"]), os.path.relpath(files[-1], ROOT)
+    except (OSError, ValueError, KeyError):
+        return None, None
+
+
 def cpu_baseline(sample_seconds=12.0):
     """The oracle (CPU restatement of the reference algorithm, kind 'port') timed on this host's cores on a bounded
     sample of the same workload: fp32 N=4096 forward, batch sized to take about `sample_seconds`."""
@@ -129,6 +146,7 @@ def main():
         gflops = flops_per_step / (elapsed / args.steps) / 1e9
         alg_bytes = 2.0 * N * BATCH_PER_GPU * 8  # per launch: every element read once + written once
         achieved = alg_bytes / (avg_kernel_ms * 1e-3) / 1e9
+        traffic, traffic_src = pmc_traffic()
         result = {
             "metric": "GFLOP/s (5Nlog2N) + achieved-HBM% for fp32 C2C 1D, 1/2/4/8 GPUs",
             "value": round(gflops, 1),
@@ -147,7 +165,8 @@ def main():
                        "global_batch": BATCH_PER_GPU * world, "sharding": "batches, no data-path collective",
                        "parity_rel_l2_vs_numpy": worst},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "traffic_source": traffic_src,
                          "kernel": "stockham_wg_kernel<f32, 16x16x16, wg256>", "kernel_ms": round(avg_kernel_ms, 5),
                          "algorithmic_bytes_per_launch": alg_bytes},
         }

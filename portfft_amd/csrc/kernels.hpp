@@ -9,6 +9,7 @@
 #include <cstddef>
 
 #include "generic_args.hpp"
+#include "strided_args.hpp"
 
 namespace pfa {
 
@@ -26,6 +27,22 @@ struct spec_kernel {
   hipError_t (*launch)(hipStream_t stream, unsigned grid, const void* in, void* out, const void* tw, long long nfft,
                        double scale, int backward);
 };
+
+/// One strided work-group kernel (stockham_strided.hpp): FPW FFTs side by side, any element stride / FFT distance.
+struct strided_kernel {
+  int precision;
+  int n;
+  int wg;
+  int fpw;
+  size_t lds_bytes;
+  int n_radices;
+  int radices[8];
+  const void* fn[4];  // [backward * 2 + store_modifier]
+  hipError_t (*launch)(hipStream_t stream, unsigned grid, const strided_args& args, int backward, int store_modifier);
+};
+
+const strided_kernel* strided_kernels_f32(int* count);
+const strided_kernel* strided_kernels_f64(int* count);
 
 const spec_kernel* spec_kernels_f32(int* count);
 const spec_kernel* spec_kernels_f64(int* count);

@@ -3,6 +3,7 @@
 #include "../../include/portfft_amd.h"
 #include "generic_kernel.hpp"
 #include "kernels.hpp"
+#include "stockham_strided.hpp"
 #include "stockham_wg.hpp"
 
 namespace pfa {
@@ -38,6 +39,44 @@ spec_kernel make_spec_entry() {
   k.fn[0] = reinterpret_cast<const void*>(&stockham_wg_kernel<Cfg, false>);
   k.fn[1] = reinterpret_cast<const void*>(&stockham_wg_kernel<Cfg, true>);
   k.launch = &launch_spec<Cfg>;
+  return k;
+}
+
+template <typename Cfg>
+hipError_t launch_strided(hipStream_t stream, unsigned grid, const strided_args& args, int backward, int stw) {
+  constexpr size_t lds = strided_lds_bytes<Cfg>();
+  const dim3 g(grid), b(Cfg::WG);
+  if (backward) {
+    if (stw) {
+      hipLaunchKernelGGL((stockham_strided_kernel<Cfg, true, true>), g, b, lds, stream, args);
+    } else {
+      hipLaunchKernelGGL((stockham_strided_kernel<Cfg, true, false>), g, b, lds, stream, args);
+    }
+  } else {
+    if (stw) {
+      hipLaunchKernelGGL((stockham_strided_kernel<Cfg, false, true>), g, b, lds, stream, args);
+    } else {
+      hipLaunchKernelGGL((stockham_strided_kernel<Cfg, false, false>), g, b, lds, stream, args);
+    }
+  }
+  return hipGetLastError();
+}
+
+template <typename Cfg>
+strided_kernel make_strided_entry() {
+  strided_kernel k{};
+  k.precision = sizeof(typename Cfg::T) == 8 ? PFFT_PRECISION_F64 : PFFT_PRECISION_F32;
+  k.n = Cfg::N;
+  k.wg = Cfg::WG;
+  k.fpw = Cfg::FPW;
+  k.lds_bytes = strided_lds_bytes<Cfg>();
+  k.n_radices = Cfg::NP;
+  for (int i = 0; i < Cfg::NP; ++i) k.radices[i] = Cfg::Seq::r[i];
+  k.fn[0] = reinterpret_cast<const void*>(&stockham_strided_kernel<Cfg, false, false>);
+  k.fn[1] = reinterpret_cast<const void*>(&stockham_strided_kernel<Cfg, false, true>);
+  k.fn[2] = reinterpret_cast<const void*>(&stockham_strided_kernel<Cfg, true, false>);
+  k.fn[3] = reinterpret_cast<const void*>(&stockham_strided_kernel<Cfg, true, true>);
+  k.launch = &launch_strided<Cfg>;
   return k;
 }
 

@@ -12,6 +12,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <vector>
@@ -41,6 +42,9 @@ struct addressing {
 struct stage {
   bool generic = false;
   const spec_kernel* spec = nullptr;
+  const strided_kernel* strided = nullptr;
+  strided_args sa{};
+  int store_modifier = 0;
   int in_buf = BUF_IN, out_buf = BUF_OUT;
   long long count = 0;  // number of FFTs
   unsigned grid = 1;
@@ -55,6 +59,11 @@ struct stage {
   size_t lds_bytes = 0;
   // info
   int n = 0;
+  // GLOBAL tier: the stages of one transform run chunk by chunk so that the intermediate stays cache resident
+  int chunk_group = -1;            // stages with the same id advance together
+  long long ffts_per_batch = 0;    // FFTs this stage runs per user transform
+  long long in_batch_dist = 0;     // elements between consecutive user transforms in the stage's input (0: scratch)
+  long long out_batch_dist = 0;
 };
 
 const double PI_L = 3.14159265358979323846264338327950288;
@@ -154,6 +163,8 @@ struct plan_t {
   void* scratch = nullptr;
   size_t scratch_bytes = 0;
   size_t twiddle_bytes = 0;
+  long long chunk_batches = 0;  // user transforms per chunk of the GLOBAL tier
+  int n_chunk_groups = 0;
   pfft_plan_info_t info{};
 
   int scalar_bytes() const { return desc.precision == PFFT_PRECISION_F64 ? 8 : 4; }
@@ -214,6 +225,79 @@ struct plan_t {
       if (k[i].n == n && k[i].lds_bytes <= max_lds) return &k[i];
     }
     return nullptr;
+  }
+
+  const strided_kernel* find_strided(long long n) const {
+    int count = 0;
+    const strided_kernel* k =
+        desc.precision == PFFT_PRECISION_F64 ? strided_kernels_f64(&count) : strided_kernels_f32(&count);
+    for (int i = 0; i < count; ++i) {
+      if (k[i].n == n && k[i].lds_bytes <= max_lds) return &k[i];
+    }
+    return nullptr;
+  }
+
+  /// can the strided kernel `k` address this stage?  (interleaved data, whole groups, 32-bit byte ranges)
+  bool strided_fits(const strided_kernel* k, long long inner_count, int in_buf, const addressing& ia, int out_buf,
+                    const addressing& oa) const {
+    if (k == nullptr) return false;
+    const bool split = desc.complex_storage == PFFT_SPLIT_COMPLEX;
+    if (split && (in_buf != BUF_SCRATCH || out_buf != BUF_SCRATCH)) return false;
+    if (inner_count % k->fpw != 0) return false;
+    auto range_ok = [&](const addressing& a) {
+      const unsigned long long elems = static_cast<unsigned long long>(k->fpw - 1) * a.dist_inner +
+                                       static_cast<unsigned long long>(k->n - 1) * a.stride + 1;
+      return a.stride < (1ll << 31) && a.dist_inner < (1ll << 31) && elems * elem_bytes() < 0xFFFFFFF0ull;
+    };
+    return range_ok(ia) && range_ok(oa);
+  }
+
+  stage make_strided_stage(const strided_kernel* k, long long count, long long inner_count, int in_buf,
+                           const addressing& ia, int out_buf, const addressing& oa, double scale, int backward) {
+    stage s;
+    s.strided = k;
+    s.n = k->n;
+    s.in_buf = in_buf;
+    s.out_buf = out_buf;
+    s.count = count;
+    s.in_addr = ia;
+    s.out_addr = oa;
+    s.backward = backward;
+    strided_args& a = s.sa;
+    a.tw = upload_twiddles(std::vector<int>(k->radices, k->radices + k->n_radices));
+    a.total = count;
+    a.inner = std::max<long long>(inner_count, 1);
+    a.in_dist_outer = ia.dist_outer;
+    a.out_dist_outer = oa.dist_outer;
+    a.in_stride = static_cast<unsigned>(ia.stride);
+    a.out_stride = static_cast<unsigned>(oa.stride);
+    a.in_fdist = static_cast<unsigned>(ia.dist_inner);
+    a.out_fdist = static_cast<unsigned>(oa.dist_inner);
+    a.scale = scale;
+    a.stw_lo = nullptr;
+    a.stw_hi = nullptr;
+    a.stw_shift = 0;
+    s.lds_bytes = k->lds_bytes;
+    for (int i = 0; i < 4; ++i) {
+      if (k->lds_bytes > 48 * 1024) {
+        hip_check(hipFuncSetAttribute(k->fn[i], hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      static_cast<int>(k->lds_bytes)),
+                  "hipFuncSetAttribute");
+      }
+    }
+    s.grid = persistent_grid(k->fn[backward * 2], k->wg, k->lds_bytes, (count + k->fpw - 1) / k->fpw);
+    return s;
+  }
+
+  /// bytes of intermediate data per chunk of the GLOBAL tier = cap of the scratch allocation
+  /// (PFFT_GLOBAL_CHUNK_MIB overrides; 0 = unbounded)
+  static size_t global_chunk_bytes() {
+    if (const char* e = getenv("PFFT_GLOBAL_CHUNK_MIB")) {
+      const long v = std::atol(e);
+      if (v <= 0) return ~size_t{0} >> 1;
+      return static_cast<size_t>(v) << 20;
+    }
+    return size_t{4} << 30;
   }
 
   /// largest length the generic tier can hold (two LDS images)
@@ -338,6 +422,15 @@ struct plan_t {
         return PFFT_TIER_WORKGROUP;
       }
     }
+    // the strided tier pays when at least one side is "column" shaped (consecutive FFTs adjacent in memory)
+    const bool column_shaped = ia.dist_inner == 1 || oa.dist_inner == 1;
+    if (const strided_kernel* k = find_strided(n);
+        column_shaped && strided_fits(k, inner_count, in_buf, ia, out_buf, oa)) {
+      out.push_back(make_strided_stage(k, count, inner_count, in_buf, ia, out_buf, oa, scale, backward));
+      record(PFFT_TIER_WORKGROUP, std::vector<int>(k->radices, k->radices + k->n_radices), k->wg, k->fpw,
+             k->lds_bytes);
+      return PFFT_TIER_WORKGROUP;
+    }
     if (n <= generic_max_n()) {
       stage s = make_generic_stage(n, count, inner_count, in_buf, ia, out_buf, oa, scale, backward, backward);
       record(PFFT_TIER_GENERIC, std::vector<int>(s.ga.radix, s.ga.radix + s.ga.n_passes), GENERIC_WG, s.ga.fpw,
@@ -354,8 +447,15 @@ struct plan_t {
     }
     const long long gmax = generic_max_n();
     long long n1 = 0;
-    // most balanced split whose two lengths both run on the generic tier
+    // most balanced split whose two lengths both have a strided work-group kernel ...
     for (long long c = static_cast<long long>(std::sqrt(static_cast<double>(n))); c >= 2; --c) {
+      if (n % c == 0 && find_strided(c) != nullptr && find_strided(n / c) != nullptr) {
+        n1 = c;
+        break;
+      }
+    }
+    // ... otherwise the most balanced split whose two lengths both run on the generic tier
+    for (long long c = static_cast<long long>(std::sqrt(static_cast<double>(n))); n1 == 0 && c >= 2; --c) {
       if (n % c == 0 && n / c <= gmax && !choose_radices(c).empty() && !choose_radices(n / c).empty()) {
         n1 = c;
         break;
@@ -366,24 +466,66 @@ struct plan_t {
            " (large prime factors are not supported)");
     }
     const long long n2 = n / n1;
-    const size_t need = static_cast<size_t>(count) * static_cast<size_t>(n) * elem_bytes();
+    // Chunking (the reference's num_batches_in_l2 idea, committed_descriptor_impl.hpp:603-611) bounds the scratch.
+    // Measured on MI355X (profiles/r1_notes.md): cache-sized chunks (16-256 MiB) do NOT make stage B's reads hit the
+    // Infinity Cache -- they only shrink the launches -- so the default chunk is as large as the scratch cap allows.
+    const size_t per_transform = static_cast<size_t>(n) * elem_bytes();
+    long long chunk = static_cast<long long>(global_chunk_bytes() / per_transform);
+    chunk = std::max<long long>(1, std::min<long long>(chunk, count));
+    chunk_batches = chunk;
+    const int group_id = n_chunk_groups++;
+    const size_t need = static_cast<size_t>(chunk) * per_transform;
     scratch_bytes = std::max(scratch_bytes, need);
     // stage A: for every batch b and column c: length-n1 FFT over rows (stride n2), x W_n^{k1*c}, same layout out
     addressing a_in{ia.offset, n2, 1, n};
     addressing a_out{0, n2, 1, n};
-    stage sa = make_generic_stage(n1, count * n2, n2, in_buf, a_in, BUF_SCRATCH, a_out, 1.0, backward, 0);
     int shift = 0;
     while ((1ll << (2 * shift)) < n) ++shift;
-    upload_store_twiddles(n, shift, &sa.ga.stw_lo, &sa.ga.stw_hi);
-    sa.ga.stw_shift = shift;
+    const void* stw_lo = nullptr;
+    const void* stw_hi = nullptr;
+    upload_store_twiddles(n, shift, &stw_lo, &stw_hi);
+    const strided_kernel* ka = find_strided(n1);
+    const strided_kernel* kb = find_strided(n2);
+    const bool interleaved_user = desc.complex_storage == PFFT_INTERLEAVED_COMPLEX;
+    const char* dbg = getenv("PFFT_DEBUG_GLOBAL");  // debugging aid: "ga" / "gb" force the generic kernel for a stage
+    const bool force_generic_a = dbg != nullptr && std::strstr(dbg, "ga") != nullptr;
+    const bool force_generic_b = dbg != nullptr && std::strstr(dbg, "gb") != nullptr;
+    stage sa;
+    if (!force_generic_a && interleaved_user && strided_fits(ka, n2, in_buf, a_in, BUF_SCRATCH, a_out)) {
+      // conjugating on load and store in both stages is the identity in between, so the backward transform can use
+      // the kernels' BWD form on both
+      sa = make_strided_stage(ka, count * n2, n2, in_buf, a_in, BUF_SCRATCH, a_out, 1.0, backward);
+      sa.sa.stw_lo = stw_lo;
+      sa.sa.stw_hi = stw_hi;
+      sa.sa.stw_shift = shift;
+      sa.store_modifier = 1;
+    } else {
+      sa = make_generic_stage(n1, count * n2, n2, in_buf, a_in, BUF_SCRATCH, a_out, 1.0, backward, backward);
+      sa.ga.stw_lo = stw_lo;
+      sa.ga.stw_hi = stw_hi;
+      sa.ga.stw_shift = shift;
+    }
+    sa.chunk_group = group_id;
+    sa.ffts_per_batch = n2;
+    sa.in_batch_dist = n;
+    sa.out_batch_dist = 0;
     out.push_back(sa);
     // stage B: for every batch b and row k1: length-n2 FFT (contiguous), output X[k1 + n1*k2]
     addressing b_in{0, 1, n2, n};
     addressing b_out{oa.offset, n1, 1, n};
-    stage sb = make_generic_stage(n2, count * n1, n1, BUF_SCRATCH, b_in, out_buf, b_out, scale, 0, backward);
+    stage sb;
+    if (!force_generic_b && interleaved_user && strided_fits(kb, n1, BUF_SCRATCH, b_in, out_buf, b_out)) {
+      sb = make_strided_stage(kb, count * n1, n1, BUF_SCRATCH, b_in, out_buf, b_out, scale, backward);
+    } else {
+      sb = make_generic_stage(n2, count * n1, n1, BUF_SCRATCH, b_in, out_buf, b_out, scale, backward, backward);
+    }
+    sb.chunk_group = group_id;
+    sb.ffts_per_batch = n1;
+    sb.in_batch_dist = 0;
+    sb.out_batch_dist = n;
     out.push_back(sb);
-    record(PFFT_TIER_GLOBAL, {static_cast<int>(n1), static_cast<int>(n2)}, GENERIC_WG, sb.ga.fpw,
-           std::max(sa.lds_bytes, sb.lds_bytes));
+    record(PFFT_TIER_GLOBAL, {static_cast<int>(n1), static_cast<int>(n2)}, sb.generic ? GENERIC_WG : kb->wg,
+           sb.generic ? sb.ga.fpw : kb->fpw, std::max(sa.lds_bytes, sb.lds_bytes));
     return PFFT_TIER_GLOBAL;
   }
 
@@ -448,7 +590,12 @@ struct plan_t {
     info.scratch_bytes = scratch_bytes;
   }
 
-  void run_stage(const stage& s, const void* in_re, const void* in_im, void* out_re, void* out_im) {
+  /// run stage `s` for the user transforms [b0, b0 + nb) (chunked stages) or entirely (nb < 0)
+  void run_stage(const stage& s, const void* in_re, const void* in_im, void* out_re, void* out_im, long long b0 = 0,
+                 long long nb = -1) {
+    const long long in_shift = nb < 0 ? 0 : b0 * s.in_batch_dist;    // elements
+    const long long out_shift = nb < 0 ? 0 : b0 * s.out_batch_dist;  // elements
+    const long long count = nb < 0 ? s.count : nb * s.ffts_per_batch;
     const size_t sb = static_cast<size_t>(scalar_bytes());
     const bool split = desc.complex_storage == PFFT_SPLIT_COMPLEX;
     // resolve buffers: user buffers follow the descriptor's storage, scratch is always interleaved
@@ -464,6 +611,17 @@ struct plan_t {
       return split ? static_cast<const char*>(out_im) : static_cast<const char*>(out_re) + sb;
     };
     auto step_of = [&](int buf) { return (buf == BUF_SCRATCH || !split) ? 2 : 1; };
+    if (s.strided != nullptr) {
+      strided_args a = s.sa;
+      a.total = count;
+      a.in = base_re(s.in_buf, true) + static_cast<size_t>(s.in_addr.offset + in_shift) * elem_bytes();
+      a.out = const_cast<char*>(base_re(s.out_buf, false)) +
+              static_cast<size_t>(s.out_addr.offset + out_shift) * elem_bytes();
+      const long long groups = (count + s.strided->fpw - 1) / s.strided->fpw;
+      const unsigned grid = static_cast<unsigned>(std::min<long long>(s.grid, std::max<long long>(groups, 1)));
+      hip_check(s.strided->launch(stream, grid, a, s.backward, s.store_modifier), "kernel launch");
+      return;
+    }
     if (!s.generic) {
       const char* i = base_re(s.in_buf, true) + static_cast<size_t>(s.in_offset) * elem_bytes();
       char* o = const_cast<char*>(base_re(s.out_buf, false)) + static_cast<size_t>(s.out_offset) * elem_bytes();
@@ -471,14 +629,15 @@ struct plan_t {
       return;
     }
     generic_args g = s.ga;
+    g.total_count = count;
     g.in_step = step_of(s.in_buf);
     g.out_step = step_of(s.out_buf);
-    g.in_re = base_re(s.in_buf, true) + static_cast<size_t>(s.in_addr.offset) * sb * static_cast<size_t>(g.in_step);
-    g.in_im = base_im(s.in_buf) + static_cast<size_t>(s.in_addr.offset) * sb * static_cast<size_t>(g.in_step);
-    g.out_re = const_cast<char*>(base_re(s.out_buf, false)) +
-               static_cast<size_t>(s.out_addr.offset) * sb * static_cast<size_t>(g.out_step);
-    g.out_im = const_cast<char*>(base_im(s.out_buf)) +
-               static_cast<size_t>(s.out_addr.offset) * sb * static_cast<size_t>(g.out_step);
+    const size_t ioff = static_cast<size_t>(s.in_addr.offset + in_shift);
+    const size_t ooff = static_cast<size_t>(s.out_addr.offset + out_shift);
+    g.in_re = base_re(s.in_buf, true) + ioff * sb * static_cast<size_t>(g.in_step);
+    g.in_im = base_im(s.in_buf) + ioff * sb * static_cast<size_t>(g.in_step);
+    g.out_re = const_cast<char*>(base_re(s.out_buf, false)) + ooff * sb * static_cast<size_t>(g.out_step);
+    g.out_im = const_cast<char*>(base_im(s.out_buf)) + ooff * sb * static_cast<size_t>(g.out_step);
     const hipError_t e = desc.precision == PFFT_PRECISION_F64 ? launch_generic_f64(stream, s.grid, s.lds_bytes, g)
                                                               : launch_generic_f32(stream, s.grid, s.lds_bytes, g);
     hip_check(e, "kernel launch");
@@ -489,7 +648,22 @@ struct plan_t {
       fail(PFFT_INVALID_CONFIGURATION, "Invalid direction ", direction);
     }
     if (in_re == nullptr || out_re == nullptr) fail(PFFT_INVALID_CONFIGURATION, "null data pointer");
-    for (const stage& s : stages[direction]) run_stage(s, in_re, in_im, out_re, out_im);
+    const std::vector<stage>& st = stages[direction];
+    for (size_t i = 0; i < st.size();) {
+      if (st[i].chunk_group < 0) {
+        run_stage(st[i], in_re, in_im, out_re, out_im);
+        ++i;
+        continue;
+      }
+      size_t j = i;
+      while (j < st.size() && st[j].chunk_group == st[i].chunk_group) ++j;
+      const long long batches = st[i].count / st[i].ffts_per_batch;
+      for (long long b0 = 0; b0 < batches; b0 += chunk_batches) {
+        const long long nb = std::min(chunk_batches, batches - b0);
+        for (size_t k = i; k < j; ++k) run_stage(st[k], in_re, in_im, out_re, out_im, b0, nb);
+      }
+      i = j;
+    }
   }
 };
 

@@ -124,6 +124,12 @@ PFA_DEV void buf_store(cx<T> v, __amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsi
     __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(buf_b64_t, v), rsrc, voff, soff, AUX);
   } else {
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(buf_b128_t, v), rsrc, voff, soff, AUX);
+    // gfx950 hazard (observed, ROCm 7.2): a >64-bit buffer store with an SGPR soffset still reads its data VGPRs for
+    // two more cycles; hipcc only pads the soffset-immediate form, so a VALU write to the data registers right
+    // behind the store corrupts the last quad of every 16-lane row.  Pad by hand.
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_nop 1");
+    __builtin_amdgcn_sched_barrier(0);
   }
 }
 

@@ -1,0 +1,23 @@
+// Launch-time arguments of the strided work-group tier (plain C++: shared by the host planner and the kernel).
+#pragma once
+
+namespace pfa {
+
+/// Launch-time description of a strided stage (all counts in complex elements).
+/// FFT t: (o, c) = (t / inner, t % inner); its element i lives at  o * dist_outer + c * fdist + i * stride.
+struct strided_args {
+  const void* in;
+  void* out;
+  const void* tw;
+  long long total;  // number of FFTs
+  long long inner;  // FFTs per outer index; must be a multiple of the kernel's FPW
+  long long in_dist_outer, out_dist_outer;
+  unsigned in_stride, out_stride;  // element stride inside one FFT
+  unsigned in_fdist, out_fdist;    // distance between consecutive FFTs of a group
+  double scale;
+  const void* stw_lo;
+  const void* stw_hi;
+  int stw_shift;
+};
+
+}  // namespace pfa

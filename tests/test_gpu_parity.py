@@ -182,6 +182,49 @@ def test_multidimensional(prec, oracle):
     _check(got.reshape(2, -1), ref.reshape(2, -1), 16 * 512, dtype, "nd vs oracle")
 
 
+@pytest.mark.parametrize("prec", ["f32", "f64"])
+def test_strided_workgroup_tier(prec, oracle):
+    """lengths and batch counts that route through the strided work-group kernels (stockham_strided.hpp):
+    batch-interleaved on either or both sides, N-D outer dimensions, the two four-step stages of large 1-D
+    transforms; ragged groups and offsets included"""
+    import gpu_utils as G
+    pf = _pf()
+    dtype = np.complex64 if prec == "f32" else np.complex128
+    for n in (64, 128, 256, 512, 1024, 2048):
+        for batch in (32, 96, 160):
+            x, y = H.gen_fourier_data(batch, [n], dtype)
+            for place, lin, lout in PLACEMENT_LAYOUTS[1:]:
+                for direction in (F, B):
+                    d = _layout_desc(G, n, prec, batch, place, lin, lout, direction, 0)
+                    d.forward_offset, d.backward_offset = (5, 5) if place == 0 else (3, 11)
+                    src, ref = (x, y) if direction == F else (y, x.astype(np.complex128) * n)
+                    got, _ = G.transform_packed(d, pf.direction(direction), src)
+                    _check(got, ref, n, dtype, ("strided tier", prec, n, batch, place, lin, lout, direction))
+                    if "BI" in (lin, lout):
+                        info = d.commit().info()
+                        assert info.dims[0].tier == 1, (n, batch, lin, lout, info.dims[0].tier)
+    for dims in ([256, 256], [64, 1024], [1024, 64], [32, 128, 64]):
+        n = int(np.prod(dims))
+        x, y = H.gen_fourier_data(2, dims, dtype)
+        for place in (0, 1):
+            d = G.make_descriptor(dims, prec, batch=2, placement=place, bwd_scale=0.5)
+            got, _ = G.transform_packed(d, pf.direction.FORWARD, x)
+            _check(got.reshape(2, -1), y.reshape(2, -1), n, dtype, ("nd strided fwd", dims, place))
+            back, _ = G.transform_packed(d, pf.direction.BACKWARD, y)
+            _check(back.reshape(2, -1), x.reshape(2, -1).astype(np.complex128) * n * 0.5, n, dtype, ("nd strided bwd", dims))
+    for n in (65536, 1 << 20, 1 << 18):
+        x, y = H.gen_fourier_data(2, [n], dtype, seed=4)
+        d = G.make_descriptor([n], prec, batch=2, fwd_scale=2.0)
+        got, _ = G.transform_packed(d, pf.direction.FORWARD, x)
+        _check(got, 2.0 * y, n, dtype, ("four-step strided", prec, n))
+        back, _ = G.transform_packed(d, pf.direction.BACKWARD, y)
+        _check(back, x.astype(np.complex128) * n, n, dtype, ("four-step strided bwd", prec, n))
+    x, _ = H.gen_fourier_data(1, [65536], dtype, seed=9)
+    got, _ = G.transform_packed(G.make_descriptor([65536], prec), pf.direction.FORWARD, x)
+    ref = oracle.compute(oracle.make_desc([65536], prec), F, x.ravel()).reshape(x.shape)
+    _check(got, ref, 65536, dtype, "four-step vs oracle")
+
+
 def test_offsets():
     """Offsets* suites (instantiate_fft_tests.hpp:187-218): data starts at an offset; everything before the
     output offset must stay untouched"""
