@@ -31,7 +31,14 @@ struct generic_args {
   const void* stw_lo;
   const void* stw_hi;
   int stw_shift;
+  /// exact division by small runtime constants without integer-divide sequences:
+  /// e / d == (e * magic(d)) >> 40 for e < 2^24, d < 2^16   (magic(d) = floor(2^40 / d) + 1)
+  unsigned long long magic_n, magic_fpw;
+  unsigned long long magic_nb[GENERIC_MAX_PASSES];
+  unsigned long long magic_ns[GENERIC_MAX_PASSES];
 };
+
+inline unsigned long long generic_magic(unsigned d) { return ((1ull << 40) / d) + 1; }
 
 /// radices the generic kernel can run; the planner factorises lengths into these (plan.cpp: choose_radices)
 #define PFA_GENERIC_RADICES(X) \

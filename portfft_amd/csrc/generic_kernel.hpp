@@ -15,15 +15,20 @@
 
 namespace pfa {
 
+PFA_DEV unsigned fast_div(unsigned e, unsigned long long magic) {
+  return static_cast<unsigned>((static_cast<unsigned long long>(e) * magic) >> 40);
+}
+
 template <int R, typename T>
-PFA_DEV void generic_butterfly(const cx<T>* __restrict__ a, cx<T>* __restrict__ b, int j, int nb, int ns,
-                               const cx<T>* __restrict__ tw) {
+PFA_DEV void generic_butterfly(const cx<T>* __restrict__ a, cx<T>* __restrict__ b, unsigned j, unsigned nb,
+                               unsigned ns, unsigned long long magic_ns, const cx<T>* __restrict__ tw) {
   cx<T> v[R];
   sfor<0, R>([&](auto t_) PFA_LAMBDA {
     constexpr int t = decltype(t_)::value;
     v[t] = a[j + t * nb];
   });
-  const int q = j % ns;
+  const unsigned jq = fast_div(j, magic_ns);
+  const unsigned q = j - jq * ns;
   if (ns > 1) {
     sfor<1, R>([&](auto t_) PFA_LAMBDA {
       constexpr int t = decltype(t_)::value;
@@ -31,7 +36,7 @@ PFA_DEV void generic_butterfly(const cx<T>* __restrict__ a, cx<T>* __restrict__ 
     });
   }
   dft<R>(v);
-  const int base = (j / ns) * (ns * R) + q;
+  const unsigned base = jq * (ns * R) + q;
   sfor<0, R>([&](auto u_) PFA_LAMBDA {
     constexpr int u = decltype(u_)::value;
     b[base + u * ns] = v[u];
@@ -43,9 +48,9 @@ __global__ __launch_bounds__(GENERIC_WG) void generic_fft_kernel(const generic_a
   extern __shared__ __attribute__((aligned(16))) char pfa_smem_generic[];
   cx<T>* A = reinterpret_cast<cx<T>*>(pfa_smem_generic);
   cx<T>* B = A + static_cast<size_t>(p.fpw) * p.n;
-  const int tid = threadIdx.x;
-  const int n = p.n;
-  const int fpw = p.fpw;
+  const unsigned tid = threadIdx.x;
+  const unsigned n = p.n;
+  const unsigned fpw = p.fpw;
   const T* __restrict__ in_re = static_cast<const T*>(p.in_re);
   const T* __restrict__ in_im = static_cast<const T*>(p.in_im);
   T* __restrict__ out_re = static_cast<T*>(p.out_re);
@@ -55,14 +60,29 @@ __global__ __launch_bounds__(GENERIC_WG) void generic_fft_kernel(const generic_a
   const T scale = static_cast<T>(p.scale);
 
   for (long long g = blockIdx.x; g < ngroups; g += gridDim.x) {
+    // position of the group's first FFT: one 64-bit division per group, none per element
+    const long long t0 = g * fpw;
+    const long long o0 = t0 / p.inner_count;
+    const long long c0 = t0 - o0 * p.inner_count;
+    const long long left = p.total_count - t0;
+    const unsigned nf = left < static_cast<long long>(fpw) ? static_cast<unsigned>(left) : fpw;
     // ---- stage in ----
-    for (int e = tid; e < fpw * n; e += GENERIC_WG) {
-      const int f = p.in_f_fast ? e % fpw : e / n;
-      const int i = p.in_f_fast ? e / fpw : e % n;
-      const long long t = g * fpw + f;
-      if (t < p.total_count) {
-        const long long idx = (t / p.inner_count) * p.in_dist_outer + (t % p.inner_count) * p.in_dist_inner +
-                              static_cast<long long>(i) * p.in_stride;
+    for (unsigned e = tid; e < fpw * n; e += GENERIC_WG) {
+      unsigned f, i;
+      if (p.in_f_fast) {
+        i = fast_div(e, p.magic_fpw);
+        f = e - i * fpw;
+      } else {
+        f = fast_div(e, p.magic_n);
+        i = e - f * n;
+      }
+      if (f < nf) {
+        long long c = c0 + f, o = o0;
+        while (c >= p.inner_count) {
+          c -= p.inner_count;
+          ++o;
+        }
+        const long long idx = o * p.in_dist_outer + c * p.in_dist_inner + static_cast<long long>(i) * p.in_stride;
         cx<T> x = {in_re[idx * p.in_step], in_im[idx * p.in_step]};
         if (p.conj_in) x.im = -x.im;
         A[f * n + i] = x;
@@ -72,20 +92,22 @@ __global__ __launch_bounds__(GENERIC_WG) void generic_fft_kernel(const generic_a
     // ---- Stockham passes, LDS image A -> B ----
     cx<T>* src = A;
     cx<T>* dst = B;
-    int ns = 1;
+    unsigned ns = 1;
     for (int pass = 0; pass < p.n_passes; ++pass) {
-      const int R = p.radix[pass];
-      const int nb = n / R;
+      const unsigned R = p.radix[pass];
+      const unsigned nb = n / R;
+      const unsigned long long mnb = p.magic_nb[pass];
+      const unsigned long long mns = p.magic_ns[pass];
       const cx<T>* twp = tw + p.tw_off[pass];
-      for (int w = tid; w < fpw * nb; w += GENERIC_WG) {
-        const int f = w / nb;
-        const int j = w % nb;
+      for (unsigned w = tid; w < nf * nb; w += GENERIC_WG) {
+        const unsigned f = fast_div(w, mnb);
+        const unsigned j = w - f * nb;
         const cx<T>* a = src + f * n;
         cx<T>* b = dst + f * n;
         switch (R) {
-#define PFA_CASE(r)                            \
-  case r:                                      \
-    generic_butterfly<r>(a, b, j, nb, ns, twp); \
+#define PFA_CASE(r)                                      \
+  case r:                                                \
+    generic_butterfly<r>(a, b, j, nb, ns, mns, twp); \
     break;
           PFA_GENERIC_RADICES(PFA_CASE)
 #undef PFA_CASE
@@ -100,13 +122,22 @@ __global__ __launch_bounds__(GENERIC_WG) void generic_fft_kernel(const generic_a
       ns *= R;
     }
     // ---- stage out ----
-    for (int e = tid; e < fpw * n; e += GENERIC_WG) {
-      const int f = p.out_f_fast ? e % fpw : e / n;
-      const int k = p.out_f_fast ? e / fpw : e % n;
-      const long long t = g * fpw + f;
-      if (t < p.total_count) {
+    for (unsigned e = tid; e < fpw * n; e += GENERIC_WG) {
+      unsigned f, k;
+      if (p.out_f_fast) {
+        k = fast_div(e, p.magic_fpw);
+        f = e - k * fpw;
+      } else {
+        f = fast_div(e, p.magic_n);
+        k = e - f * n;
+      }
+      if (f < nf) {
+        long long c = c0 + f, o = o0;
+        while (c >= p.inner_count) {
+          c -= p.inner_count;
+          ++o;
+        }
         cx<T> y = src[f * n + k];
-        const long long c = t % p.inner_count;
         if (p.stw_lo != nullptr) {
           const long long m = static_cast<long long>(k) * c;
           const cx<T> wl = static_cast<const cx<T>*>(p.stw_lo)[m & ((1ll << p.stw_shift) - 1)];
@@ -116,8 +147,7 @@ __global__ __launch_bounds__(GENERIC_WG) void generic_fft_kernel(const generic_a
         if (p.conj_out) y.im = -y.im;
         y.re *= scale;
         y.im *= scale;
-        const long long idx = (t / p.inner_count) * p.out_dist_outer + c * p.out_dist_inner +
-                              static_cast<long long>(k) * p.out_stride;
+        const long long idx = o * p.out_dist_outer + c * p.out_dist_inner + static_cast<long long>(k) * p.out_stride;
         out_re[idx * p.out_step] = y.re;
         out_im[idx * p.out_step] = y.im;
       }

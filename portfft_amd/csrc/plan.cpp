@@ -385,6 +385,16 @@ struct plan_t {
       fail(PFFT_OUT_OF_LOCAL_MEMORY, "FFT size ", n, " needs ", s.lds_bytes, " bytes of LDS, device has ", max_lds);
     }
     // lane order: walk whichever index is contiguous in memory
+    g.magic_n = generic_magic(static_cast<unsigned>(n));
+    g.magic_fpw = generic_magic(static_cast<unsigned>(fpw));
+    {
+      unsigned ns = 1;
+      for (int p = 0; p < g.n_passes; ++p) {
+        g.magic_nb[p] = generic_magic(static_cast<unsigned>(n / g.radix[p]));
+        g.magic_ns[p] = generic_magic(ns);
+        ns *= static_cast<unsigned>(g.radix[p]);
+      }
+    }
     g.in_f_fast = (fpw > 1 && ia.dist_inner < ia.stride) ? 1 : 0;
     g.out_f_fast = (fpw > 1 && oa.dist_inner < oa.stride) ? 1 : 0;
     const void* fn = generic_kernel_symbol(desc.precision);

@@ -50,7 +50,12 @@ enum : int { TW_GLOBAL = 0, TW_REGS = 1 };
 ///  TWM     TW_GLOBAL: twiddles re-read from the table (L1/L2 resident) at every use
 ///          TW_REGS  : twiddles loaded once per work-group lifetime into VGPRs
 ///  OCC     waves per SIMD to keep resident (bounds the VGPR budget: 512 / OCC)
-template <typename T_, typename Seq_, int WG_, int FPW_, int PADS_, int PADW_, int TWM_, int OCC_ = 1, int AUX_ = 0>
+///  AUX     cache policy bits of the HBM accesses
+///  STAGED  1: small lengths -- the group's FPW*N contiguous elements are copied HBM <-> LDS with fully coalesced
+///          accesses and every pass works LDS -> LDS (the reference's global2local / local2global staging,
+///          common/transfers.hpp:390-443); 0: pass 0 reads HBM and the last pass writes HBM directly
+template <typename T_, typename Seq_, int WG_, int FPW_, int PADS_, int PADW_, int TWM_, int OCC_ = 1, int AUX_ = 0,
+          int STAGED_ = 0>
 struct wg_cfg {
   using T = T_;
   using Seq = Seq_;
@@ -63,10 +68,11 @@ struct wg_cfg {
   static constexpr int TWM = TWM_;
   static constexpr int OCC = OCC_;  // minimum waves per SIMD the register allocator must leave room for
   static constexpr int AUX = AUX_;  // cache-policy bits of the HBM accesses (0 default, 2 = nt streaming)
+  static constexpr int STAGED = STAGED_;
   static constexpr int NP = Seq_::count;
   static constexpr int pad(int i) { return PADS_ == 0 ? i : i + ((i >> PADS_) * PADW_); }
   static constexpr int LDS_PER_FFT = pad(N - 1) + 1 + (PADS_ == 0 ? 0 : PADW_);
-  static constexpr int LDS_ELEMS = NP > 1 ? LDS_PER_FFT * FPW_ : 0;
+  static constexpr int LDS_ELEMS = (NP > 1 || STAGED_) ? LDS_PER_FFT * FPW_ : 0;
   static constexpr size_t LDS_BYTES = size_t(LDS_ELEMS) * sizeof(cx<T_>);
   /// butterflies each lane performs in pass p
   static constexpr int bpt(int p) { return (N / Seq_::r[p] + TPF - 1) / TPF; }
@@ -168,6 +174,8 @@ PFA_DEV void wg_pass(const IO& io, unsigned f, cx<typename Cfg::T>* lds, int tid
   constexpr bool ragged = (NB % Cfg::TPF) != 0;
   constexpr bool first = P == 0;
   constexpr bool last = P == Cfg::NP - 1;
+  constexpr bool from_global = first && !Cfg::STAGED;
+  constexpr bool to_global = last && !Cfg::STAGED;
 
   cx<T> v[BPT][R];
   // ---- gather the R inputs of each butterfly (stride NB: lane-contiguous) ----
@@ -175,7 +183,7 @@ PFA_DEV void wg_pass(const IO& io, unsigned f, cx<typename Cfg::T>* lds, int tid
     constexpr int i = decltype(i_)::value;
     const unsigned j = tid + i * Cfg::TPF;
     if (!ragged || j < NB) {
-      if constexpr (first) {
+      if constexpr (from_global) {
         sfor<0, R>([&](auto t_) PFA_LAMBDA {
           constexpr int t = decltype(t_)::value;
           cx<T> x = io.load(IO::lane_off(f, j), IO::step(t * NB));
@@ -197,7 +205,7 @@ PFA_DEV void wg_pass(const IO& io, unsigned f, cx<typename Cfg::T>* lds, int tid
     }
   });
   // the LDS image is free for the next writer once every lane has its inputs in registers
-  if constexpr (!first) __syncthreads();
+  if constexpr (!from_global) __syncthreads();
   // ---- twiddle, butterfly, scatter ----
   sfor<0, BPT>([&](auto i_) PFA_LAMBDA {
     constexpr int i = decltype(i_)::value;
@@ -218,7 +226,7 @@ PFA_DEV void wg_pass(const IO& io, unsigned f, cx<typename Cfg::T>* lds, int tid
       }
       dft<R>(v[i]);
       const unsigned base = (j / Ns) * (Ns * R) + q;
-      if constexpr (last) {
+      if constexpr (to_global) {
         sfor<0, R>([&](auto u_) PFA_LAMBDA {
           constexpr int u = decltype(u_)::value;
           cx<T> y = v[i][u];
@@ -241,7 +249,7 @@ PFA_DEV void wg_pass(const IO& io, unsigned f, cx<typename Cfg::T>* lds, int tid
       }
     }
   });
-  if constexpr (!last) __syncthreads();
+  if constexpr (!to_global) __syncthreads();
 }
 
 template <typename Cfg, bool BWD, int P, typename IO>
@@ -287,12 +295,45 @@ __global__ __launch_bounds__(Cfg::WG, Cfg::OCC) void stockham_wg_kernel(const cx
   const long long ngroups = (nfft + Cfg::FPW - 1) / Cfg::FPW;
   for (long long g = blockIdx.x; g < ngroups; g += gridDim.x) {
     const packed_io<T, Cfg::N, Cfg::FPW, Cfg::AUX> io(in, out, g, nfft);
+    if constexpr (Cfg::STAGED) {
+      // coalesced copy of the group's FPW*N contiguous elements into the (padded) per-FFT LDS images
+      constexpr int CH = Cfg::FPW * Cfg::N;
+      constexpr int EPT = (CH + Cfg::WG - 1) / Cfg::WG;
+      cx<T>* all = reinterpret_cast<cx<T>*>(pfa_smem);
+      sfor<0, EPT>([&](auto k_) PFA_LAMBDA {
+        constexpr int k = decltype(k_)::value;
+        const unsigned e = threadIdx.x + k * Cfg::WG;
+        if (CH % Cfg::WG == 0 || e < CH) {
+          cx<T> x = io.load(e * static_cast<unsigned>(sizeof(cx<T>)), 0);
+          if constexpr (BWD) x.im = -x.im;
+          all[(e / Cfg::N) * Cfg::LDS_PER_FFT + lds_pad<Cfg>(e % Cfg::N)] = x;
+        }
+      });
+      __syncthreads();
+    }
     const cx<T>* twp = tw;
     if constexpr (Cfg::TWM == TW_GLOBAL) {
       // keep the table reads inside the loop (L1/L2 hits) instead of letting LICM pin them in VGPRs
       asm volatile("" : "+s"(twp));
     }
     wg_passes<Cfg, BWD, 0>(io, f, lds, tid, twp, twr, scale);
+    if constexpr (Cfg::STAGED) {
+      constexpr int CH = Cfg::FPW * Cfg::N;
+      constexpr int EPT = (CH + Cfg::WG - 1) / Cfg::WG;
+      const cx<T>* all = reinterpret_cast<const cx<T>*>(pfa_smem);
+      sfor<0, EPT>([&](auto k_) PFA_LAMBDA {
+        constexpr int k = decltype(k_)::value;
+        const unsigned e = threadIdx.x + k * Cfg::WG;
+        if (CH % Cfg::WG == 0 || e < CH) {
+          cx<T> y = all[(e / Cfg::N) * Cfg::LDS_PER_FFT + lds_pad<Cfg>(e % Cfg::N)];
+          if constexpr (BWD) y.im = -y.im;
+          y.re *= scale;
+          y.im *= scale;
+          io.store(y, e * static_cast<unsigned>(sizeof(cx<T>)), 0);
+        }
+      });
+      __syncthreads();  // the next group's copy-in overwrites the images
+    }
   }
 }
 

@@ -225,6 +225,26 @@ def test_strided_workgroup_tier(prec, oracle):
     _check(got, ref, 65536, dtype, "four-step vs oracle")
 
 
+@pytest.mark.parametrize("prec", ["f32", "f64"])
+def test_every_registered_length(prec):
+    """every length that has a specialised kernel (kernels_f32.hip / kernels_f64.hip), plus neighbours that fall to
+    the generic tier, packed, ragged batch counts, forward and backward"""
+    import gpu_utils as G
+    pf = _pf()
+    dtype = np.complex64 if prec == "f32" else np.complex128
+    sizes = [2, 4, 8, 16, 32, 64, 128, 256, 512, 1024, 2048, 4096, 8192, 16384, 96, 192, 384, 768, 1536, 3072, 6144,
+             12288, 80, 100, 160, 320, 640, 1280, 2560, 5120, 1000, 10000, 6, 12, 15, 17, 19, 23, 29, 31, 49, 121,
+             169, 243, 625, 2401, 7 * 11 * 13, 30030 // 2]
+    for n in sizes:
+        for batch in (1, 5, 67):
+            x, y = H.gen_fourier_data(batch, [n], dtype, seed=n)
+            d = G.make_descriptor([n], prec, batch=batch)
+            got, _ = G.transform_packed(d, pf.direction.FORWARD, x)
+            _check(got, y, n, dtype, ("registered fwd", prec, n, batch))
+            back, _ = G.transform_packed(d, pf.direction.BACKWARD, y)
+            _check(back, x.astype(np.complex128) * n, n, dtype, ("registered bwd", prec, n, batch))
+
+
 def test_offsets():
     """Offsets* suites (instantiate_fft_tests.hpp:187-218): data starts at an offset; everything before the
     output offset must stay untouched"""

@@ -113,19 +113,20 @@ void run_variant(const char* name, int wgs_per_cu, int num_cus) {
   CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS_BYTES));
   int occ = 0;
   CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, Cfg::WG, Cfg::LDS_BYTES));
-  long long groups = (g_batch + Cfg::FPW - 1) / Cfg::FPW;
+  const long long nfft = g_batch * 4096 / Cfg::N;
+  long long groups = (nfft + Cfg::FPW - 1) / Cfg::FPW;
   long long grid = wgs_per_cu > 0 ? std::min<long long>(groups, (long long)wgs_per_cu * num_cus) : groups;
   CK(hipMemset(g_out, 0, (size_t)g_batch * Cfg::N * sizeof(cx<T>)));
   float ms = time_ms(
       [&] {
         hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(Cfg::WG), Cfg::LDS_BYTES, 0, (const cx<T>*)g_in,
-                           (cx<T>*)g_out, d_tw, g_batch, (T)1);
+                           (cx<T>*)g_out, d_tw, nfft, (T)1);
       },
       10);
   // verify
   double worst = 0;
   std::vector<std::complex<float>> h(Cfg::N);
-  for (int k = 0; k < 3; ++k) {
+  for (int k = 0; k < 3 && Cfg::N == 4096; ++k) {
     CK(hipMemcpy(h.data(), g_out + g_ref_b[k] * Cfg::N, Cfg::N * sizeof(cx<T>), hipMemcpyDeviceToHost));
     double num = 0, den = 0;
     for (int i = 0; i < Cfg::N; ++i) {
@@ -135,8 +136,8 @@ void run_variant(const char* name, int wgs_per_cu, int num_cus) {
     }
     worst = std::max(worst, std::sqrt(num / den));
   }
-  double bytes = 2.0 * g_batch * Cfg::N * sizeof(cx<T>);
-  double flops = 5.0 * Cfg::N * std::log2((double)Cfg::N) * g_batch;
+  double bytes = 2.0 * nfft * Cfg::N * sizeof(cx<T>);
+  double flops = 5.0 * Cfg::N * std::log2((double)Cfg::N) * nfft;
   printf("%-34s grid=%-6lld occ=%d lds=%-6zu  %.4f ms  %.2f TB/s  %.1f TFLOP/s  relL2=%.2e\n", name, grid, occ,
          Cfg::LDS_BYTES, ms, bytes / ms * 1e-9, flops / ms * 1e-9, worst);
   CK(hipFree(d_tw));
@@ -203,31 +204,16 @@ int main(int argc, char** argv) {
 
   // ---- FFT variants ----
   using S16 = radix_list<16, 16, 16>;
-  using S8 = radix_list<8, 8, 8, 8>;
-  run_variant<wg_cfg<float, S16, 256, 1, 0, 0, TW_GLOBAL, 4>>("r16x3 wg256 nopad twG o4 grid=batch", 0, cus);
-  run_variant<wg_cfg<float, S16, 256, 1, 4, 1, TW_GLOBAL, 4>>("r16x3 wg256 pad16 twG o4 grid=batch", 0, cus);
-  run_variant<wg_cfg<float, S16, 256, 1, 4, 1, TW_GLOBAL, 4, 2>>("r16x3 wg256 pad16 twG o4 nt grid=batch", 0, cus);
-  run_variant<wg_cfg<float, S16, 256, 1, 4, 1, TW_GLOBAL, 3>>("r16x3 wg256 pad16 twG o3 grid=batch", 0, cus);
-  run_variant<wg_cfg<float, S16, 256, 1, 4, 1, TW_GLOBAL, 2>>("r16x3 wg256 pad16 twG o2 grid=batch", 0, cus);
-  for (int w : {2, 3, 4, 5, 8}) {
-    char nm[64];
-    snprintf(nm, sizeof nm, "r16x3 wg256 pad16 twG o4 %d/CU", w);
-    run_variant<wg_cfg<float, S16, 256, 1, 4, 1, TW_GLOBAL, 4>>(nm, w, cus);
-    snprintf(nm, sizeof nm, "r16x3 wg256 pad16 twR o4 %d/CU", w);
-    run_variant<wg_cfg<float, S16, 256, 1, 4, 1, TW_REGS, 4>>(nm, w, cus);
-    snprintf(nm, sizeof nm, "r16x3 wg256 pad16 twR o4 nt %d/CU", w);
-    run_variant<wg_cfg<float, S16, 256, 1, 4, 1, TW_REGS, 4, 2>>(nm, w, cus);
-    snprintf(nm, sizeof nm, "r16x3 wg256 pad16 twR o3 %d/CU", w);
-    run_variant<wg_cfg<float, S16, 256, 1, 4, 1, TW_REGS, 3>>(nm, w, cus);
-    snprintf(nm, sizeof nm, "r16x3 wg256 nopad twR o4 %d/CU", w);
-    run_variant<wg_cfg<float, S16, 256, 1, 0, 0, TW_REGS, 4>>(nm, w, cus);
+  for (int rep = 0; rep < 2; ++rep) {
+    run_variant<wg_cfg<float, S16, 256, 1, 4, 1, TW_REGS, 4, 2>>("r16x3 twR o4 nt 8/CU (current)", 8, cus);
+    run_variant<wg_cfg<float, S16, 256, 1, 4, 1, TW_REGS, 4, 2>>("r16x3 twR o4 nt 4/CU", 4, cus);
+    run_variant<wg_cfg<float, S16, 256, 1, 4, 1, TW_REGS, 4, 2>>("r16x3 twR o4 nt grid=batch", 0, cus);
+    run_variant<wg_cfg<float, S16, 256, 1, 4, 1, TW_GLOBAL, 4, 2>>("r16x3 twG o4 nt 8/CU", 8, cus);
+    run_variant<wg_cfg<float, S16, 256, 1, 4, 1, TW_GLOBAL, 4, 2>>("r16x3 twG o4 nt grid=batch", 0, cus);
+    run_variant<wg_cfg<float, S16, 256, 1, 4, 1, TW_GLOBAL, 4, 2, 1>>("r16x3 twG o4 nt STAGED 8/CU", 8, cus);
+    run_variant<wg_cfg<float, S16, 256, 1, 4, 1, TW_GLOBAL, 4, 2, 1>>("r16x3 twG o4 nt STAGED grid=batch", 0, cus);
+    run_variant<wg_cfg<float, S16, 256, 1, 4, 1, TW_REGS, 4, 2, 1>>("r16x3 twR o4 nt STAGED 8/CU", 8, cus);
+    run_variant<wg_cfg<float, radix_list<16>, 256, 256, 4, 1, TW_GLOBAL, 4, 2, 1>>("N=16 staged (x256 batch) 8/CU", 8, cus);
   }
-  run_variant<wg_cfg<float, S8, 512, 1, 4, 1, TW_GLOBAL, 8>>("r8x4 wg512 pad16 twG o8 grid=batch", 0, cus);
-  run_variant<wg_cfg<float, S8, 512, 1, 4, 1, TW_GLOBAL, 6>>("r8x4 wg512 pad16 twG o6 grid=batch", 0, cus);
-  run_variant<wg_cfg<float, S8, 512, 1, 4, 1, TW_REGS, 6>>("r8x4 wg512 pad16 twR o6 3/CU", 3, cus);
-  run_variant<wg_cfg<float, S8, 512, 1, 4, 1, TW_REGS, 4>>("r8x4 wg512 pad16 twR o4 2/CU", 2, cus);
-  run_variant<wg_cfg<float, S16, 128, 1, 4, 1, TW_GLOBAL, 2>>("r16x3 wg128 pad16 twG o2 grid=batch", 0, cus);
-  run_variant<wg_cfg<float, S16, 512, 2, 4, 1, TW_REGS, 4>>("r16x3 wg512 fpw2 pad16 twR o4 2/CU", 2, cus);
-  run_variant<wg_cfg<float, S16, 1024, 4, 4, 1, TW_REGS, 4>>("r16x3 wg1024 fpw4 pad16 twR o4 1/CU", 1, cus);
   return 0;
 }
