@@ -74,13 +74,71 @@ def cpu_baseline(sample_seconds=12.0):
                       "batch=%d of the 65536 x %d passes, %.1f s" % (N, batch, reps, total)}
 
 
+def other_config(args):
+    """BASELINE configs[2] / configs[4] on one GPU: same protocol, same JSON fields (no cpu_baseline)."""
+    import torch
+    import portfft_amd as pf
+    import numpy as np
+
+    torch.cuda.set_device(0)
+    if args.config == "c3":
+        lengths, batch, prec, dt, name = [1 << 20], 128, "f64", torch.complex128, "BASELINE configs[2]: fp64 C2C 1D N=1048576 batch=128"
+    else:
+        lengths, batch, prec, dt, name = [1024, 1024], 256, "f32", torch.complex64, "BASELINE configs[4]: fp32 C2C 2D 1024x1024 batch=256"
+    n = int(np.prod(lengths))
+    d = pf.descriptor(lengths, prec)
+    d.number_of_transforms = batch
+    plan = d.commit()
+    xs = []
+    for _ in range(2):
+        x = torch.empty(batch * n, dtype=dt, device="cuda")
+        torch.view_as_real(x).uniform_(-1, 1)
+        xs.append(x)
+    y = torch.empty_like(xs[0])
+    for w in range(args.warmup):
+        plan.compute_forward(xs[w % 2], y)
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    s.record()
+    for k in range(args.steps):
+        plan.compute_forward(xs[k % 2], y)
+    e.record()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    dev_ms = s.elapsed_time(e) / args.steps
+    last = xs[(args.steps - 1) % 2].view([batch] + lengths)[batch - 1].cpu().numpy()
+    ref = np.fft.fftn(last.astype(np.complex128))
+    got = y.view([batch] + lengths)[batch - 1].cpu().numpy()
+    err = float(np.linalg.norm(got - ref) / np.linalg.norm(ref))
+    assert err < 1e-4, err
+    esz = 16 if prec == "f64" else 8
+    alg = 2.0 * n * batch * esz
+    print(json.dumps({
+        "metric": "GFLOP/s (5Nlog2N) + achieved-HBM%% (%s)" % args.config, "value": round(5.0 * n * math.log2(n) * batch / (elapsed / args.steps) / 1e9, 1),
+        "unit": "GFLOP/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 5), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": prec, "data": "synthetic",
+        "config": {"workload": name + ", out-of-place, inputs resident in HBM", "parity_rel_l2_vs_numpy": err},
+        "roofline": {"bound": "hbm", "achieved": round(alg / (dev_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(alg / (dev_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
+                     "kernel": "two launches per execute (see DESIGN.md 3.3)", "kernel_ms": round(dev_ms, 5),
+                     "algorithmic_bytes_per_launch": alg}}))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--config", default="c2", choices=["c2", "c3", "c5"],
+                    help="c2 (default, the headline line): fp32 N=4096 batch=65536; c3: fp64 N=2^20 batch=128; "
+                         "c5: fp32 2-D 1024x1024 batch=256 -- the other single-GPU configs of BASELINE.json, "
+                         "reported with the same fields")
     args = ap.parse_args()
+    if args.config != "c2":
+        return other_config(args)
 
     import torch
     import portfft_amd as pf
