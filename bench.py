@@ -225,7 +225,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "traffic_source": traffic_src,
-                         "kernel": "stockham_wg_kernel<f32, 16x16x16, wg256>", "kernel_ms": round(avg_kernel_ms, 5),
+                         "kernel": "stockham_wg_prefetch_kernel<f32, 16x16x16, wg256, twiddles in VGPRs>", "kernel_ms": round(avg_kernel_ms, 5),
                          "algorithmic_bytes_per_launch": alg_bytes},
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -9,6 +9,23 @@
 namespace pfa {
 
 template <typename Cfg>
+hipError_t launch_spec_prefetch(hipStream_t stream, unsigned grid, const void* in, void* out, const void* tw,
+                                long long nfft, double scale, int backward) {
+  using T = typename Cfg::T;
+  const auto* i = static_cast<const cx<T>*>(in);
+  auto* o = static_cast<cx<T>*>(out);
+  const auto* t = static_cast<const cx<T>*>(tw);
+  if (backward) {
+    hipLaunchKernelGGL((stockham_wg_prefetch_kernel<Cfg, true>), dim3(grid), dim3(Cfg::WG), Cfg::LDS_BYTES, stream, i,
+                       o, t, nfft, static_cast<T>(scale));
+  } else {
+    hipLaunchKernelGGL((stockham_wg_prefetch_kernel<Cfg, false>), dim3(grid), dim3(Cfg::WG), Cfg::LDS_BYTES, stream,
+                       i, o, t, nfft, static_cast<T>(scale));
+  }
+  return hipGetLastError();
+}
+
+template <typename Cfg>
 hipError_t launch_spec(hipStream_t stream, unsigned grid, const void* in, void* out, const void* tw, long long nfft,
                        double scale, int backward) {
   using T = typename Cfg::T;
@@ -26,6 +43,19 @@ hipError_t launch_spec(hipStream_t stream, unsigned grid, const void* in, void* 
 }
 
 template <typename Cfg>
+spec_kernel make_spec_entry();
+
+/// software-pipelined form (stockham_wg_prefetch_kernel) of a direct-I/O multi-pass variant
+template <typename Cfg>
+spec_kernel make_spec_entry_prefetch() {
+  spec_kernel k = make_spec_entry<Cfg>();
+  k.fn[0] = reinterpret_cast<const void*>(&stockham_wg_prefetch_kernel<Cfg, false>);
+  k.fn[1] = reinterpret_cast<const void*>(&stockham_wg_prefetch_kernel<Cfg, true>);
+  k.launch = &launch_spec_prefetch<Cfg>;
+  return k;
+}
+
+template <typename Cfg>
 spec_kernel make_spec_entry() {
   spec_kernel k{};
   k.precision = sizeof(typename Cfg::T) == 8 ? PFFT_PRECISION_F64 : PFFT_PRECISION_F32;
@@ -36,6 +66,7 @@ spec_kernel make_spec_entry() {
   k.n_radices = Cfg::NP;
   for (int i = 0; i < Cfg::NP; ++i) k.radices[i] = Cfg::Seq::r[i];
   k.tw_total = Cfg::Seq::tw_total;
+  k.tw_in_regs = Cfg::TWM == TW_REGS ? 1 : 0;
   k.fn[0] = reinterpret_cast<const void*>(&stockham_wg_kernel<Cfg, false>);
   k.fn[1] = reinterpret_cast<const void*>(&stockham_wg_kernel<Cfg, true>);
   k.launch = &launch_spec<Cfg>;

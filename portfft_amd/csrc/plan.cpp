@@ -285,7 +285,7 @@ struct plan_t {
                   "hipFuncSetAttribute");
       }
     }
-    s.grid = persistent_grid(k->fn[backward * 2], k->wg, k->lds_bytes, (count + k->fpw - 1) / k->fpw);
+    s.grid = persistent_grid(k->fn[backward * 2], k->wg, k->lds_bytes, (count + k->fpw - 1) / k->fpw, 1);
     return s;
   }
 
@@ -303,13 +303,22 @@ struct plan_t {
   /// largest length the generic tier can hold (two LDS images)
   long long generic_max_n() const { return static_cast<long long>(max_lds / (2 * elem_bytes())); }
 
-  unsigned persistent_grid(const void* fn, int wg, size_t lds, long long groups) {
+  /// Grid of a persistent kernel.  Measured on the N=4096 kernel (tools/proto_c2.hip, interleaved rounds): a grid of
+  /// 1-2x the resident work-groups keeps every work-group in lock-step (all load, then all compute) and loses ~5 %
+  /// against a grid where each work-group handles only `groups_per_wg` groups (4-5 is the optimum when the kernel
+  /// pre-loads its twiddles into registers, 1 when it re-reads them per FFT): staggered work-group start times smooth
+  /// the HBM demand.
+  unsigned persistent_grid(const void* fn, int wg, size_t lds, long long groups, int groups_per_wg) {
     int per_cu = 0;
     hip_check(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, wg, lds), "occupancy query");
     per_cu = std::max(per_cu, 1);
     const long long resident = static_cast<long long>(per_cu) * n_cus;
-    // two waves of work-groups: keeps the tail short while the per-work-group set-up (twiddles) stays amortised
-    return static_cast<unsigned>(std::max<long long>(1, std::min<long long>(groups, 2 * resident)));
+    // kernels whose LDS footprint leaves only one or two work-groups per CU did better with the long persistent
+    // loop (f64 N=4096, f32 N=16384): their work-groups are too few to de-phase by dispatch order anyway
+    long long grid = per_cu <= 2 ? 2 * resident : (groups + groups_per_wg - 1) / groups_per_wg;
+    grid = std::min(groups, std::max(grid, std::min<long long>(groups, 2 * resident)));
+    grid = std::min<long long>(grid, 1ll << 30);
+    return static_cast<unsigned>(std::max<long long>(1, grid));
   }
 
   stage make_spec_stage(const spec_kernel* k, long long count, int in_buf, long long in_off, int out_buf,
@@ -333,7 +342,8 @@ struct plan_t {
                   "hipFuncSetAttribute");
       }
     }
-    s.grid = persistent_grid(k->fn[backward], k->wg, k->lds_bytes, (count + k->fpw - 1) / k->fpw);
+    s.grid = persistent_grid(k->fn[backward], k->wg, k->lds_bytes, (count + k->fpw - 1) / k->fpw,
+                             k->tw_in_regs ? 4 : 1);
     return s;
   }
 
@@ -402,7 +412,7 @@ struct plan_t {
       hip_check(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(max_lds)),
                 "hipFuncSetAttribute");
     }
-    s.grid = persistent_grid(fn, GENERIC_WG, s.lds_bytes, (count + fpw - 1) / fpw);
+    s.grid = persistent_grid(fn, GENERIC_WG, s.lds_bytes, (count + fpw - 1) / fpw, 1);
     return s;
   }
 

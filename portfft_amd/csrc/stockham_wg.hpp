@@ -262,6 +262,122 @@ PFA_DEV void wg_passes(const IO& io, unsigned f, cx<typename Cfg::T>* lds, int t
   }
 }
 
+/// Pass 0 split in two for the prefetching kernel: issue the HBM loads of a group ...
+template <typename Cfg, bool BWD, typename IO>
+PFA_DEV void wg_pass0_load(const IO& io, unsigned f, int tid,
+                           cx<typename Cfg::T> (&v)[Cfg::bpt(0)][Cfg::Seq::r[0]]) {
+  using T = typename Cfg::T;
+  constexpr int R = Cfg::Seq::r[0];
+  constexpr int NB = Cfg::N / R;
+  constexpr int BPT = Cfg::bpt(0);
+  constexpr bool ragged = (NB % Cfg::TPF) != 0;
+  sfor<0, BPT>([&](auto i_) PFA_LAMBDA {
+    constexpr int i = decltype(i_)::value;
+    const unsigned j = tid + i * Cfg::TPF;
+    if (!ragged || j < NB) {
+      sfor<0, R>([&](auto t_) PFA_LAMBDA {
+        constexpr int t = decltype(t_)::value;
+        cx<T> x = io.load(IO::lane_off(f, j), IO::step(t * NB));
+        if constexpr (BWD) x.im = -x.im;
+        v[i][t] = x;
+      });
+    }
+  });
+}
+
+/// ... and butterfly + scatter them into LDS later.
+template <typename Cfg>
+PFA_DEV void wg_pass0_compute(cx<typename Cfg::T> (&v)[Cfg::bpt(0)][Cfg::Seq::r[0]], cx<typename Cfg::T>* lds,
+                              int tid) {
+  using T = typename Cfg::T;
+  constexpr int R = Cfg::Seq::r[0];
+  constexpr int NB = Cfg::N / R;
+  constexpr int BPT = Cfg::bpt(0);
+  constexpr bool ragged = (NB % Cfg::TPF) != 0;
+  sfor<0, BPT>([&](auto i_) PFA_LAMBDA {
+    constexpr int i = decltype(i_)::value;
+    const unsigned j = tid + i * Cfg::TPF;
+    if (!ragged || j < NB) {
+      dft<R>(v[i]);
+      const unsigned base = j * R;
+      if constexpr (pad_is_linear<Cfg>(1, R, R)) {
+        cx<T>* p = lds + lds_pad<Cfg>(base);
+        sfor<0, R>([&](auto u_) PFA_LAMBDA {
+          constexpr int u = decltype(u_)::value;
+          p[u * pad_step<Cfg>(1)] = v[i][u];
+        });
+      } else {
+        sfor<0, R>([&](auto u_) PFA_LAMBDA {
+          constexpr int u = decltype(u_)::value;
+          lds[lds_pad<Cfg>(base + u)] = v[i][u];
+        });
+      }
+    }
+  });
+  __syncthreads();
+}
+
+/// Software-pipelined variant: the HBM loads of the work-group's NEXT group are issued right after pass 0 of the
+/// current one, so every work-group keeps loads in flight through its LDS/compute passes instead of alternating
+/// between a load phase and a compute phase.  Costs one extra register image of the inputs.
+template <typename Cfg, bool BWD>
+__global__ __launch_bounds__(Cfg::WG, Cfg::OCC) void stockham_wg_prefetch_kernel(
+    const cx<typename Cfg::T>* __restrict__ in, cx<typename Cfg::T>* __restrict__ out,
+    const cx<typename Cfg::T>* __restrict__ tw, long long nfft, typename Cfg::T scale) {
+  using T = typename Cfg::T;
+  using Seq = typename Cfg::Seq;
+  static_assert(Cfg::NP >= 2 && !Cfg::STAGED, "prefetching needs a direct-I/O multi-pass kernel");
+  extern __shared__ __attribute__((aligned(16))) char pfa_smem[];
+  const int f = threadIdx.x / Cfg::TPF;
+  const int tid = threadIdx.x % Cfg::TPF;
+  cx<T>* lds = reinterpret_cast<cx<T>*>(pfa_smem) + f * Cfg::LDS_PER_FFT;
+  using IO = packed_io<T, Cfg::N, Cfg::FPW, Cfg::AUX>;
+
+  cx<T> twr[Cfg::TWR_TOTAL];
+  if constexpr (Cfg::TWM == TW_REGS) {
+    sfor<1, Cfg::NP>([&](auto p_) PFA_LAMBDA {
+      constexpr int p = decltype(p_)::value;
+      constexpr int R = Seq::r[p];
+      constexpr int Ns = Seq::ns(p);
+      sfor<0, Cfg::bpt(p)>([&](auto i_) PFA_LAMBDA {
+        constexpr int i = decltype(i_)::value;
+        const int q = (tid + i * Cfg::TPF) % Ns;
+        sfor<1, R>([&](auto t_) PFA_LAMBDA {
+          constexpr int t = decltype(t_)::value;
+          twr[Cfg::twr_off(p) + i * (R - 1) + (t - 1)] = tw[Seq::tw_off(p) + (t - 1) * Ns + q];
+        });
+      });
+    });
+  }
+
+  const long long ngroups = (nfft + Cfg::FPW - 1) / Cfg::FPW;
+  long long g = blockIdx.x;
+  if (g >= ngroups) return;
+  cx<T> cur[Cfg::bpt(0)][Seq::r[0]];
+  cx<T> nxt[Cfg::bpt(0)][Seq::r[0]];
+  {
+    const IO io0(in, out, g, nfft);
+    wg_pass0_load<Cfg, BWD>(io0, f, tid, cur);
+  }
+  for (; g < ngroups; g += gridDim.x) {
+    const IO io(in, out, g, nfft);
+    wg_pass0_compute<Cfg>(cur, lds, tid);
+    const long long gn = g + gridDim.x;
+    if (gn < ngroups) {
+      const IO ion(in, out, gn, nfft);
+      wg_pass0_load<Cfg, BWD>(ion, f, tid, nxt);
+    }
+    const cx<T>* twp = tw;
+    if constexpr (Cfg::TWM == TW_GLOBAL) {
+      asm volatile("" : "+s"(twp));
+    }
+    wg_passes<Cfg, BWD, 1>(io, f, lds, tid, twp, twr, scale);
+    sfor<0, Cfg::bpt(0)>([&](auto i_) PFA_LAMBDA {
+      sfor<0, Seq::r[0]>([&](auto t_) PFA_LAMBDA { cur[decltype(i_)::value][decltype(t_)::value] = nxt[decltype(i_)::value][decltype(t_)::value]; });
+    });
+  }
+}
+
 /// Persistent work-group kernel: work-group g handles FFT groups g, g+G, ...  (FPW FFTs per group).
 template <typename Cfg, bool BWD>
 __global__ __launch_bounds__(Cfg::WG, Cfg::OCC) void stockham_wg_kernel(const cx<typename Cfg::T>* __restrict__ in,

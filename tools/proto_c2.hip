@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
+#include <algorithm>
 
 #include "../portfft_amd/csrc/stockham_wg.hpp"
 
@@ -202,18 +203,53 @@ int main(int argc, char** argv) {
     printf("hipMemcpy D2D   %.4f ms  %.2f TB/s\n", ms, bytes / ms * 1e-9);
   }
 
-  // ---- FFT variants ----
+  // ---- FFT variants: interleaved rounds, medians ----
   using S16 = radix_list<16, 16, 16>;
-  for (int rep = 0; rep < 2; ++rep) {
-    run_variant<wg_cfg<float, S16, 256, 1, 4, 1, TW_REGS, 4, 2>>("r16x3 twR o4 nt 8/CU (current)", 8, cus);
-    run_variant<wg_cfg<float, S16, 256, 1, 4, 1, TW_REGS, 4, 2>>("r16x3 twR o4 nt 4/CU", 4, cus);
-    run_variant<wg_cfg<float, S16, 256, 1, 4, 1, TW_REGS, 4, 2>>("r16x3 twR o4 nt grid=batch", 0, cus);
-    run_variant<wg_cfg<float, S16, 256, 1, 4, 1, TW_GLOBAL, 4, 2>>("r16x3 twG o4 nt 8/CU", 8, cus);
-    run_variant<wg_cfg<float, S16, 256, 1, 4, 1, TW_GLOBAL, 4, 2>>("r16x3 twG o4 nt grid=batch", 0, cus);
-    run_variant<wg_cfg<float, S16, 256, 1, 4, 1, TW_GLOBAL, 4, 2, 1>>("r16x3 twG o4 nt STAGED 8/CU", 8, cus);
-    run_variant<wg_cfg<float, S16, 256, 1, 4, 1, TW_GLOBAL, 4, 2, 1>>("r16x3 twG o4 nt STAGED grid=batch", 0, cus);
-    run_variant<wg_cfg<float, S16, 256, 1, 4, 1, TW_REGS, 4, 2, 1>>("r16x3 twR o4 nt STAGED 8/CU", 8, cus);
-    run_variant<wg_cfg<float, radix_list<16>, 256, 256, 4, 1, TW_GLOBAL, 4, 2, 1>>("N=16 staged (x256 batch) 8/CU", 8, cus);
+  using CfgR = wg_cfg<float, S16, 256, 1, 4, 1, TW_REGS, 4, 2>;
+  using CfgG = wg_cfg<float, S16, 256, 1, 4, 1, TW_GLOBAL, 4, 2>;
+  auto tw = make_twiddles<S16, float>();
+  cx<float>* d_tw;
+  CK(hipMalloc(&d_tw, tw.size() * sizeof(cx<float>)));
+  CK(hipMemcpy(d_tw, tw.data(), tw.size() * sizeof(cx<float>), hipMemcpyHostToDevice));
+  auto kr = stockham_wg_kernel<CfgR, false>;
+#ifdef PF_TWR
+  using CfgP = wg_cfg<float, S16, 256, 1, 4, 1, TW_REGS, 3, 2>;
+#else
+  using CfgP = wg_cfg<float, S16, 256, 1, 4, 1, TW_GLOBAL, 4, 2>;
+#endif
+  auto kg = stockham_wg_prefetch_kernel<CfgP, false>;
+  CK(hipFuncSetAttribute((const void*)kr, hipFuncAttributeMaxDynamicSharedMemorySize, (int)CfgR::LDS_BYTES));
+  CK(hipFuncSetAttribute((const void*)kg, hipFuncAttributeMaxDynamicSharedMemorySize, (int)CfgG::LDS_BYTES));
+  const int grids[] = {512, 768, 1024, 1280, 2048, 4096, 8192, 12288, 16384, 24576, 32768};
+  const int NG = sizeof(grids) / sizeof(grids[0]);
+  std::vector<std::vector<float>> tr(NG), tg(NG);
+  std::vector<float> tcopy;
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0));
+  CK(hipEventCreate(&e1));
+  auto timed = [&](auto&& launch) {
+    CK(hipEventRecord(e0));
+    launch();
+    CK(hipEventRecord(e1));
+    CK(hipEventSynchronize(e1));
+    float ms;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    return ms;
+  };
+  for (int round = 0; round < 9; ++round) {
+    for (int gi = 0; gi < NG; ++gi) {
+      float a = timed([&] { hipLaunchKernelGGL(kr, dim3(grids[gi]), dim3(256), CfgR::LDS_BYTES, 0, (const cx<float>*)g_in, (cx<float>*)g_out, d_tw, g_batch, 1.0f); });
+      float b = timed([&] { hipLaunchKernelGGL(kg, dim3(grids[gi]), dim3(256), CfgG::LDS_BYTES, 0, (const cx<float>*)g_in, (cx<float>*)g_out, d_tw, g_batch, 1.0f); });
+      if (round) { tr[gi].push_back(a); tg[gi].push_back(b); }
+    }
+    float c = timed([&] { hipLaunchKernelGGL((copy_rows_kernel<16>), dim3((unsigned)g_batch), dim3(256), 0, 0, (const float2*)d_in, (float2*)d_out, g_batch); });
+    if (round) tcopy.push_back(c);
+  }
+  auto med = [](std::vector<float> v) { std::sort(v.begin(), v.end()); return v[v.size() / 2]; };
+  auto mn = [](std::vector<float> v) { std::sort(v.begin(), v.end()); return v[0]; };
+  printf("copy rows (no nt) median %.4f ms %.2f TB/s\n", med(tcopy), bytes / med(tcopy) * 1e-9);
+  for (int gi = 0; gi < NG; ++gi) {
+    printf("grid %6d  twR median %.4f ms %.2f TB/s (min %.4f)   PF median %.4f ms %.2f TB/s (min %.4f)\n", grids[gi], med(tr[gi]), bytes / med(tr[gi]) * 1e-9, mn(tr[gi]), med(tg[gi]), bytes / med(tg[gi]) * 1e-9, mn(tg[gi]));
   }
   return 0;
 }
