@@ -39,11 +39,11 @@ def main(src, dst):
     out["calibration"] = {"known_KiB_per_launch": known_kib, "FETCH_SIZE_mean": sum(kf) / len(kf),
                           "WRITE_SIZE_mean": sum(kw) / len(kw), "fetch_correction": round(fetch_corr, 4),
                           "write_correction": round(write_corr, 4)}
-    f = [v for k, vs in per_kernel(src + "/FETCH_SIZE", "FETCH_SIZE").items() if "stockham_wg_kernel" in k for v in vs]
-    w = [v for k, vs in per_kernel(src + "/WRITE_SIZE", "WRITE_SIZE").items() if "stockham_wg_kernel" in k for v in vs]
+    f = [v for k, vs in per_kernel(src + "/FETCH_SIZE", "FETCH_SIZE").items() if "stockham_wg" in k for v in vs]
+    w = [v for k, vs in per_kernel(src + "/WRITE_SIZE", "WRITE_SIZE").items() if "stockham_wg" in k for v in vs]
     fetch_b = sum(f) / len(f) * 1024 * 2.0  # guide's gfx950 correction (confirmed by the calibration above)
     write_b = sum(w) / len(w) * 1024
-    out["kernel"] = "stockham_wg_kernel<f32, 16x16x16, wg256> (bench.py workload: N=4096 batch=65536)"
+    out["kernel"] = "stockham_wg_prefetch_kernel<f32, 16x16x16, wg256> (bench.py workload: N=4096 batch=65536)"
     out["launches_sampled"] = {"FETCH_SIZE": len(f), "WRITE_SIZE": len(w)}
     out["FETCH_SIZE_mean_KiB"] = sum(f) / len(f)
     out["WRITE_SIZE_mean_KiB"] = sum(w) / len(w)
