@@ -24,6 +24,7 @@ struct spec_kernel {
   int radices[8];
   int tw_total;  // complex entries of the twiddle table the kernel expects (layout: radix_list::tw_off)
   int tw_in_regs;  // 1: the kernel keeps its twiddles in VGPRs for its whole lifetime (TW_REGS)
+  int groups_per_wg;  // tuned grid rule: FFT groups each work-group handles; 0 = persistent grid of 2x resident
   const void* fn[2];  // kernel symbols, [0] forward, [1] backward (for occupancy queries / attributes)
   hipError_t (*launch)(hipStream_t stream, unsigned grid, const void* in, void* out, const void* tw, long long nfft,
                        double scale, int backward);

@@ -18,13 +18,13 @@ const spec_kernel g_spec_f32[] = {
     make_spec_entry<wg_cfg<f, radix_list<8, 8>, 256, 32, 3, 1, TW_GLOBAL, 4, NT, 1>>(),        // 64
     make_spec_entry<wg_cfg<f, radix_list<16, 8>, 256, 32, 4, 1, TW_GLOBAL, 4, NT, 1>>(),       // 128
     make_spec_entry<wg_cfg<f, radix_list<16, 16>, 256, 16, 4, 1, TW_GLOBAL, 4, NT>>(),         // 256
-    make_spec_entry<wg_cfg<f, radix_list<8, 8, 8>, 256, 4, 4, 1, TW_GLOBAL, 4, NT>>(),         // 512
+    make_spec_entry<wg_cfg<f, radix_list<8, 8, 8>, 256, 4, 4, 1, TW_REGS, 4, NT>>(2),           // 512
     make_spec_entry<wg_cfg<f, radix_list<16, 8, 8>, 256, 4, 4, 1, TW_GLOBAL, 4, NT>>(),        // 1024
-    make_spec_entry<wg_cfg<f, radix_list<16, 16, 8>, 256, 2, 4, 1, TW_GLOBAL, 4, NT>>(),       // 2048
+    make_spec_entry<wg_cfg<f, radix_list<16, 16, 8>, 256, 2, 4, 1, TW_REGS, 4, NT>>(4),        // 2048
     // the headline shape: register-resident twiddles + software-pipelined loads (3 work-groups per CU)
-    make_spec_entry_prefetch<wg_cfg<f, radix_list<16, 16, 16>, 256, 1, 4, 1, TW_REGS, 3, NT>>(),  // 4096
-    make_spec_entry<wg_cfg<f, radix_list<32, 16, 16>, 256, 1, 4, 1, TW_GLOBAL, 2, NT>>(),      // 8192
-    make_spec_entry<wg_cfg<f, radix_list<32, 32, 16>, 512, 1, 4, 1, TW_GLOBAL, 2, NT>>(),      // 16384
+    make_spec_entry_prefetch<wg_cfg<f, radix_list<16, 16, 16>, 256, 1, 4, 1, TW_REGS, 3, NT>>(4),  // 4096
+    make_spec_entry<wg_cfg<f, radix_list<32, 16, 16>, 256, 1, 4, 1, TW_REGS, 2, NT>>(4),       // 8192
+    make_spec_entry<wg_cfg<f, radix_list<32, 16, 32>, 512, 1, 0, 0, TW_REGS, 2, NT>>(0),       // 16384
     // 3 * 2^k and 5 * 2^k families, powers of ten
     make_spec_entry<wg_cfg<f, radix_list<12, 8>, 256, 32, 0, 0, TW_GLOBAL, 4, NT, 1>>(),       // 96
     make_spec_entry<wg_cfg<f, radix_list<16, 12>, 256, 16, 4, 1, TW_GLOBAL, 4, NT>>(),         // 192

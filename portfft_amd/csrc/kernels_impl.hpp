@@ -43,12 +43,12 @@ hipError_t launch_spec(hipStream_t stream, unsigned grid, const void* in, void* 
 }
 
 template <typename Cfg>
-spec_kernel make_spec_entry();
+spec_kernel make_spec_entry(int groups_per_wg = 1);
 
 /// software-pipelined form (stockham_wg_prefetch_kernel) of a direct-I/O multi-pass variant
 template <typename Cfg>
-spec_kernel make_spec_entry_prefetch() {
-  spec_kernel k = make_spec_entry<Cfg>();
+spec_kernel make_spec_entry_prefetch(int groups_per_wg = 4) {
+  spec_kernel k = make_spec_entry<Cfg>(groups_per_wg);
   k.fn[0] = reinterpret_cast<const void*>(&stockham_wg_prefetch_kernel<Cfg, false>);
   k.fn[1] = reinterpret_cast<const void*>(&stockham_wg_prefetch_kernel<Cfg, true>);
   k.launch = &launch_spec_prefetch<Cfg>;
@@ -56,8 +56,9 @@ spec_kernel make_spec_entry_prefetch() {
 }
 
 template <typename Cfg>
-spec_kernel make_spec_entry() {
+spec_kernel make_spec_entry(int groups_per_wg) {
   spec_kernel k{};
+  k.groups_per_wg = groups_per_wg;
   k.precision = sizeof(typename Cfg::T) == 8 ? PFFT_PRECISION_F64 : PFFT_PRECISION_F32;
   k.n = Cfg::N;
   k.wg = Cfg::WG;

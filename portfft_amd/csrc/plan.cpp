@@ -313,9 +313,9 @@ struct plan_t {
     hip_check(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, wg, lds), "occupancy query");
     per_cu = std::max(per_cu, 1);
     const long long resident = static_cast<long long>(per_cu) * n_cus;
-    // kernels whose LDS footprint leaves only one or two work-groups per CU did better with the long persistent
-    // loop (f64 N=4096, f32 N=16384): their work-groups are too few to de-phase by dispatch order anyway
-    long long grid = per_cu <= 2 ? 2 * resident : (groups + groups_per_wg - 1) / groups_per_wg;
+    // groups_per_wg comes from the per-kernel tuning (tools/tune.hip, profiles/r1_notes.md); 0 selects the long
+    // persistent loop, which only the one-work-group-per-CU kernels (f32 N=16384) prefer
+    long long grid = groups_per_wg <= 0 ? 2 * resident : (groups + groups_per_wg - 1) / groups_per_wg;
     grid = std::min(groups, std::max(grid, std::min<long long>(groups, 2 * resident)));
     grid = std::min<long long>(grid, 1ll << 30);
     return static_cast<unsigned>(std::max<long long>(1, grid));
@@ -343,7 +343,7 @@ struct plan_t {
       }
     }
     s.grid = persistent_grid(k->fn[backward], k->wg, k->lds_bytes, (count + k->fpw - 1) / k->fpw,
-                             k->tw_in_regs ? 4 : 1);
+                             k->groups_per_wg);
     return s;
   }
 

@@ -1,0 +1,161 @@
+// Scratch tuner: interleaved timing of work-group kernel variants for one length (compile with -DTUNE_CASE=n).
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <functional>
+#include <string>
+#include <vector>
+#include "../portfft_amd/csrc/stockham_wg.hpp"
+using namespace pfa;
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s line %d\n", hipGetErrorString(e_), __LINE__); exit(1);} } while (0)
+
+template <typename Seq, typename T>
+std::vector<cx<T>> make_twiddles() {
+  std::vector<cx<T>> tw(Seq::tw_total > 0 ? Seq::tw_total : 1);
+  for (int p = 1; p < Seq::count; ++p) {
+    const int R = Seq::r[p], Ns = Seq::ns(p);
+    for (int t = 1; t < R; ++t) for (int q = 0; q < Ns; ++q) {
+      const long double a = -2.0L * 3.14159265358979323846264338327950288L * (long double)(t * q) / (long double)(Ns * R);
+      tw[Seq::tw_off(p) + (t - 1) * Ns + q] = {(T)cosl(a), (T)sinl(a)};
+    }
+  }
+  return tw;
+}
+
+struct variant { std::string name; int fpw; int wg; size_t lds; const void* fn; std::function<void(unsigned, long long)> launch; };
+static std::vector<variant> g_variants;
+static void *g_in, *g_out;
+
+template <typename Cfg, bool PF>
+void add(const char* name) {
+  using T = typename Cfg::T;
+  auto tw = make_twiddles<typename Cfg::Seq, T>();
+  cx<T>* d_tw;
+  CK(hipMalloc(&d_tw, tw.size() * sizeof(cx<T>)));
+  CK(hipMemcpy(d_tw, tw.data(), tw.size() * sizeof(cx<T>), hipMemcpyHostToDevice));
+  const void* fn;
+  if constexpr (PF) fn = (const void*)&stockham_wg_prefetch_kernel<Cfg, false>; else fn = (const void*)&stockham_wg_kernel<Cfg, false>;
+  CK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS_BYTES));
+  g_variants.push_back({name, Cfg::FPW, Cfg::WG, Cfg::LDS_BYTES, fn, [d_tw](unsigned grid, long long nfft) {
+    if constexpr (PF) hipLaunchKernelGGL((stockham_wg_prefetch_kernel<Cfg, false>), dim3(grid), dim3(Cfg::WG), Cfg::LDS_BYTES, 0, (const cx<T>*)g_in, (cx<T>*)g_out, d_tw, nfft, (T)1);
+    else hipLaunchKernelGGL((stockham_wg_kernel<Cfg, false>), dim3(grid), dim3(Cfg::WG), Cfg::LDS_BYTES, 0, (const cx<T>*)g_in, (cx<T>*)g_out, d_tw, nfft, (T)1);
+  }});
+}
+
+int main() {
+  const size_t bytes = (size_t)2 << 30;
+  CK(hipMalloc(&g_in, bytes)); CK(hipMalloc(&g_out, bytes));
+  CK(hipMemset(g_in, 0x3c, bytes));
+  hipDeviceProp_t prop; CK(hipGetDeviceProperties(&prop, 0));
+  const int cus = prop.multiProcessorCount;
+  using f = float; using d = double;
+  constexpr int NT = 2;
+#if TUNE_CASE == 2048
+  using S = radix_list<16, 16, 8>; using T = f; const int N = 2048;
+  add<wg_cfg<f, S, 256, 2, 4, 1, TW_GLOBAL, 4, NT>, false>("twG fpw2 o4");
+  add<wg_cfg<f, S, 256, 2, 4, 1, TW_REGS, 4, NT>, false>("twR fpw2 o4");
+  add<wg_cfg<f, S, 256, 2, 4, 1, TW_REGS, 3, NT>, true>("twR fpw2 o3 PF");
+  add<wg_cfg<f, S, 256, 2, 4, 1, TW_GLOBAL, 4, NT>, true>("twG fpw2 o4 PF");
+  add<wg_cfg<f, S, 128, 1, 4, 1, TW_REGS, 4, NT>, false>("twR wg128 fpw1 o4");
+  add<wg_cfg<f, S, 128, 1, 4, 1, TW_REGS, 3, NT>, true>("twR wg128 fpw1 o3 PF");
+#elif TUNE_CASE == 1024
+  using S = radix_list<16, 8, 8>; using T = f; const int N = 1024;
+  add<wg_cfg<f, S, 256, 4, 4, 1, TW_GLOBAL, 4, NT>, false>("twG fpw4 o4");
+  add<wg_cfg<f, S, 256, 4, 4, 1, TW_REGS, 4, NT>, false>("twR fpw4 o4");
+  add<wg_cfg<f, S, 256, 4, 4, 1, TW_REGS, 3, NT>, true>("twR fpw4 o3 PF");
+  add<wg_cfg<f, radix_list<32, 32>, 256, 8, 5, 1, TW_REGS, 2, NT>, false>("r32x32 twR fpw8 o2");
+  add<wg_cfg<f, radix_list<32, 32>, 256, 8, 5, 1, TW_GLOBAL, 2, NT>, false>("r32x32 twG fpw8 o2");
+  add<wg_cfg<f, S, 64, 1, 4, 1, TW_REGS, 4, NT>, false>("twR wg64 fpw1 o4");
+#elif TUNE_CASE == 8192
+  using S = radix_list<32, 16, 16>; using T = f; const int N = 8192;
+  add<wg_cfg<f, S, 256, 1, 4, 1, TW_GLOBAL, 2, NT>, false>("r32.16.16 twG wg256 o2");
+  add<wg_cfg<f, S, 256, 1, 4, 1, TW_REGS, 2, NT>, false>("r32.16.16 twR wg256 o2");
+  add<wg_cfg<f, radix_list<16, 16, 32>, 256, 1, 4, 1, TW_GLOBAL, 2, NT>, false>("r16.16.32 twG wg256 o2");
+  add<wg_cfg<f, radix_list<16, 16, 16, 2>, 512, 1, 4, 1, TW_GLOBAL, 4, NT>, false>("r16.16.16.2 twG wg512 o4");
+  add<wg_cfg<f, radix_list<8, 8, 8, 16>, 512, 1, 4, 1, TW_GLOBAL, 4, NT>, false>("r8.8.8.16 twG wg512 o4");
+  add<wg_cfg<f, radix_list<16, 8, 8, 8>, 512, 1, 4, 1, TW_GLOBAL, 4, NT>, false>("r16.8.8.8 twG wg512 o4");
+#elif TUNE_CASE == 16384
+  using S = radix_list<32, 32, 16>; using T = f; const int N = 16384;
+  add<wg_cfg<f, S, 512, 1, 4, 1, TW_GLOBAL, 2, NT>, false>("r32.32.16 twG wg512 o2");
+  add<wg_cfg<f, radix_list<16, 16, 8, 8>, 1024, 1, 4, 1, TW_GLOBAL, 4, NT>, false>("r16.16.8.8 twG wg1024 o4");
+  add<wg_cfg<f, radix_list<16, 16, 16, 4>, 1024, 1, 4, 1, TW_GLOBAL, 4, NT>, false>("r16.16.16.4 twG wg1024 o4");
+  add<wg_cfg<f, radix_list<32, 32, 16>, 512, 1, 0, 0, TW_GLOBAL, 2, NT>, false>("r32.32.16 twG wg512 nopad");
+#elif TUNE_CASE == 4096064
+  using S = radix_list<16, 16, 16>; using T = d; const int N = 4096;
+  add<wg_cfg<d, S, 256, 1, 4, 1, TW_GLOBAL, 2, NT>, false>("f64 twG o2");
+  add<wg_cfg<d, S, 256, 1, 4, 1, TW_GLOBAL, 1, NT>, true>("f64 twG o1 PF");
+  add<wg_cfg<d, S, 256, 1, 4, 1, TW_REGS, 1, NT>, false>("f64 twR o1");
+  add<wg_cfg<d, radix_list<8, 8, 8, 8>, 512, 1, 4, 1, TW_GLOBAL, 2, NT>, false>("f64 r8x4 wg512 o2");
+#elif TUNE_CASE == 16385
+  using S = radix_list<32, 32, 16>; using T = f; const int N = 16384;
+  add<wg_cfg<f, S, 512, 1, 0, 0, TW_GLOBAL, 2, NT>, false>("r32.32.16 twG wg512 nopad");
+  add<wg_cfg<f, S, 512, 1, 0, 0, TW_REGS, 2, NT>, false>("r32.32.16 twR wg512 nopad");
+  add<wg_cfg<f, S, 512, 1, 4, 1, TW_REGS, 2, NT>, false>("r32.32.16 twR wg512 pad");
+  add<wg_cfg<f, radix_list<32, 16, 32>, 512, 1, 0, 0, TW_REGS, 2, NT>, false>("r32.16.32 twR wg512 nopad");
+#elif TUNE_CASE == 1024064
+  using S = radix_list<16, 8, 8>; using T = d; const int N = 1024;
+  add<wg_cfg<d, S, 256, 4, 4, 1, TW_GLOBAL, 2, NT>, false>("f64 1024 twG fpw4 o2");
+  add<wg_cfg<d, S, 256, 4, 4, 1, TW_REGS, 2, NT>, false>("f64 1024 twR fpw4 o2");
+  add<wg_cfg<d, S, 64, 1, 4, 1, TW_REGS, 2, NT>, false>("f64 1024 twR wg64 fpw1 o2");
+  add<wg_cfg<d, S, 128, 2, 4, 1, TW_REGS, 2, NT>, false>("f64 1024 twR wg128 fpw2 o2");
+#elif TUNE_CASE == 2048064
+  using S = radix_list<16, 16, 8>; using T = d; const int N = 2048;
+  add<wg_cfg<d, S, 256, 2, 4, 1, TW_GLOBAL, 2, NT>, false>("f64 2048 twG fpw2 o2");
+  add<wg_cfg<d, S, 256, 2, 4, 1, TW_REGS, 2, NT>, false>("f64 2048 twR fpw2 o2");
+  add<wg_cfg<d, S, 128, 1, 4, 1, TW_REGS, 2, NT>, false>("f64 2048 twR wg128 fpw1 o2");
+#elif TUNE_CASE == 8192064
+  using S = radix_list<16, 16, 16, 2>; using T = d; const int N = 8192;
+  add<wg_cfg<d, S, 512, 1, 4, 1, TW_GLOBAL, 2, NT>, false>("f64 8192 r16.16.16.2 twG wg512");
+  add<wg_cfg<d, radix_list<32, 16, 16>, 256, 1, 4, 1, TW_GLOBAL, 1, NT>, false>("f64 8192 r32.16.16 twG wg256 o1");
+  add<wg_cfg<d, radix_list<32, 16, 16>, 256, 1, 0, 0, TW_GLOBAL, 1, NT>, false>("f64 8192 r32.16.16 twG wg256 nopad");
+  add<wg_cfg<d, radix_list<16, 8, 8, 8>, 512, 1, 4, 1, TW_GLOBAL, 2, NT>, false>("f64 8192 r16.8.8.8 twG wg512");
+#elif TUNE_CASE == 256
+  using S = radix_list<16, 16>; using T = f; const int N = 256;
+  add<wg_cfg<f, S, 256, 16, 4, 1, TW_GLOBAL, 4, NT>, false>("256 twG fpw16 o4");
+  add<wg_cfg<f, S, 256, 16, 4, 1, TW_REGS, 4, NT>, false>("256 twR fpw16 o4");
+  add<wg_cfg<f, S, 256, 16, 4, 1, TW_GLOBAL, 4, NT, 1>, false>("256 twG fpw16 o4 STAGED");
+  add<wg_cfg<f, S, 64, 4, 4, 1, TW_REGS, 4, NT>, false>("256 twR wg64 fpw4 o4");
+#elif TUNE_CASE == 512
+  using S = radix_list<8, 8, 8>; using T = f; const int N = 512;
+  add<wg_cfg<f, S, 256, 4, 4, 1, TW_GLOBAL, 4, NT>, false>("twG fpw4 o4");
+  add<wg_cfg<f, S, 256, 4, 4, 1, TW_REGS, 4, NT>, false>("twR fpw4 o4");
+  add<wg_cfg<f, S, 256, 4, 4, 1, TW_REGS, 4, NT>, true>("twR fpw4 o4 PF");
+  add<wg_cfg<f, radix_list<32, 16>, 256, 16, 4, 1, TW_GLOBAL, 2, NT>, false>("r32x16 twG fpw16 o2");
+  add<wg_cfg<f, radix_list<16, 32>, 256, 16, 4, 1, TW_GLOBAL, 2, NT>, false>("r16x32 twG fpw16 o2");
+  add<wg_cfg<f, S, 256, 4, 4, 1, TW_GLOBAL, 4, NT, 1>, false>("twG fpw4 o4 STAGED");
+#endif
+  const long long nfft = (long long)(bytes / (sizeof(cx<T>) * N));
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  struct gridopt { const char* name; int mode; int k; };
+  const gridopt gopts[] = {{"2xres", 0, 2}, {"4xres", 0, 4}, {"grp/8", 1, 8}, {"grp/4", 1, 4}, {"grp/2", 1, 2}, {"grp/1", 1, 1}};
+  const int NGO = sizeof(gopts) / sizeof(gopts[0]);
+  std::vector<std::vector<std::vector<float>>> times(g_variants.size(), std::vector<std::vector<float>>(NGO));
+  for (int round = 0; round < 6; ++round) {
+    for (size_t v = 0; v < g_variants.size(); ++v) {
+      int occ = 0; CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, g_variants[v].fn, g_variants[v].wg, g_variants[v].lds));
+      const long long groups = (nfft + g_variants[v].fpw - 1) / g_variants[v].fpw;
+      for (int go = 0; go < NGO; ++go) {
+        long long grid = gopts[go].mode == 0 ? (long long)gopts[go].k * occ * cus : (groups + gopts[go].k - 1) / gopts[go].k;
+        grid = std::max<long long>(1, std::min(grid, groups));
+        CK(hipEventRecord(e0));
+        g_variants[v].launch((unsigned)grid, nfft);
+        CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        if (round) times[v][go].push_back(ms);
+      }
+    }
+  }
+  CK(hipGetLastError());
+  for (size_t v = 0; v < g_variants.size(); ++v) {
+    int occ = 0; CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, g_variants[v].fn, g_variants[v].wg, g_variants[v].lds));
+    printf("%-28s occ=%d lds=%-6zu", g_variants[v].name.c_str(), occ, g_variants[v].lds);
+    for (int go = 0; go < NGO; ++go) {
+      auto t = times[v][go]; std::sort(t.begin(), t.end());
+      printf("  %s %.2f", gopts[go].name, 2.0 * bytes / t[t.size() / 2] * 1e-9);
+    }
+    printf("  TB/s\n");
+  }
+  return 0;
+}
