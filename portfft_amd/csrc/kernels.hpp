@@ -39,6 +39,7 @@ struct strided_kernel {
   size_t lds_bytes;
   int n_radices;
   int radices[8];
+  int groups_per_wg;  // tuned grid rule (see spec_kernel)
   const void* fn[4];  // [backward * 2 + store_modifier]
   hipError_t (*launch)(hipStream_t stream, unsigned grid, const strided_args& args, int backward, int store_modifier);
 };

@@ -51,7 +51,7 @@ const strided_kernel g_strided_f32[] = {
     make_strided_entry<wg_cfg<f, radix_list<16, 8>, 256, 32, 0, 0, TW_GLOBAL, 2, NT>>(),         // 128
     make_strided_entry<wg_cfg<f, radix_list<16, 16>, 256, 16, 0, 0, TW_GLOBAL, 2, NT>>(),        // 256
     make_strided_entry<wg_cfg<f, radix_list<8, 8, 8>, 1024, 16, 0, 0, TW_GLOBAL, 4, NT>>(),      // 512
-    make_strided_entry<wg_cfg<f, radix_list<16, 8, 8>, 1024, 16, 0, 0, TW_GLOBAL, 4, NT>>(),     // 1024
+    make_strided_entry_prefetch<wg_cfg<f, radix_list<32, 32>, 512, 16, 0, 0, TW_GLOBAL, 2, NT>>(4),  // 1024
     make_strided_entry<wg_cfg<f, radix_list<16, 16, 8>, 1024, 8, 0, 0, TW_GLOBAL, 4, NT>>(),     // 2048
     make_strided_entry<wg_cfg<f, radix_list<16, 16, 16>, 1024, 4, 0, 0, TW_GLOBAL, 4, NT>>(),    // 4096
 };

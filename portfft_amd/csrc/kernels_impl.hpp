@@ -95,8 +95,43 @@ hipError_t launch_strided(hipStream_t stream, unsigned grid, const strided_args&
 }
 
 template <typename Cfg>
-strided_kernel make_strided_entry() {
+hipError_t launch_strided_prefetch(hipStream_t stream, unsigned grid, const strided_args& args, int backward, int stw) {
+  constexpr size_t lds = strided_lds_bytes<Cfg>();
+  const dim3 g(grid), b(Cfg::WG);
+  if (backward) {
+    if (stw) {
+      hipLaunchKernelGGL((stockham_strided_prefetch_kernel<Cfg, true, true>), g, b, lds, stream, args);
+    } else {
+      hipLaunchKernelGGL((stockham_strided_prefetch_kernel<Cfg, true, false>), g, b, lds, stream, args);
+    }
+  } else {
+    if (stw) {
+      hipLaunchKernelGGL((stockham_strided_prefetch_kernel<Cfg, false, true>), g, b, lds, stream, args);
+    } else {
+      hipLaunchKernelGGL((stockham_strided_prefetch_kernel<Cfg, false, false>), g, b, lds, stream, args);
+    }
+  }
+  return hipGetLastError();
+}
+
+template <typename Cfg>
+strided_kernel make_strided_entry(int groups_per_wg = 1);
+
+template <typename Cfg>
+strided_kernel make_strided_entry_prefetch(int groups_per_wg = 4) {
+  strided_kernel k = make_strided_entry<Cfg>(groups_per_wg);
+  k.fn[0] = reinterpret_cast<const void*>(&stockham_strided_prefetch_kernel<Cfg, false, false>);
+  k.fn[1] = reinterpret_cast<const void*>(&stockham_strided_prefetch_kernel<Cfg, false, true>);
+  k.fn[2] = reinterpret_cast<const void*>(&stockham_strided_prefetch_kernel<Cfg, true, false>);
+  k.fn[3] = reinterpret_cast<const void*>(&stockham_strided_prefetch_kernel<Cfg, true, true>);
+  k.launch = &launch_strided_prefetch<Cfg>;
+  return k;
+}
+
+template <typename Cfg>
+strided_kernel make_strided_entry(int groups_per_wg) {
   strided_kernel k{};
+  k.groups_per_wg = groups_per_wg;
   k.precision = sizeof(typename Cfg::T) == 8 ? PFFT_PRECISION_F64 : PFFT_PRECISION_F32;
   k.n = Cfg::N;
   k.wg = Cfg::WG;

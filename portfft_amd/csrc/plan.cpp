@@ -285,7 +285,8 @@ struct plan_t {
                   "hipFuncSetAttribute");
       }
     }
-    s.grid = persistent_grid(k->fn[backward * 2], k->wg, k->lds_bytes, (count + k->fpw - 1) / k->fpw, 1);
+    s.grid = persistent_grid(k->fn[backward * 2], k->wg, k->lds_bytes, (count + k->fpw - 1) / k->fpw,
+                             k->groups_per_wg);
     return s;
   }
 
