@@ -51,6 +51,64 @@ PFA_DEV cx<T> mul_pi(cx<T> a) {
   return {-a.im, a.re};
 }
 
+/// a + (-i)*b and a - (-i)*b
+template <typename T>
+PFA_DEV cx<T> add_mi(cx<T> a, cx<T> b) {
+  return {a.re + b.im, a.im - b.re};
+}
+template <typename T>
+PFA_DEV cx<T> sub_mi(cx<T> a, cx<T> b) {
+  return {a.re - b.im, a.im + b.re};
+}
+/// a * (c - i*s) for a constant pair (c, s)
+template <typename T>
+PFA_DEV cx<T> mul_cs(cx<T> a, T c, T s) {
+  return {a.re * c + a.im * s, a.im * c - a.re * s};
+}
+
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(PFA_NO_PK_ASM)
+// fp32 on gfx950: one complex value = one 64-bit VGPR pair, arithmetic = packed-f32 VOP3P.  hipcc (ROCm 7.2) does not
+// use the per-half op_sel / neg modifiers of v_pk_*_f32: a complex multiply becomes 3 packed ops + a move, a
+// "+/- i" rotation 2 packed ops + a move (37 % of the N=4096 kernel's VALU instructions were moves).  The forms
+// below are the 2- and 1-instruction sequences; each asm statement is a single VALU instruction, so the scheduler
+// stays free to interleave them.
+typedef float pfa_v2f __attribute__((ext_vector_type(2)));
+PFA_DEV pfa_v2f to_v2(cx<float> a) { return __builtin_bit_cast(pfa_v2f, a); }
+PFA_DEV cx<float> from_v2(pfa_v2f a) { return __builtin_bit_cast(cx<float>, a); }
+
+template <>
+PFA_DEV cx<float> cmul<float>(cx<float> a, cx<float> b) {
+  pfa_v2f t, r;
+  const pfa_v2f x = to_v2(a), y = to_v2(b);
+  // t = (a.re*b.re, a.re*b.im);  r = (-a.im*b.im + t.lo, a.im*b.re + t.hi)
+  asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(t) : "v"(x), "v"(y));
+  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]" : "=v"(r) : "v"(x), "v"(y), "v"(t));
+  return from_v2(r);
+}
+template <>
+PFA_DEV cx<float> add_mi<float>(cx<float> a, cx<float> b) {
+  pfa_v2f r;
+  asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(to_v2(a)), "v"(to_v2(b)));
+  return from_v2(r);
+}
+template <>
+PFA_DEV cx<float> sub_mi<float>(cx<float> a, cx<float> b) {
+  pfa_v2f r;
+  asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(to_v2(a)), "v"(to_v2(b)));
+  return from_v2(r);
+}
+template <>
+PFA_DEV cx<float> mul_cs<float>(cx<float> a, float c, float s) {
+  pfa_v2f t, r;
+  const pfa_v2f x = to_v2(a);
+  const pfa_v2f k = {c, s};
+  // t = (a.re*c, a.im*c);  r = (a.im*s + t.lo, -a.re*s + t.hi)
+  asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(t) : "v"(x), "s"(k));
+  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[1,0,0]" : "=v"(r) : "v"(x), "s"(k), "v"(t));
+  return from_v2(r);
+}
+#endif
+
 #include "radix_constants.inc"
 
 /// compile-time loop: f(std::integral_constant<int, I>) for I in [B, E)
@@ -77,7 +135,7 @@ PFA_DEV cx<T> mul_root(cx<T> a) {
   } else {
     constexpr T c = static_cast<T>(unit_roots<R>::c[k]);
     constexpr T s = static_cast<T>(unit_roots<R>::s[k]);
-    return {a.re * c + a.im * s, a.im * c - a.re * s};
+    return mul_cs<T>(a, c, s);
   }
 }
 
@@ -144,11 +202,11 @@ PFA_DEV void dft(cx<T> (&v)[R]) {
     v[1] = a - b;
   } else if constexpr (R == 4) {
     const cx<T> a = v[0] + v[2], b = v[0] - v[2];
-    const cx<T> c = v[1] + v[3], d = mul_mi(v[1] - v[3]);
+    const cx<T> c = v[1] + v[3], e = v[1] - v[3];
     v[0] = a + c;
-    v[1] = b + d;
+    v[1] = add_mi(b, e);
     v[2] = a - c;
-    v[3] = b - d;
+    v[3] = sub_mi(b, e);
   } else if constexpr (is_prime(R)) {
     dft_odd_prime<R>(v);
   } else {

@@ -117,6 +117,14 @@ int main() {
   add<wg_cfg<f, S, 256, 16, 4, 1, TW_REGS, 4, NT>, false>("256 twR fpw16 o4");
   add<wg_cfg<f, S, 256, 16, 4, 1, TW_GLOBAL, 4, NT, 1>, false>("256 twG fpw16 o4 STAGED");
   add<wg_cfg<f, S, 64, 4, 4, 1, TW_REGS, 4, NT>, false>("256 twR wg64 fpw4 o4");
+#elif TUNE_CASE == 4096
+  using S = radix_list<16, 16, 16>; using T = f; const int N = 4096;
+  add<wg_cfg<f, S, 256, 1, 4, 1, TW_REGS, 3, NT>, true>("twR o3 PF (current)");
+  add<wg_cfg<f, S, 256, 1, 4, 1, TW_REGS, 4, NT>, true>("twR o4 PF");
+  add<wg_cfg<f, S, 256, 1, 4, 1, TW_REGS, 4, NT>, false>("twR o4");
+  add<wg_cfg<f, S, 256, 1, 4, 1, TW_GLOBAL, 4, NT>, true>("twG o4 PF");
+  add<wg_cfg<f, S, 256, 1, 4, 1, TW_GLOBAL, 4, NT>, false>("twG o4");
+  add<wg_cfg<f, S, 256, 1, 4, 1, TW_GLOBAL, 5, NT>, false>("twG o5");
 #elif TUNE_CASE == 512
   using S = radix_list<8, 8, 8>; using T = f; const int N = 512;
   add<wg_cfg<f, S, 256, 4, 4, 1, TW_GLOBAL, 4, NT>, false>("twG fpw4 o4");
