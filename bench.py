@@ -147,8 +147,13 @@ def main():
 
     world, rank, local_rank = env_world()
     distributed = world > 1
-    torch.cuda.set_device(local_rank if distributed else 0)
-    pg = process_group("nccl", torch.device("cuda", torch.cuda.current_device()))
+    # one process per GPU; PFFT_BENCH_BACKEND=gloo + PFFT_BENCH_ONE_DEVICE=1 exist only to smoke-test the multi-rank
+    # plumbing on a single-GPU box (every rank on device 0, scalar collectives over gloo)
+    one_device = os.environ.get("PFFT_BENCH_ONE_DEVICE") == "1"
+    backend = os.environ.get("PFFT_BENCH_BACKEND", "nccl")
+    torch.cuda.set_device(local_rank if (distributed and not one_device) else 0)
+    cuda_dev = torch.device("cuda", torch.cuda.current_device())
+    pg = process_group(backend, cuda_dev if backend == "nccl" else torch.device("cpu"))
     if args.gpus != world and rank == 0:
         print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
     # weak scaling: the global batch is BATCH_PER_GPU * world transforms, sharded contiguously

@@ -45,9 +45,11 @@ class process_group:
                 dist.init_process_group(backend)
 
     def barrier(self):
+        if self.torch.cuda.is_available():
+            self.torch.cuda.synchronize()
         if self.active:
             self.dist.barrier()
-        if self.device.type == "cuda":
+        if self.torch.cuda.is_available():
             self.torch.cuda.synchronize()
 
     def max(self, value):
