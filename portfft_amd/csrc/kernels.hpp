@@ -28,6 +28,10 @@ struct spec_kernel {
   const void* fn[2];  // kernel symbols, [0] forward, [1] backward (for occupancy queries / attributes)
   hipError_t (*launch)(hipStream_t stream, unsigned grid, const void* in, void* out, const void* tw, long long nfft,
                        double scale, int backward);
+  /// SPLIT_COMPLEX form (separate real / imaginary planes); fn_split are its kernel symbols
+  const void* fn_split[2];
+  hipError_t (*launch_split)(hipStream_t stream, unsigned grid, const void* in_re, const void* in_im, void* out_re,
+                             void* out_im, const void* tw, long long nfft, double scale, int backward);
 };
 
 /// One strided work-group kernel (stockham_strided.hpp): FPW FFTs side by side, any element stride / FFT distance.
@@ -42,6 +46,9 @@ struct strided_kernel {
   int groups_per_wg;  // tuned grid rule (see spec_kernel)
   const void* fn[4];  // [backward * 2 + store_modifier]
   hipError_t (*launch)(hipStream_t stream, unsigned grid, const strided_args& args, int backward, int store_modifier);
+  /// SPLIT_COMPLEX form on both sides (no store modifier); fn_split[backward]
+  const void* fn_split[2];
+  hipError_t (*launch_split)(hipStream_t stream, unsigned grid, const strided_args& args, int backward);
 };
 
 const strided_kernel* strided_kernels_f32(int* count);

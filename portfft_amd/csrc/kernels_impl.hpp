@@ -43,6 +43,24 @@ hipError_t launch_spec(hipStream_t stream, unsigned grid, const void* in, void* 
 }
 
 template <typename Cfg>
+hipError_t launch_spec_split(hipStream_t stream, unsigned grid, const void* in_re, const void* in_im, void* out_re,
+                             void* out_im, const void* tw, long long nfft, double scale, int backward) {
+  using T = typename Cfg::T;
+  const auto* t = static_cast<const cx<T>*>(tw);
+  const dim3 g(grid), b(Cfg::WG);
+  if (backward) {
+    hipLaunchKernelGGL((stockham_wg_split_kernel<Cfg, true>), g, b, Cfg::LDS_BYTES, stream, static_cast<const T*>(in_re),
+                       static_cast<const T*>(in_im), static_cast<T*>(out_re), static_cast<T*>(out_im), t, nfft,
+                       static_cast<T>(scale));
+  } else {
+    hipLaunchKernelGGL((stockham_wg_split_kernel<Cfg, false>), g, b, Cfg::LDS_BYTES, stream,
+                       static_cast<const T*>(in_re), static_cast<const T*>(in_im), static_cast<T*>(out_re),
+                       static_cast<T*>(out_im), t, nfft, static_cast<T>(scale));
+  }
+  return hipGetLastError();
+}
+
+template <typename Cfg>
 spec_kernel make_spec_entry(int groups_per_wg = 1);
 
 /// software-pipelined form (stockham_wg_prefetch_kernel) of a direct-I/O multi-pass variant
@@ -71,6 +89,9 @@ spec_kernel make_spec_entry(int groups_per_wg) {
   k.fn[0] = reinterpret_cast<const void*>(&stockham_wg_kernel<Cfg, false>);
   k.fn[1] = reinterpret_cast<const void*>(&stockham_wg_kernel<Cfg, true>);
   k.launch = &launch_spec<Cfg>;
+  k.fn_split[0] = reinterpret_cast<const void*>(&stockham_wg_split_kernel<Cfg, false>);
+  k.fn_split[1] = reinterpret_cast<const void*>(&stockham_wg_split_kernel<Cfg, true>);
+  k.launch_split = &launch_spec_split<Cfg>;
   return k;
 }
 
@@ -115,6 +136,17 @@ hipError_t launch_strided_prefetch(hipStream_t stream, unsigned grid, const stri
 }
 
 template <typename Cfg>
+hipError_t launch_strided_split(hipStream_t stream, unsigned grid, const strided_args& args, int backward) {
+  constexpr size_t lds = strided_lds_bytes<Cfg>();
+  if (backward) {
+    hipLaunchKernelGGL((stockham_strided_kernel<Cfg, true, false, true>), dim3(grid), dim3(Cfg::WG), lds, stream, args);
+  } else {
+    hipLaunchKernelGGL((stockham_strided_kernel<Cfg, false, false, true>), dim3(grid), dim3(Cfg::WG), lds, stream, args);
+  }
+  return hipGetLastError();
+}
+
+template <typename Cfg>
 strided_kernel make_strided_entry(int groups_per_wg = 1);
 
 template <typename Cfg>
@@ -144,6 +176,9 @@ strided_kernel make_strided_entry(int groups_per_wg) {
   k.fn[2] = reinterpret_cast<const void*>(&stockham_strided_kernel<Cfg, true, false>);
   k.fn[3] = reinterpret_cast<const void*>(&stockham_strided_kernel<Cfg, true, true>);
   k.launch = &launch_strided<Cfg>;
+  k.fn_split[0] = reinterpret_cast<const void*>(&stockham_strided_kernel<Cfg, false, false, true>);
+  k.fn_split[1] = reinterpret_cast<const void*>(&stockham_strided_kernel<Cfg, true, false, true>);
+  k.launch_split = &launch_strided_split<Cfg>;
   return k;
 }
 

@@ -241,8 +241,9 @@ struct plan_t {
   bool strided_fits(const strided_kernel* k, long long inner_count, int in_buf, const addressing& ia, int out_buf,
                     const addressing& oa) const {
     if (k == nullptr) return false;
+    // split storage: both sides must be user buffers (split variant) or both scratch (interleaved variant)
     const bool split = desc.complex_storage == PFFT_SPLIT_COMPLEX;
-    if (split && (in_buf != BUF_SCRATCH || out_buf != BUF_SCRATCH)) return false;
+    if (split && ((in_buf == BUF_SCRATCH) != (out_buf == BUF_SCRATCH))) return false;
     if (inner_count % k->fpw != 0) return false;
     auto range_ok = [&](const addressing& a) {
       const unsigned long long elems = static_cast<unsigned long long>(k->fpw - 1) * a.dist_inner +
@@ -281,6 +282,9 @@ struct plan_t {
     for (int i = 0; i < 4; ++i) {
       if (k->lds_bytes > 48 * 1024) {
         hip_check(hipFuncSetAttribute(k->fn[i], hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      static_cast<int>(k->lds_bytes)),
+                  "hipFuncSetAttribute");
+        hip_check(hipFuncSetAttribute(k->fn_split[i / 2], hipFuncAttributeMaxDynamicSharedMemorySize,
                                       static_cast<int>(k->lds_bytes)),
                   "hipFuncSetAttribute");
       }
@@ -339,6 +343,9 @@ struct plan_t {
     for (int d = 0; d < 2; ++d) {
       if (k->lds_bytes > 48 * 1024) {
         hip_check(hipFuncSetAttribute(k->fn[d], hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      static_cast<int>(k->lds_bytes)),
+                  "hipFuncSetAttribute");
+        hip_check(hipFuncSetAttribute(k->fn_split[d], hipFuncAttributeMaxDynamicSharedMemorySize,
                                       static_cast<int>(k->lds_bytes)),
                   "hipFuncSetAttribute");
       }
@@ -435,7 +442,7 @@ struct plan_t {
       info->ffts_per_workgroup = fpw;
       info->lds_bytes = lds;
     };
-    if (packed_io && interleaved) {
+    if (packed_io && (interleaved || (in_buf != BUF_SCRATCH && out_buf != BUF_SCRATCH))) {
       if (const spec_kernel* k = find_spec(n)) {
         out.push_back(make_spec_stage(k, count, in_buf, ia.offset, out_buf, oa.offset, scale, backward));
         record(k->n_radices == 1 ? PFFT_TIER_REGISTER : PFFT_TIER_WORKGROUP,
@@ -635,15 +642,34 @@ struct plan_t {
     if (s.strided != nullptr) {
       strided_args a = s.sa;
       a.total = count;
+      const long long groups = (count + s.strided->fpw - 1) / s.strided->fpw;
+      const unsigned grid = static_cast<unsigned>(std::min<long long>(s.grid, std::max<long long>(groups, 1)));
+      if (split && s.in_buf != BUF_SCRATCH) {  // strided_fits: then the output is a user buffer too
+        const size_t io = static_cast<size_t>(s.in_addr.offset + in_shift) * sb;
+        const size_t oo = static_cast<size_t>(s.out_addr.offset + out_shift) * sb;
+        a.in = base_re(s.in_buf, true) + io;
+        a.in_im = base_im(s.in_buf) + io;
+        a.out = const_cast<char*>(base_re(s.out_buf, false)) + oo;
+        a.out_im = const_cast<char*>(base_im(s.out_buf)) + oo;
+        hip_check(s.strided->launch_split(stream, grid, a, s.backward), "kernel launch");
+        return;
+      }
       a.in = base_re(s.in_buf, true) + static_cast<size_t>(s.in_addr.offset + in_shift) * elem_bytes();
       a.out = const_cast<char*>(base_re(s.out_buf, false)) +
               static_cast<size_t>(s.out_addr.offset + out_shift) * elem_bytes();
-      const long long groups = (count + s.strided->fpw - 1) / s.strided->fpw;
-      const unsigned grid = static_cast<unsigned>(std::min<long long>(s.grid, std::max<long long>(groups, 1)));
       hip_check(s.strided->launch(stream, grid, a, s.backward, s.store_modifier), "kernel launch");
       return;
     }
     if (!s.generic) {
+      if (split) {  // spec stages only touch user buffers when the storage is split (plan_1d)
+        const size_t io = static_cast<size_t>(s.in_offset) * sb, oo = static_cast<size_t>(s.out_offset) * sb;
+        const char* sr = static_cast<const char*>(s.in_buf == BUF_IN ? in_re : out_re);
+        const char* si = static_cast<const char*>(s.in_buf == BUF_IN ? in_im : out_im);
+        hip_check(s.spec->launch_split(stream, s.grid, sr + io, si + io, static_cast<char*>(out_re) + oo,
+                                       static_cast<char*>(out_im) + oo, s.tw, s.count, s.scale, s.backward),
+                  "kernel launch");
+        return;
+      }
       const char* i = base_re(s.in_buf, true) + static_cast<size_t>(s.in_offset) * elem_bytes();
       char* o = const_cast<char*>(base_re(s.out_buf, false)) + static_cast<size_t>(s.out_offset) * elem_bytes();
       hip_check(s.spec->launch(stream, s.grid, i, o, s.tw, s.count, s.scale, s.backward), "kernel launch");

@@ -18,8 +18,30 @@
 
 namespace pfa {
 
-template <typename Cfg, bool BWD, bool STW, int P>
-PFA_DEV void strided_pass(__amdgpu_buffer_rsrc_t rin, __amdgpu_buffer_rsrc_t rout, const strided_args& a, unsigned f,
+/// The descriptors of one group: interleaved (one per side) or split (real + imaginary plane per side).
+template <typename T, int AUX, bool SPLIT>
+struct strided_io {
+  static constexpr unsigned ES = SPLIT ? sizeof(T) : sizeof(cx<T>);
+  __amdgpu_buffer_rsrc_t rin, rout, rin_im, rout_im;
+  PFA_DEV cx<T> load(unsigned voff, unsigned soff) const {
+    if constexpr (SPLIT) {
+      return {buf_load_scalar<T, AUX>(rin, voff, soff), buf_load_scalar<T, AUX>(rin_im, voff, soff)};
+    } else {
+      return buf_load<T, AUX>(rin, voff, soff);
+    }
+  }
+  PFA_DEV void store(cx<T> v, unsigned voff, unsigned soff) const {
+    if constexpr (SPLIT) {
+      buf_store_scalar<T, AUX>(v.re, rout, voff, soff);
+      buf_store_scalar<T, AUX>(v.im, rout_im, voff, soff);
+    } else {
+      buf_store<T, AUX>(v, rout, voff, soff);
+    }
+  }
+};
+
+template <typename Cfg, bool BWD, bool STW, int P, typename IO>
+PFA_DEV void strided_pass(const IO& io, const strided_args& a, unsigned f,
                           unsigned tid, bool live, long long c0, cx<typename Cfg::T>* lds,
                           const cx<typename Cfg::T>* __restrict__ tw) {
   using T = typename Cfg::T;
@@ -33,7 +55,7 @@ PFA_DEV void strided_pass(__amdgpu_buffer_rsrc_t rin, __amdgpu_buffer_rsrc_t rou
   constexpr bool first = P == 0;
   constexpr bool last = P == Cfg::NP - 1;
   constexpr int FPW = Cfg::FPW;
-  constexpr unsigned ES = sizeof(cx<T>);
+  constexpr unsigned ES = IO::ES;
 
   cx<T> v[BPT][R];
   sfor<0, BPT>([&](auto i_) PFA_LAMBDA {
@@ -45,7 +67,7 @@ PFA_DEV void strided_pass(__amdgpu_buffer_rsrc_t rin, __amdgpu_buffer_rsrc_t rou
         const unsigned voff = live ? (f * a.in_fdist + j * a.in_stride) * ES : 0xFFFFFFF0u;
         sfor<0, R>([&](auto t_) PFA_LAMBDA {
           constexpr int t = decltype(t_)::value;
-          cx<T> x = buf_load<T, Cfg::AUX>(rin, voff, static_cast<unsigned>(t * NB) * a.in_stride * ES);
+          cx<T> x = io.load(voff, static_cast<unsigned>(t * NB) * a.in_stride * ES);
           if constexpr (BWD) x.im = -x.im;
           v[i][t] = x;
         });
@@ -88,7 +110,7 @@ PFA_DEV void strided_pass(__amdgpu_buffer_rsrc_t rin, __amdgpu_buffer_rsrc_t rou
           if constexpr (BWD) y.im = -y.im;
           y.re *= scale;
           y.im *= scale;
-          buf_store<T, Cfg::AUX>(y, rout, voff, static_cast<unsigned>(u * Ns) * a.out_stride * ES);
+          io.store(y, voff, static_cast<unsigned>(u * Ns) * a.out_stride * ES);
         });
       } else {
         cx<T>* p = lds + base * FPW + f;
@@ -102,25 +124,24 @@ PFA_DEV void strided_pass(__amdgpu_buffer_rsrc_t rin, __amdgpu_buffer_rsrc_t rou
   if constexpr (!last) __syncthreads();
 }
 
-template <typename Cfg, bool BWD, bool STW, int P>
-PFA_DEV void strided_passes(__amdgpu_buffer_rsrc_t rin, __amdgpu_buffer_rsrc_t rout, const strided_args& a,
-                            unsigned f, unsigned tid, bool live, long long c0, cx<typename Cfg::T>* lds,
-                            const cx<typename Cfg::T>* __restrict__ tw) {
+template <typename Cfg, bool BWD, bool STW, int P, typename IO>
+PFA_DEV void strided_passes(const IO& io, const strided_args& a, unsigned f, unsigned tid, bool live, long long c0,
+                            cx<typename Cfg::T>* lds, const cx<typename Cfg::T>* __restrict__ tw) {
   if constexpr (P < Cfg::NP) {
-    strided_pass<Cfg, BWD, STW, P>(rin, rout, a, f, tid, live, c0, lds, tw);
-    strided_passes<Cfg, BWD, STW, P + 1>(rin, rout, a, f, tid, live, c0, lds, tw);
+    strided_pass<Cfg, BWD, STW, P>(io, a, f, tid, live, c0, lds, tw);
+    strided_passes<Cfg, BWD, STW, P + 1>(io, a, f, tid, live, c0, lds, tw);
   }
 }
 
 /// Pass 0 of the strided kernel split in two (loads / butterfly + scatter) for the prefetching variant.
-template <typename Cfg, bool BWD>
-PFA_DEV void strided_pass0_load(__amdgpu_buffer_rsrc_t rin, const strided_args& a, unsigned f, unsigned tid, bool live,
+template <typename Cfg, bool BWD, typename IO>
+PFA_DEV void strided_pass0_load(const IO& io, const strided_args& a, unsigned f, unsigned tid, bool live,
                                 cx<typename Cfg::T> (&v)[Cfg::bpt(0)][Cfg::Seq::r[0]]) {
   using T = typename Cfg::T;
   constexpr int R = Cfg::Seq::r[0];
   constexpr int NB = Cfg::N / R;
   constexpr bool ragged = (NB % Cfg::TPF) != 0;
-  constexpr unsigned ES = sizeof(cx<T>);
+  constexpr unsigned ES = IO::ES;
   sfor<0, Cfg::bpt(0)>([&](auto i_) PFA_LAMBDA {
     constexpr int i = decltype(i_)::value;
     const unsigned j = tid + i * Cfg::TPF;
@@ -128,7 +149,7 @@ PFA_DEV void strided_pass0_load(__amdgpu_buffer_rsrc_t rin, const strided_args& 
       const unsigned voff = live ? (f * a.in_fdist + j * a.in_stride) * ES : 0xFFFFFFF0u;
       sfor<0, R>([&](auto t_) PFA_LAMBDA {
         constexpr int t = decltype(t_)::value;
-        cx<T> x = buf_load<T, Cfg::AUX>(rin, voff, static_cast<unsigned>(t * NB) * a.in_stride * ES);
+        cx<T> x = io.load(voff, static_cast<unsigned>(t * NB) * a.in_stride * ES);
         if constexpr (BWD) x.im = -x.im;
         v[i][t] = x;
       });
@@ -157,29 +178,44 @@ PFA_DEV void strided_pass0_compute(cx<typename Cfg::T> (&v)[Cfg::bpt(0)][Cfg::Se
   __syncthreads();
 }
 
-template <typename Cfg>
-PFA_DEV void strided_group(const strided_args& a, long long g, unsigned f, __amdgpu_buffer_rsrc_t* rin,
-                           __amdgpu_buffer_rsrc_t* rout, bool* live, long long* c0_out) {
+template <typename Cfg, bool SPLIT>
+PFA_DEV strided_io<typename Cfg::T, Cfg::AUX, SPLIT> strided_group(const strided_args& a, long long g, unsigned f,
+                                                                   bool* live, long long* c0_out) {
   using T = typename Cfg::T;
-  constexpr unsigned ES = sizeof(cx<T>);
+  using IO = strided_io<T, Cfg::AUX, SPLIT>;
+  constexpr unsigned ES = IO::ES;
   const long long t0 = g * Cfg::FPW;
   const long long o = t0 / a.inner;
   const long long c0 = t0 - o * a.inner;
   *live = static_cast<long long>(f) < a.total - t0;
   *c0_out = c0;
-  const cx<T>* in0 = static_cast<const cx<T>*>(a.in) + o * a.in_dist_outer + c0 * a.in_fdist;
-  cx<T>* out0 = static_cast<cx<T>*>(a.out) + o * a.out_dist_outer + c0 * a.out_fdist;
+  const long long ioff = o * a.in_dist_outer + c0 * a.in_fdist;
+  const long long ooff = o * a.out_dist_outer + c0 * a.out_fdist;
+  // ranges: last element of the last FFT of the group (the planner guarantees < 4 GiB)
   const unsigned in_bytes =
       (static_cast<unsigned>(Cfg::FPW - 1) * a.in_fdist + static_cast<unsigned>(Cfg::N - 1) * a.in_stride + 1) * ES;
   const unsigned out_bytes =
       (static_cast<unsigned>(Cfg::FPW - 1) * a.out_fdist + static_cast<unsigned>(Cfg::N - 1) * a.out_stride + 1) * ES;
-  *rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<cx<T>*>(in0), 0, in_bytes, 0x00020000);
-  *rout = __builtin_amdgcn_make_buffer_rsrc(out0, 0, out_bytes, 0x00020000);
+  IO io;
+  char* ip = const_cast<char*>(static_cast<const char*>(a.in)) + ioff * ES;
+  char* op = static_cast<char*>(a.out) + ooff * ES;
+  io.rin = __builtin_amdgcn_make_buffer_rsrc(ip, 0, in_bytes, 0x00020000);
+  io.rout = __builtin_amdgcn_make_buffer_rsrc(op, 0, out_bytes, 0x00020000);
+  if constexpr (SPLIT) {
+    char* ipi = const_cast<char*>(static_cast<const char*>(a.in_im)) + ioff * ES;
+    char* opi = static_cast<char*>(a.out_im) + ooff * ES;
+    io.rin_im = __builtin_amdgcn_make_buffer_rsrc(ipi, 0, in_bytes, 0x00020000);
+    io.rout_im = __builtin_amdgcn_make_buffer_rsrc(opi, 0, out_bytes, 0x00020000);
+  } else {
+    io.rin_im = io.rin;
+    io.rout_im = io.rout;
+  }
+  return io;
 }
 
 /// Software-pipelined strided kernel: the loads of the work-group's next group are in flight during the LDS passes
 /// of the current one (see stockham_wg_prefetch_kernel).
-template <typename Cfg, bool BWD, bool STW>
+template <typename Cfg, bool BWD, bool STW, bool SPLIT = false>
 __global__ __launch_bounds__(Cfg::WG, Cfg::OCC) void stockham_strided_prefetch_kernel(const strided_args a) {
   using T = typename Cfg::T;
   static_assert(Cfg::NP >= 2, "the strided tier needs at least two passes (LDS exchange)");
@@ -193,24 +229,23 @@ __global__ __launch_bounds__(Cfg::WG, Cfg::OCC) void stockham_strided_prefetch_k
   if (g >= ngroups) return;
   cx<T> cur[Cfg::bpt(0)][Cfg::Seq::r[0]];
   cx<T> nxt[Cfg::bpt(0)][Cfg::Seq::r[0]];
-  __amdgpu_buffer_rsrc_t rin, rout, rin_n, rout_n;
-  bool live, live_n;
-  long long c0, c0_n;
-  strided_group<Cfg>(a, g, f, &rin, &rout, &live, &c0);
-  strided_pass0_load<Cfg, BWD>(rin, a, f, tid, live, cur);
+  bool live, live_n = false;
+  long long c0, c0_n = 0;
+  auto io = strided_group<Cfg, SPLIT>(a, g, f, &live, &c0);
+  auto io_n = io;
+  strided_pass0_load<Cfg, BWD>(io, a, f, tid, live, cur);
   for (; g < ngroups; g += gridDim.x) {
     strided_pass0_compute<Cfg>(cur, f, tid, lds);
     const long long gn = g + gridDim.x;
     if (gn < ngroups) {
-      strided_group<Cfg>(a, gn, f, &rin_n, &rout_n, &live_n, &c0_n);
-      strided_pass0_load<Cfg, BWD>(rin_n, a, f, tid, live_n, nxt);
+      io_n = strided_group<Cfg, SPLIT>(a, gn, f, &live_n, &c0_n);
+      strided_pass0_load<Cfg, BWD>(io_n, a, f, tid, live_n, nxt);
     }
-    strided_passes<Cfg, BWD, STW, 1>(rin, rout, a, f, tid, live, c0, lds, tw);
+    strided_passes<Cfg, BWD, STW, 1>(io, a, f, tid, live, c0, lds, tw);
     sfor<0, Cfg::bpt(0)>([&](auto i_) PFA_LAMBDA {
       sfor<0, Cfg::Seq::r[0]>([&](auto t_) PFA_LAMBDA { cur[decltype(i_)::value][decltype(t_)::value] = nxt[decltype(i_)::value][decltype(t_)::value]; });
     });
-    rin = rin_n;
-    rout = rout_n;
+    io = io_n;
     live = live_n;
     c0 = c0_n;
   }
@@ -222,7 +257,7 @@ constexpr size_t strided_lds_bytes() {
   return Cfg::NP > 1 ? size_t(Cfg::N) * Cfg::FPW * sizeof(cx<typename Cfg::T>) : 0;
 }
 
-template <typename Cfg, bool BWD, bool STW>
+template <typename Cfg, bool BWD, bool STW, bool SPLIT = false>
 __global__ __launch_bounds__(Cfg::WG, Cfg::OCC) void stockham_strided_kernel(const strided_args a) {
   using T = typename Cfg::T;
   static_assert(Cfg::NP >= 2, "the strided tier needs at least two passes (LDS exchange)");
@@ -232,25 +267,12 @@ __global__ __launch_bounds__(Cfg::WG, Cfg::OCC) void stockham_strided_kernel(con
   const unsigned tid = threadIdx.x / Cfg::FPW;
   const cx<T>* __restrict__ tw = static_cast<const cx<T>*>(a.tw);
   const long long ngroups = (a.total + Cfg::FPW - 1) / Cfg::FPW;
-  constexpr unsigned ES = sizeof(cx<T>);
   for (long long g = blockIdx.x; g < ngroups; g += gridDim.x) {
-    const long long t0 = g * Cfg::FPW;
-    const long long o = t0 / a.inner;
-    const long long c0 = t0 - o * a.inner;
-    const long long left = a.total - t0;
-    const bool live = static_cast<long long>(f) < left;
-    const cx<T>* in0 = static_cast<const cx<T>*>(a.in) + o * a.in_dist_outer + c0 * a.in_fdist;
-    cx<T>* out0 = static_cast<cx<T>*>(a.out) + o * a.out_dist_outer + c0 * a.out_fdist;
-    // ranges: last element of the last FFT of the group (the planner guarantees < 4 GiB)
-    const unsigned in_bytes =
-        (static_cast<unsigned>(Cfg::FPW - 1) * a.in_fdist + static_cast<unsigned>(Cfg::N - 1) * a.in_stride + 1) * ES;
-    const unsigned out_bytes =
-        (static_cast<unsigned>(Cfg::FPW - 1) * a.out_fdist + static_cast<unsigned>(Cfg::N - 1) * a.out_stride + 1) * ES;
-    const __amdgpu_buffer_rsrc_t rin =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<cx<T>*>(in0), 0, in_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc(out0, 0, out_bytes, 0x00020000);
+    bool live;
+    long long c0;
+    const auto io = strided_group<Cfg, SPLIT>(a, g, f, &live, &c0);
     // no barrier needed here: the last pass ends its LDS reads with a barrier before the next group's first write
-    strided_passes<Cfg, BWD, STW, 0>(rin, rout, a, f, tid, live, c0, lds, tw);
+    strided_passes<Cfg, BWD, STW, 0>(io, a, f, tid, live, c0, lds, tw);
   }
 }
 

@@ -144,6 +144,7 @@ PFA_DEV void buf_store(cx<T> v, __amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsi
 /// that exist (ragged last group: missing FFTs read zeros and their stores are dropped by the range check).
 template <typename T, int N, int FPW, int AUX>
 struct packed_io {
+  static constexpr unsigned ES = sizeof(cx<T>);
   __amdgpu_buffer_rsrc_t rin, rout;
   PFA_DEV packed_io(const cx<T>* in, cx<T>* out, long long g, long long nfft) {
     const long long first = g * FPW;
@@ -158,6 +159,51 @@ struct packed_io {
   static constexpr unsigned step(int k) { return k * sizeof(cx<T>); }
   PFA_DEV cx<T> load(unsigned voff, unsigned soff) const { return buf_load<T, AUX>(rin, voff, soff); }
   PFA_DEV void store(cx<T> v, unsigned voff, unsigned soff) const { buf_store<T, AUX>(v, rout, voff, soff); }
+};
+
+using buf_b32_t = decltype(__builtin_amdgcn_raw_buffer_load_b32(std::declval<__amdgpu_buffer_rsrc_t>(), 0u, 0u, 0));
+
+template <typename T, int AUX>
+PFA_DEV T buf_load_scalar(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff) {
+  if constexpr (sizeof(T) == 4) {
+    return __builtin_bit_cast(T, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, soff, AUX));
+  } else {
+    return __builtin_bit_cast(T, __builtin_amdgcn_raw_buffer_load_b64(rsrc, voff, soff, AUX));
+  }
+}
+template <typename T, int AUX>
+PFA_DEV void buf_store_scalar(T v, __amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff) {
+  if constexpr (sizeof(T) == 4) {
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(buf_b32_t, v), rsrc, voff, soff, AUX);
+  } else {
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(buf_b64_t, v), rsrc, voff, soff, AUX);
+  }
+}
+
+/// PACKED layout with SPLIT_COMPLEX storage (reference: complex_storage::SPLIT_COMPLEX, enums.hpp:27; the
+/// `else` storage branches of the dispatchers): separate real and imaginary planes, same element indexing.
+template <typename T, int N, int FPW, int AUX>
+struct packed_split_io {
+  static constexpr unsigned ES = sizeof(T);
+  __amdgpu_buffer_rsrc_t rin_re, rin_im, rout_re, rout_im;
+  PFA_DEV packed_split_io(const T* in_re, const T* in_im, T* out_re, T* out_im, long long g, long long nfft) {
+    const long long first = g * FPW;
+    const long long left = nfft - first;
+    const unsigned bytes = static_cast<unsigned>((left < FPW ? left : FPW) * N * sizeof(T));
+    rin_re = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(in_re + first * N), 0, bytes, 0x00020000);
+    rin_im = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(in_im + first * N), 0, bytes, 0x00020000);
+    rout_re = __builtin_amdgcn_make_buffer_rsrc(out_re + first * N, 0, bytes, 0x00020000);
+    rout_im = __builtin_amdgcn_make_buffer_rsrc(out_im + first * N, 0, bytes, 0x00020000);
+  }
+  static PFA_DEV unsigned lane_off(unsigned f, unsigned j) { return (f * N + j) * ES; }
+  static constexpr unsigned step(int k) { return k * ES; }
+  PFA_DEV cx<T> load(unsigned voff, unsigned soff) const {
+    return {buf_load_scalar<T, AUX>(rin_re, voff, soff), buf_load_scalar<T, AUX>(rin_im, voff, soff)};
+  }
+  PFA_DEV void store(cx<T> v, unsigned voff, unsigned soff) const {
+    buf_store_scalar<T, AUX>(v.re, rout_re, voff, soff);
+    buf_store_scalar<T, AUX>(v.im, rout_im, voff, soff);
+  }
 };
 
 template <typename Cfg, bool BWD, int P, typename IO>
@@ -378,12 +424,10 @@ __global__ __launch_bounds__(Cfg::WG, Cfg::OCC) void stockham_wg_prefetch_kernel
   }
 }
 
-/// Persistent work-group kernel: work-group g handles FFT groups g, g+G, ...  (FPW FFTs per group).
-template <typename Cfg, bool BWD>
-__global__ __launch_bounds__(Cfg::WG, Cfg::OCC) void stockham_wg_kernel(const cx<typename Cfg::T>* __restrict__ in,
-                                                              cx<typename Cfg::T>* __restrict__ out,
-                                                              const cx<typename Cfg::T>* __restrict__ tw,
-                                                              long long nfft, typename Cfg::T scale) {
+/// Body shared by the interleaved and the split-storage kernels: `make_io(g)` builds the group's I/O object.
+template <typename Cfg, bool BWD, typename MakeIO>
+PFA_DEV void stockham_wg_body(MakeIO&& make_io, const cx<typename Cfg::T>* __restrict__ tw, long long nfft,
+                              typename Cfg::T scale) {
   using T = typename Cfg::T;
   using Seq = typename Cfg::Seq;
   extern __shared__ __attribute__((aligned(16))) char pfa_smem[];
@@ -410,7 +454,8 @@ __global__ __launch_bounds__(Cfg::WG, Cfg::OCC) void stockham_wg_kernel(const cx
 
   const long long ngroups = (nfft + Cfg::FPW - 1) / Cfg::FPW;
   for (long long g = blockIdx.x; g < ngroups; g += gridDim.x) {
-    const packed_io<T, Cfg::N, Cfg::FPW, Cfg::AUX> io(in, out, g, nfft);
+    const auto io = make_io(g);
+    using IO = decltype(io);
     if constexpr (Cfg::STAGED) {
       // coalesced copy of the group's FPW*N contiguous elements into the (padded) per-FFT LDS images
       constexpr int CH = Cfg::FPW * Cfg::N;
@@ -420,7 +465,7 @@ __global__ __launch_bounds__(Cfg::WG, Cfg::OCC) void stockham_wg_kernel(const cx
         constexpr int k = decltype(k_)::value;
         const unsigned e = threadIdx.x + k * Cfg::WG;
         if (CH % Cfg::WG == 0 || e < CH) {
-          cx<T> x = io.load(e * static_cast<unsigned>(sizeof(cx<T>)), 0);
+          cx<T> x = io.load(e * IO::ES, 0);
           if constexpr (BWD) x.im = -x.im;
           all[(e / Cfg::N) * Cfg::LDS_PER_FFT + lds_pad<Cfg>(e % Cfg::N)] = x;
         }
@@ -445,12 +490,38 @@ __global__ __launch_bounds__(Cfg::WG, Cfg::OCC) void stockham_wg_kernel(const cx
           if constexpr (BWD) y.im = -y.im;
           y.re *= scale;
           y.im *= scale;
-          io.store(y, e * static_cast<unsigned>(sizeof(cx<T>)), 0);
+          io.store(y, e * IO::ES, 0);
         }
       });
       __syncthreads();  // the next group's copy-in overwrites the images
     }
   }
+}
+
+/// Persistent work-group kernel, interleaved complex: work-group g handles FFT groups g, g+G, ...
+template <typename Cfg, bool BWD>
+__global__ __launch_bounds__(Cfg::WG, Cfg::OCC) void stockham_wg_kernel(const cx<typename Cfg::T>* __restrict__ in,
+                                                                        cx<typename Cfg::T>* __restrict__ out,
+                                                                        const cx<typename Cfg::T>* __restrict__ tw,
+                                                                        long long nfft, typename Cfg::T scale) {
+  using T = typename Cfg::T;
+  stockham_wg_body<Cfg, BWD>(
+      [&](long long g) PFA_LAMBDA { return packed_io<T, Cfg::N, Cfg::FPW, Cfg::AUX>(in, out, g, nfft); }, tw, nfft,
+      scale);
+}
+
+/// Same kernel for SPLIT_COMPLEX storage (separate real / imaginary planes).
+template <typename Cfg, bool BWD>
+__global__ __launch_bounds__(Cfg::WG, Cfg::OCC) void stockham_wg_split_kernel(
+    const typename Cfg::T* __restrict__ in_re, const typename Cfg::T* __restrict__ in_im,
+    typename Cfg::T* __restrict__ out_re, typename Cfg::T* __restrict__ out_im,
+    const cx<typename Cfg::T>* __restrict__ tw, long long nfft, typename Cfg::T scale) {
+  using T = typename Cfg::T;
+  stockham_wg_body<Cfg, BWD>(
+      [&](long long g) PFA_LAMBDA {
+        return packed_split_io<T, Cfg::N, Cfg::FPW, Cfg::AUX>(in_re, in_im, out_re, out_im, g, nfft);
+      },
+      tw, nfft, scale);
 }
 
 }  // namespace pfa

@@ -6,8 +6,10 @@ namespace pfa {
 /// Launch-time description of a strided stage (all counts in complex elements).
 /// FFT t: (o, c) = (t / inner, t % inner); its element i lives at  o * dist_outer + c * fdist + i * stride.
 struct strided_args {
-  const void* in;
+  const void* in;  // interleaved complex, or the real plane when the kernel is a split-storage variant
   void* out;
+  const void* in_im;  // imaginary planes (split-storage variants only)
+  void* out_im;
   const void* tw;
   long long total;  // number of FFTs
   long long inner;  // FFTs per outer index; must be a multiple of the kernel's FPW

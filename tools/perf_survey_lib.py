@@ -11,13 +11,18 @@ def run(name, lengths, batch, prec="f32", reps=8, **kw):
     for k, v in kw.items(): setattr(d, k, v)
     dt = torch.complex64 if prec == "f32" else torch.complex128
     cnt_in, cnt_out = d.get_input_count(pf.direction.FORWARD), d.get_output_count(pf.direction.FORWARD)
-    x = torch.empty(cnt_in, dtype=dt, device="cuda"); torch.view_as_real(x).uniform_(-1, 1)
-    y = torch.empty(cnt_out, dtype=dt, device="cuda")
+    split = int(d.complex_storage) == 1
+    if split:
+        rt = torch.float32 if prec == "f32" else torch.float64
+        args = [torch.empty(cnt_in, dtype=rt, device="cuda").uniform_(-1, 1) for _ in range(2)] + [torch.empty(cnt_out, dtype=rt, device="cuda") for _ in range(2)]
+    else:
+        x = torch.empty(cnt_in, dtype=dt, device="cuda"); torch.view_as_real(x).uniform_(-1, 1)
+        args = [x, torch.empty(cnt_out, dtype=dt, device="cuda")]
     plan = d.commit()
-    plan.compute_forward(x, y); torch.cuda.synchronize()
+    plan.compute_forward(*args); torch.cuda.synchronize()
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     s.record()
-    for _ in range(reps): plan.compute_forward(x, y)
+    for _ in range(reps): plan.compute_forward(*args)
     e.record(); torch.cuda.synchronize()
     ms = s.elapsed_time(e) / reps
     esz = 8 if prec == "f32" else 16

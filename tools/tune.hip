@@ -125,6 +125,14 @@ int main() {
   add<wg_cfg<f, S, 256, 1, 4, 1, TW_GLOBAL, 4, NT>, true>("twG o4 PF");
   add<wg_cfg<f, S, 256, 1, 4, 1, TW_GLOBAL, 4, NT>, false>("twG o4");
   add<wg_cfg<f, S, 256, 1, 4, 1, TW_GLOBAL, 5, NT>, false>("twG o5");
+#elif TUNE_CASE == 4097
+  using S = radix_list<16, 16, 16>; using T = f; const int N = 4096;
+  add<wg_cfg<f, S, 256, 1, 4, 1, TW_REGS, 3, NT>, true>("twR o3 PF (current)");
+  add<wg_cfg<f, S, 512, 2, 4, 1, TW_REGS, 3, NT>, true>("twR wg512 fpw2 o3 PF");
+  add<wg_cfg<f, S, 512, 2, 4, 1, TW_REGS, 4, NT>, false>("twR wg512 fpw2 o4");
+  add<wg_cfg<f, S, 1024, 4, 4, 1, TW_REGS, 4, NT>, false>("twR wg1024 fpw4 o4");
+  add<wg_cfg<f, S, 1024, 4, 4, 1, TW_REGS, 3, NT>, true>("twR wg1024 fpw4 o3 PF");
+  add<wg_cfg<f, S, 128, 1, 4, 1, TW_REGS, 2, NT>, false>("twR wg128 (32pt) o2");
 #elif TUNE_CASE == 512
   using S = radix_list<8, 8, 8>; using T = f; const int N = 512;
   add<wg_cfg<f, S, 256, 4, 4, 1, TW_GLOBAL, 4, NT>, false>("twG fpw4 o4");
