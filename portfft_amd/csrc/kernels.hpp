@@ -46,6 +46,10 @@ struct strided_kernel {
   int groups_per_wg;  // tuned grid rule (see spec_kernel)
   const void* fn[4];  // [backward * 2 + store_modifier]
   hipError_t (*launch)(hipStream_t stream, unsigned grid, const strided_args& args, int backward, int store_modifier);
+  /// row-staged forms (stockham_strided_row_kernel): fn_row[row_out * 2 + backward]; null when not instantiated
+  const void* fn_row[4];
+  size_t lds_bytes_row;
+  hipError_t (*launch_row)(hipStream_t stream, unsigned grid, const strided_args& args, int backward, int row_out);
   /// SPLIT_COMPLEX form on both sides (no store modifier); fn_split[backward]
   const void* fn_split[2];
   hipError_t (*launch_split)(hipStream_t stream, unsigned grid, const strided_args& args, int backward);

@@ -136,6 +136,38 @@ hipError_t launch_strided_prefetch(hipStream_t stream, unsigned grid, const stri
 }
 
 template <typename Cfg>
+hipError_t launch_strided_row(hipStream_t stream, unsigned grid, const strided_args& args, int backward, int row_out) {
+  constexpr size_t lds = strided_row_lds_bytes<Cfg>();
+  const dim3 g(grid), b(Cfg::WG);
+  if (row_out) {
+    if (backward) {
+      hipLaunchKernelGGL((stockham_strided_row_kernel<Cfg, true, false, true>), g, b, lds, stream, args);
+    } else {
+      hipLaunchKernelGGL((stockham_strided_row_kernel<Cfg, false, false, true>), g, b, lds, stream, args);
+    }
+  } else {
+    if (backward) {
+      hipLaunchKernelGGL((stockham_strided_row_kernel<Cfg, true, true, false>), g, b, lds, stream, args);
+    } else {
+      hipLaunchKernelGGL((stockham_strided_row_kernel<Cfg, false, true, false>), g, b, lds, stream, args);
+    }
+  }
+  return hipGetLastError();
+}
+
+/// add the row-staged forms to an entry (fp32: a wave covers only 64/FPW * 8 B of a row when addressed f-fastest)
+template <typename Cfg>
+strided_kernel with_rows(strided_kernel k) {
+  k.fn_row[0] = reinterpret_cast<const void*>(&stockham_strided_row_kernel<Cfg, false, true, false>);
+  k.fn_row[1] = reinterpret_cast<const void*>(&stockham_strided_row_kernel<Cfg, true, true, false>);
+  k.fn_row[2] = reinterpret_cast<const void*>(&stockham_strided_row_kernel<Cfg, false, false, true>);
+  k.fn_row[3] = reinterpret_cast<const void*>(&stockham_strided_row_kernel<Cfg, true, false, true>);
+  k.lds_bytes_row = strided_row_lds_bytes<Cfg>();
+  k.launch_row = &launch_strided_row<Cfg>;
+  return k;
+}
+
+template <typename Cfg>
 hipError_t launch_strided_split(hipStream_t stream, unsigned grid, const strided_args& args, int backward) {
   constexpr size_t lds = strided_lds_bytes<Cfg>();
   if (backward) {

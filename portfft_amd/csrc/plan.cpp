@@ -45,6 +45,7 @@ struct stage {
   const strided_kernel* strided = nullptr;
   strided_args sa{};
   int store_modifier = 0;
+  int row_mode = 0;  // 0: both sides addressed by the passes, 1: row-shaped input staged, 2: row-shaped output staged
   int in_buf = BUF_IN, out_buf = BUF_OUT;
   long long count = 0;  // number of FFTs
   unsigned grid = 1;
@@ -279,6 +280,20 @@ struct plan_t {
     a.stw_hi = nullptr;
     a.stw_shift = 0;
     s.lds_bytes = k->lds_bytes;
+    // row-shaped side of an interleaved fp32 stage: copy it through LDS with full-line accesses
+    const bool user_split = desc.complex_storage == PFFT_SPLIT_COMPLEX && in_buf != BUF_SCRATCH;
+    if (k->launch_row != nullptr && !user_split && k->lds_bytes_row <= max_lds) {
+      if (ia.stride == 1 && ia.dist_inner != 1 && oa.dist_inner == 1) s.row_mode = 1;
+      if (oa.stride == 1 && oa.dist_inner != 1 && ia.dist_inner == 1) s.row_mode = 2;
+      if (s.row_mode != 0) {
+        s.lds_bytes = k->lds_bytes_row;
+        for (int i = 0; i < 4; ++i) {
+          hip_check(hipFuncSetAttribute(k->fn_row[i], hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        static_cast<int>(k->lds_bytes_row)),
+                    "hipFuncSetAttribute");
+        }
+      }
+    }
     for (int i = 0; i < 4; ++i) {
       if (k->lds_bytes > 48 * 1024) {
         hip_check(hipFuncSetAttribute(k->fn[i], hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -289,8 +304,13 @@ struct plan_t {
                   "hipFuncSetAttribute");
       }
     }
-    s.grid = persistent_grid(k->fn[backward * 2], k->wg, k->lds_bytes, (count + k->fpw - 1) / k->fpw,
-                             k->groups_per_wg);
+    if (s.row_mode != 0) {
+      s.grid = persistent_grid(k->fn_row[(s.row_mode - 1) * 2 + backward], k->wg, k->lds_bytes_row,
+                               (count + k->fpw - 1) / k->fpw, 1);
+    } else {
+      s.grid = persistent_grid(k->fn[backward * 2], k->wg, k->lds_bytes, (count + k->fpw - 1) / k->fpw,
+                               k->groups_per_wg);
+    }
     return s;
   }
 
@@ -657,6 +677,10 @@ struct plan_t {
       a.in = base_re(s.in_buf, true) + static_cast<size_t>(s.in_addr.offset + in_shift) * elem_bytes();
       a.out = const_cast<char*>(base_re(s.out_buf, false)) +
               static_cast<size_t>(s.out_addr.offset + out_shift) * elem_bytes();
+      if (s.row_mode != 0 && s.store_modifier == 0) {
+        hip_check(s.strided->launch_row(stream, grid, a, s.backward, s.row_mode - 1), "kernel launch");
+        return;
+      }
       hip_check(s.strided->launch(stream, grid, a, s.backward, s.store_modifier), "kernel launch");
       return;
     }

@@ -40,7 +40,15 @@ struct strided_io {
   }
 };
 
-template <typename Cfg, bool BWD, bool STW, int P, typename IO>
+/// ROW_IN / ROW_OUT: that side of the group is row shaped (each FFT contiguous) and is copied HBM <-> LDS with
+/// element-fastest lanes (full lines) instead of being addressed f-fastest by the passes; the LDS image then uses an
+/// odd pitch (FPW + 1) so that both the element-fastest copy and the f-fastest passes are bank-conflict free.
+template <typename Cfg, bool ROW>
+constexpr int strided_pitch() {
+  return ROW ? Cfg::FPW + 1 : Cfg::FPW;
+}
+
+template <typename Cfg, bool BWD, bool STW, int P, typename IO, bool ROW_IN = false, bool ROW_OUT = false>
 PFA_DEV void strided_pass(const IO& io, const strided_args& a, unsigned f,
                           unsigned tid, bool live, long long c0, cx<typename Cfg::T>* lds,
                           const cx<typename Cfg::T>* __restrict__ tw) {
@@ -52,9 +60,9 @@ PFA_DEV void strided_pass(const IO& io, const strided_args& a, unsigned f,
   constexpr int Ns = Seq::ns(P);
   constexpr int BPT = Cfg::bpt(P);
   constexpr bool ragged = (NB % Cfg::TPF) != 0;
-  constexpr bool first = P == 0;
-  constexpr bool last = P == Cfg::NP - 1;
-  constexpr int FPW = Cfg::FPW;
+  constexpr bool first = P == 0 && !ROW_IN;   // reads HBM directly
+  constexpr bool last = P == Cfg::NP - 1 && !ROW_OUT;  // writes HBM directly
+  constexpr int FPW = strided_pitch<Cfg, ROW_IN || ROW_OUT>();
   constexpr unsigned ES = IO::ES;
 
   cx<T> v[BPT][R];
@@ -86,7 +94,7 @@ PFA_DEV void strided_pass(const IO& io, const strided_args& a, unsigned f,
     const unsigned j = tid + i * Cfg::TPF;
     if (!ragged || j < NB) {
       const unsigned q = j % Ns;
-      if constexpr (!first) {
+      if constexpr (P != 0) {
         sfor<1, R>([&](auto t_) PFA_LAMBDA {
           constexpr int t = decltype(t_)::value;
           const cx<T> w = (tw + Seq::tw_off(P) + (t - 1) * Ns)[q];
@@ -124,12 +132,12 @@ PFA_DEV void strided_pass(const IO& io, const strided_args& a, unsigned f,
   if constexpr (!last) __syncthreads();
 }
 
-template <typename Cfg, bool BWD, bool STW, int P, typename IO>
+template <typename Cfg, bool BWD, bool STW, int P, typename IO, bool ROW_IN = false, bool ROW_OUT = false>
 PFA_DEV void strided_passes(const IO& io, const strided_args& a, unsigned f, unsigned tid, bool live, long long c0,
                             cx<typename Cfg::T>* lds, const cx<typename Cfg::T>* __restrict__ tw) {
   if constexpr (P < Cfg::NP) {
-    strided_pass<Cfg, BWD, STW, P>(io, a, f, tid, live, c0, lds, tw);
-    strided_passes<Cfg, BWD, STW, P + 1>(io, a, f, tid, live, c0, lds, tw);
+    strided_pass<Cfg, BWD, STW, P, IO, ROW_IN, ROW_OUT>(io, a, f, tid, live, c0, lds, tw);
+    strided_passes<Cfg, BWD, STW, P + 1, IO, ROW_IN, ROW_OUT>(io, a, f, tid, live, c0, lds, tw);
   }
 }
 
@@ -249,6 +257,68 @@ __global__ __launch_bounds__(Cfg::WG, Cfg::OCC) void stockham_strided_prefetch_k
     live = live_n;
     c0 = c0_n;
   }
+}
+
+/// Strided kernel with a row-shaped side copied through LDS (see strided_pitch).  Interleaved storage, no store
+/// modifier.  ROW_IN: in_stride must be 1 (FFT f starts at f * in_fdist); ROW_OUT: out_stride must be 1.
+template <typename Cfg, bool BWD, bool ROW_IN, bool ROW_OUT>
+__global__ __launch_bounds__(Cfg::WG, Cfg::OCC) void stockham_strided_row_kernel(const strided_args a) {
+  using T = typename Cfg::T;
+  static_assert(Cfg::NP >= 2 && (ROW_IN || ROW_OUT));
+  extern __shared__ __attribute__((aligned(16))) char pfa_smem_strided[];
+  cx<T>* lds = reinterpret_cast<cx<T>*>(pfa_smem_strided);
+  constexpr int PITCH = strided_pitch<Cfg, true>();
+  constexpr int CH = Cfg::FPW * Cfg::N;
+  constexpr int EPT = (CH + Cfg::WG - 1) / Cfg::WG;
+  constexpr unsigned ES = sizeof(cx<T>);
+  const unsigned f = threadIdx.x % Cfg::FPW;
+  const unsigned tid = threadIdx.x / Cfg::FPW;
+  const cx<T>* __restrict__ tw = static_cast<const cx<T>*>(a.tw);
+  const long long ngroups = (a.total + Cfg::FPW - 1) / Cfg::FPW;
+  for (long long g = blockIdx.x; g < ngroups; g += gridDim.x) {
+    bool live;
+    long long c0;
+    const auto io = strided_group<Cfg, false>(a, g, f, &live, &c0);
+    const long long left = a.total - g * Cfg::FPW;
+    if constexpr (ROW_IN) {
+      sfor<0, EPT>([&](auto k_) PFA_LAMBDA {
+        constexpr int k = decltype(k_)::value;
+        const unsigned e = threadIdx.x + k * Cfg::WG;
+        if (CH % Cfg::WG == 0 || e < CH) {
+          const unsigned ef = e / Cfg::N, ei = e % Cfg::N;
+          const unsigned voff = static_cast<long long>(ef) < left ? (ef * a.in_fdist + ei) * ES : 0xFFFFFFF0u;
+          cx<T> x = io.load(voff, 0);
+          if constexpr (BWD) x.im = -x.im;
+          lds[ei * PITCH + ef] = x;
+        }
+      });
+      __syncthreads();
+    }
+    strided_passes<Cfg, BWD, false, 0, decltype(io), ROW_IN, ROW_OUT>(io, a, f, tid, live, c0, lds, tw);
+    if constexpr (ROW_OUT) {
+      const T scale = static_cast<T>(a.scale);
+      sfor<0, EPT>([&](auto k_) PFA_LAMBDA {
+        constexpr int k = decltype(k_)::value;
+        const unsigned e = threadIdx.x + k * Cfg::WG;
+        if (CH % Cfg::WG == 0 || e < CH) {
+          const unsigned ef = e / Cfg::N, ei = e % Cfg::N;
+          cx<T> y = lds[ei * PITCH + ef];
+          if constexpr (BWD) y.im = -y.im;
+          y.re *= scale;
+          y.im *= scale;
+          const unsigned voff = static_cast<long long>(ef) < left ? (ef * a.out_fdist + ei) * ES : 0xFFFFFFF0u;
+          io.store(y, voff, 0);
+        }
+      });
+      __syncthreads();
+    }
+  }
+}
+
+/// LDS bytes of the row variant (odd pitch)
+template <typename Cfg>
+constexpr size_t strided_row_lds_bytes() {
+  return size_t(Cfg::N) * (Cfg::FPW + 1) * sizeof(cx<typename Cfg::T>);
 }
 
 /// LDS bytes of the strided kernel for a wg_cfg (unpadded [element][f] image)
