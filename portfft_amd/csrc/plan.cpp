@@ -279,6 +279,7 @@ struct plan_t {
     a.stw_lo = nullptr;
     a.stw_hi = nullptr;
     a.stw_shift = 0;
+    a.stw_cdiv = 1;
     s.lds_bytes = k->lds_bytes;
     // row-shaped side of an interleaved fp32 stage: copy it through LDS with full-line accesses
     const bool user_split = desc.complex_storage == PFFT_SPLIT_COMPLEX && in_buf != BUF_SCRATCH;
@@ -444,6 +445,68 @@ struct plan_t {
     return s;
   }
 
+  /// BATCH_INTERLEAVED on both sides (element i of transform b at i * B + b), length n = n1 * n2, B transforms.
+  /// Stage A: for every (c, b): FFT over r of x[(r*n2 + c)*B + b], times W_n^{k1*c}, into scratch (same layout).
+  /// Stage B: for every (k1, b): FFT over c of scratch[(k1*n2 + c)*B + b] -> out[(k2*n1 + k1)*B + b].
+  /// Only taken when a single work-group would hold fewer than 16 (fp32) / 8 (fp64) columns of the whole length.
+  bool plan_batch_interleaved_two_stage(std::vector<stage>& out, long long n, long long B, const addressing& ia,
+                                        const addressing& oa, double scale, int backward, pfft_dim_info_t* info) {
+    const strided_kernel* whole = find_strided(n);
+    const int full_fpw = desc.precision == PFFT_PRECISION_F64 ? 8 : 16;
+    if (whole != nullptr && whole->fpw >= full_fpw) return false;
+    if (static_cast<unsigned long long>(n) * static_cast<unsigned long long>(B) * elem_bytes() >= 0xFFFFFFF0ull) {
+      return false;  // a stage's byte offsets must fit the 32-bit buffer addressing
+    }
+    long long n1 = 0;
+    for (long long c = static_cast<long long>(std::sqrt(static_cast<double>(n))); c >= 2; --c) {
+      const strided_kernel* k1 = find_strided(c);
+      const strided_kernel* k2 = (n % c == 0) ? find_strided(n / c) : nullptr;
+      if (k1 != nullptr && k2 != nullptr && k1->fpw >= full_fpw && k2->fpw >= full_fpw && B % k1->fpw == 0 &&
+          B % k2->fpw == 0) {
+        n1 = c;
+        break;
+      }
+    }
+    if (n1 == 0) return false;
+    const long long n2 = n / n1;
+    const strided_kernel* ka = find_strided(n1);
+    const strided_kernel* kb = find_strided(n2);
+    addressing a_in{ia.offset, n2 * B, 1, 0};
+    addressing a_out{0, n2 * B, 1, 0};
+    addressing b_in{0, B, 1, n2 * B};
+    addressing b_out{oa.offset, n1 * B, 1, B};
+    if (!strided_fits(ka, n2 * B, BUF_IN, a_in, BUF_SCRATCH, a_out) ||
+        !strided_fits(kb, B, BUF_SCRATCH, b_in, BUF_OUT, b_out)) {
+      return false;
+    }
+    scratch_bytes = std::max(scratch_bytes, static_cast<size_t>(n) * static_cast<size_t>(B) * elem_bytes());
+    int shift = 0;
+    while ((1ll << (2 * shift)) < n) ++shift;
+    const void* stw_lo = nullptr;
+    const void* stw_hi = nullptr;
+    upload_store_twiddles(n, shift, &stw_lo, &stw_hi);
+    stage sa = make_strided_stage(ka, n2 * B, n2 * B, BUF_IN, a_in, BUF_SCRATCH, a_out, 1.0, backward);
+    sa.sa.stw_lo = stw_lo;
+    sa.sa.stw_hi = stw_hi;
+    sa.sa.stw_shift = shift;
+    sa.sa.stw_cdiv = B;
+    sa.store_modifier = 1;
+    sa.row_mode = 0;
+    out.push_back(sa);
+    stage sb = make_strided_stage(kb, n1 * B, B, BUF_SCRATCH, b_in, BUF_OUT, b_out, scale, backward);
+    out.push_back(sb);
+    if (info != nullptr) {
+      info->tier = PFFT_TIER_GLOBAL;
+      info->n_factors = 2;
+      info->factors[0] = static_cast<int>(n1);
+      info->factors[1] = static_cast<int>(n2);
+      info->workgroup_size = kb->wg;
+      info->ffts_per_workgroup = kb->fpw;
+      info->lds_bytes = std::max(ka->lds_bytes, kb->lds_bytes);
+    }
+    return true;
+  }
+
   /// Plan `count` 1-D FFTs of length n.  Returns the tier used.
   int plan_1d(std::vector<stage>& out, long long n, long long count, long long inner_count, int in_buf,
               const addressing& ia, int out_buf, const addressing& oa, bool packed_io, double scale, int backward,
@@ -469,6 +532,12 @@ struct plan_t {
                std::vector<int>(k->radices, k->radices + k->n_radices), k->wg, k->fpw, k->lds_bytes);
         return PFFT_TIER_WORKGROUP;
       }
+    }
+    // Long batch-interleaved transforms: one work-group could hold only a few columns (narrow HBM segments), so
+    // split N = n1 * n2 and run both four-step stages column shaped with full-width groups, through scratch.
+    if (interleaved && desc.rank == 1 && in_buf == BUF_IN && out_buf == BUF_OUT && ia.dist_inner == 1 &&
+        oa.dist_inner == 1 && ia.stride == count && oa.stride == count && inner_count == count) {
+      if (plan_batch_interleaved_two_stage(out, n, count, ia, oa, scale, backward, info)) return PFFT_TIER_GLOBAL;
     }
     // the strided tier pays when at least one side is "column" shaped (consecutive FFTs adjacent in memory)
     const bool column_shaped = ia.dist_inner == 1 || oa.dist_inner == 1;

@@ -106,11 +106,16 @@ PFA_DEV void strided_pass(const IO& io, const strided_args& a, unsigned f,
       if constexpr (last) {
         const unsigned voff = live ? (f * a.out_fdist + base * a.out_stride) * ES : 0xFFFFFFF0u;
         const T scale = static_cast<T>(a.scale);
+        [[maybe_unused]] unsigned long long stw_c = 0;
+        if constexpr (STW) {
+          stw_c = static_cast<unsigned long long>(c0 + f);
+          if (a.stw_cdiv > 1) stw_c /= static_cast<unsigned long long>(a.stw_cdiv);
+        }
         sfor<0, R>([&](auto u_) PFA_LAMBDA {
           constexpr int u = decltype(u_)::value;
           cx<T> y = v[i][u];
           if constexpr (STW) {
-            const unsigned long long m = static_cast<unsigned long long>(base + u * Ns) * static_cast<unsigned long long>(c0 + f);
+            const unsigned long long m = static_cast<unsigned long long>(base + u * Ns) * stw_c;
             const cx<T> wl = static_cast<const cx<T>*>(a.stw_lo)[m & ((1ull << a.stw_shift) - 1)];
             const cx<T> wh = static_cast<const cx<T>*>(a.stw_hi)[m >> a.stw_shift];
             y = cmul(y, cmul(wl, wh));

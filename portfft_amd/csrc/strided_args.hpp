@@ -20,6 +20,7 @@ struct strided_args {
   const void* stw_lo;
   const void* stw_hi;
   int stw_shift;
+  long long stw_cdiv;  // store-modifier column index c = (inner index) / stw_cdiv  (1 for packed data)
 };
 
 }  // namespace pfa

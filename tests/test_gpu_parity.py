@@ -203,6 +203,18 @@ def test_strided_workgroup_tier(prec, oracle):
                     if "BI" in (lin, lout):
                         info = d.commit().info()
                         assert info.dims[0].tier == 1, (n, batch, lin, lout, info.dims[0].tier)
+    # long batch-interleaved transforms: two column-shaped four-step stages through scratch
+    for n in (4096, 8192, 16384) if prec == "f32" else (4096, 16384, 65536):
+        for batch in (32, 64):
+            x, y = H.gen_fourier_data(batch, [n], dtype, seed=n + batch)
+            for place in (0, 1):
+                d = _layout_desc(G, n, prec, batch, place, "BI", "BI", F, 0)
+                d.forward_scale = 0.5
+                got, _ = G.transform_packed(d, pf.direction.FORWARD, x)
+                _check(got, 0.5 * y, n, dtype, ("BI two-stage fwd", prec, n, batch, place))
+                assert d.commit().info().dims[0].tier == 3
+                back, _ = G.transform_packed(d, pf.direction.BACKWARD, y)
+                _check(back, x.astype(np.complex128) * n, n, dtype, ("BI two-stage bwd", prec, n, batch, place))
     for dims in ([256, 256], [64, 1024], [1024, 64], [32, 128, 64]):
         n = int(np.prod(dims))
         x, y = H.gen_fourier_data(2, dims, dtype)
