@@ -106,20 +106,36 @@ PFA_DEV void strided_pass(const IO& io, const strided_args& a, unsigned f,
       if constexpr (last) {
         const unsigned voff = live ? (f * a.out_fdist + base * a.out_stride) * ES : 0xFFFFFFF0u;
         const T scale = static_cast<T>(a.scale);
-        [[maybe_unused]] unsigned long long stw_c = 0;
+        // store modifier W_M^{k*c}, k = base + u*Ns: W^{base*c} and the step W^{Ns*c} come from the hi/lo tables
+        // (4 loads per butterfly instead of 2 per output), the powers of the step by squaring / one multiply
+        [[maybe_unused]] cx<T> stw[R];
         if constexpr (STW) {
-          stw_c = static_cast<unsigned long long>(c0 + f);
+          unsigned long long stw_c = static_cast<unsigned long long>(c0 + f);
           if (a.stw_cdiv > 1) stw_c /= static_cast<unsigned long long>(a.stw_cdiv);
+          const cx<T>* lo = static_cast<const cx<T>*>(a.stw_lo);
+          const cx<T>* hi = static_cast<const cx<T>*>(a.stw_hi);
+          const unsigned long long mask = (1ull << a.stw_shift) - 1;
+          const unsigned long long m0 = static_cast<unsigned long long>(base) * stw_c;
+          const unsigned long long ms = static_cast<unsigned long long>(Ns) * stw_c;
+          const cx<T> w0 = cmul(lo[m0 & mask], hi[m0 >> a.stw_shift]);
+          cx<T> pw[R];
+          pw[0] = {T(1), T(0)};
+          if constexpr (R > 1) pw[1] = cmul(lo[ms & mask], hi[ms >> a.stw_shift]);
+          sfor<2, R>([&](auto u_) PFA_LAMBDA {
+            constexpr int u = decltype(u_)::value;
+            if constexpr (u % 2 == 0) {
+              pw[u] = cmul(pw[u / 2], pw[u / 2]);
+            } else {
+              pw[u] = cmul(pw[u - 1], pw[1]);
+            }
+          });
+          stw[0] = w0;
+          sfor<1, R>([&](auto u_) PFA_LAMBDA { stw[decltype(u_)::value] = cmul(w0, pw[decltype(u_)::value]); });
         }
         sfor<0, R>([&](auto u_) PFA_LAMBDA {
           constexpr int u = decltype(u_)::value;
           cx<T> y = v[i][u];
-          if constexpr (STW) {
-            const unsigned long long m = static_cast<unsigned long long>(base + u * Ns) * stw_c;
-            const cx<T> wl = static_cast<const cx<T>*>(a.stw_lo)[m & ((1ull << a.stw_shift) - 1)];
-            const cx<T> wh = static_cast<const cx<T>*>(a.stw_hi)[m >> a.stw_shift];
-            y = cmul(y, cmul(wl, wh));
-          }
+          if constexpr (STW) y = cmul(y, stw[u]);
           if constexpr (BWD) y.im = -y.im;
           y.re *= scale;
           y.im *= scale;
