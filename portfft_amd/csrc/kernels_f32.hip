@@ -45,22 +45,7 @@ const spec_kernel g_spec_f32[] = {
     make_spec_entry<wg_cfg<f, radix_list<10, 10, 10>, 200, 2, 0, 0, TW_GLOBAL, 4, NT>>(),      // 1000
     make_spec_entry<wg_cfg<f, radix_list<10, 10, 10, 10>, 250, 1, 0, 0, TW_GLOBAL, 2, NT>>(),  // 10000
 };
-// strided tier: wg_cfg<T, radices, WG, FPW, 0, 0, TW_GLOBAL, OCC, AUX>; threads per FFT = WG / FPW
-const strided_kernel g_strided_f32[] = {
-    with_rows<wg_cfg<f, radix_list<8, 8>, 256, 32, 0, 0, TW_GLOBAL, 2, NT>>(make_strided_entry<wg_cfg<f, radix_list<8, 8>, 256, 32, 0, 0, TW_GLOBAL, 2, NT>>()),          // 64
-    with_rows<wg_cfg<f, radix_list<16, 8>, 256, 32, 0, 0, TW_GLOBAL, 2, NT>>(make_strided_entry<wg_cfg<f, radix_list<16, 8>, 256, 32, 0, 0, TW_GLOBAL, 2, NT>>()),         // 128
-    with_rows<wg_cfg<f, radix_list<16, 16>, 256, 16, 0, 0, TW_GLOBAL, 2, NT>>(make_strided_entry<wg_cfg<f, radix_list<16, 16>, 256, 16, 0, 0, TW_GLOBAL, 2, NT>>()),        // 256
-    with_rows<wg_cfg<f, radix_list<8, 8, 8>, 1024, 16, 0, 0, TW_GLOBAL, 4, NT>>(make_strided_entry<wg_cfg<f, radix_list<8, 8, 8>, 1024, 16, 0, 0, TW_GLOBAL, 4, NT>>()),      // 512
-    with_rows<wg_cfg<f, radix_list<32, 32>, 512, 16, 0, 0, TW_GLOBAL, 2, NT>>(make_strided_entry_prefetch<wg_cfg<f, radix_list<32, 32>, 512, 16, 0, 0, TW_GLOBAL, 2, NT>>(4)),  // 1024
-    with_rows<wg_cfg<f, radix_list<16, 16, 8>, 1024, 8, 0, 0, TW_GLOBAL, 4, NT>>(make_strided_entry<wg_cfg<f, radix_list<16, 16, 8>, 1024, 8, 0, 0, TW_GLOBAL, 4, NT>>()),     // 2048
-    with_rows<wg_cfg<f, radix_list<16, 16, 16>, 1024, 4, 0, 0, TW_GLOBAL, 4, NT>>(make_strided_entry<wg_cfg<f, radix_list<16, 16, 16>, 1024, 4, 0, 0, TW_GLOBAL, 4, NT>>()),    // 4096
-};
 }  // namespace
-
-const strided_kernel* strided_kernels_f32(int* count) {
-  *count = static_cast<int>(sizeof(g_strided_f32) / sizeof(g_strided_f32[0]));
-  return g_strided_f32;
-}
 
 const spec_kernel* spec_kernels_f32(int* count) {
   *count = static_cast<int>(sizeof(g_spec_f32) / sizeof(g_spec_f32[0]));

@@ -31,20 +31,7 @@ const spec_kernel g_spec_f64[] = {
     make_spec_entry<wg_cfg<d, radix_list<10, 10>, 250, 25, 0, 0, TW_GLOBAL, 2, NT, 1>>(),      // 100
     make_spec_entry<wg_cfg<d, radix_list<10, 10, 10>, 200, 2, 0, 0, TW_GLOBAL, 2, NT>>(),      // 1000
 };
-const strided_kernel g_strided_f64[] = {
-    make_strided_entry<wg_cfg<d, radix_list<8, 8>, 128, 16, 0, 0, TW_GLOBAL, 2, NT>>(),         // 64
-    make_strided_entry<wg_cfg<d, radix_list<16, 8>, 128, 16, 0, 0, TW_GLOBAL, 2, NT>>(),        // 128
-    make_strided_entry<wg_cfg<d, radix_list<16, 16>, 128, 8, 0, 0, TW_GLOBAL, 2, NT>>(),        // 256
-    make_strided_entry<wg_cfg<d, radix_list<8, 8, 8>, 512, 8, 0, 0, TW_GLOBAL, 2, NT>>(),       // 512
-    make_strided_entry<wg_cfg<d, radix_list<16, 8, 8>, 512, 8, 0, 0, TW_GLOBAL, 2, NT>>(),      // 1024
-    make_strided_entry<wg_cfg<d, radix_list<16, 16, 8>, 512, 4, 0, 0, TW_GLOBAL, 2, NT>>(),     // 2048
-};
 }  // namespace
-
-const strided_kernel* strided_kernels_f64(int* count) {
-  *count = static_cast<int>(sizeof(g_strided_f64) / sizeof(g_strided_f64[0]));
-  return g_strided_f64;
-}
 
 const spec_kernel* spec_kernels_f64(int* count) {
   *count = static_cast<int>(sizeof(g_spec_f64) / sizeof(g_spec_f64[0]));

@@ -1,0 +1,24 @@
+// f64 strided work-group kernel instantiations for gfx950 (see kernels_f64.hip for the parameter legend).
+#include "kernels_impl.hpp"
+
+namespace pfa {
+
+namespace {
+using d = double;
+constexpr int NT = 2;
+const strided_kernel g_strided_f64[] = {
+    make_strided_entry<wg_cfg<d, radix_list<8, 8>, 128, 16, 0, 0, TW_GLOBAL, 2, NT>>(),         // 64
+    make_strided_entry<wg_cfg<d, radix_list<16, 8>, 128, 16, 0, 0, TW_GLOBAL, 2, NT>>(),        // 128
+    make_strided_entry<wg_cfg<d, radix_list<16, 16>, 128, 8, 0, 0, TW_GLOBAL, 2, NT>>(),        // 256
+    make_strided_entry<wg_cfg<d, radix_list<8, 8, 8>, 512, 8, 0, 0, TW_GLOBAL, 2, NT>>(),       // 512
+    make_strided_entry<wg_cfg<d, radix_list<16, 8, 8>, 512, 8, 0, 0, TW_GLOBAL, 2, NT>>(),      // 1024
+    make_strided_entry<wg_cfg<d, radix_list<16, 16, 8>, 512, 4, 0, 0, TW_GLOBAL, 2, NT>>(),     // 2048
+};
+}  // namespace
+
+const strided_kernel* strided_kernels_f64(int* count) {
+  *count = static_cast<int>(sizeof(g_strided_f64) / sizeof(g_strided_f64[0]));
+  return g_strided_f64;
+}
+
+}  // namespace pfa
