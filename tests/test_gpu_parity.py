@@ -257,6 +257,24 @@ def test_every_registered_length(prec):
             _check(back, x.astype(np.complex128) * n, n, dtype, ("registered bwd", prec, n, batch))
 
 
+def test_maximum_sizes():
+    """the largest single transforms of each tier: 16384 (one work-group, fp32), 2^22 and 2^24 (four-step),
+    a 7-smooth length near the top of the generic tier, and a long prime-factor-31 length"""
+    import gpu_utils as G
+    pf = _pf()
+    for prec, dtype, sizes in (("f32", np.complex64, [1 << 22, 1 << 24, 10080, 31 * 31 * 31 * 8, 9 * 5 * 7 * 11 * 13 * 16]),
+                               ("f64", np.complex128, [1 << 22, 5040, 31 * 29 * 23 * 4])):
+        for n in sizes:
+            x, y = H.gen_fourier_data(1, [n], dtype, seed=5)
+            d = G.make_descriptor([n], prec)
+            got, _ = G.transform_packed(d, pf.direction.FORWARD, x)
+            _check(got, y, n, dtype, ("max sizes", prec, n))
+    with pytest.raises(pf.unsupported_configuration):
+        G.make_descriptor([37 * 64]).commit()  # prime factor beyond the supported radices
+    with pytest.raises(pf.unsupported_configuration):
+        G.make_descriptor([1 << 28]).commit()  # longer than (LDS/2 elements)^2
+
+
 def test_offsets():
     """Offsets* suites (instantiate_fft_tests.hpp:187-218): data starts at an offset; everything before the
     output offset must stay untouched"""
