@@ -382,6 +382,48 @@ def test_error_behaviour_and_plan_info():
     assert G.make_descriptor([1 << 20], "f64", batch=2).commit().info().dims[0].tier == 3
 
 
+def test_streams_and_graph_capture():
+    """execute only enqueues kernels on the plan's stream (no allocation, no synchronisation): two plans on two
+    streams run concurrently, and an execute can be captured into a HIP graph and replayed on new data"""
+    import gpu_utils as G
+    pf = _pf()
+    torch = G.torch_mod()
+    n, batch = 4096, 512
+    x, y = H.gen_fourier_data(batch, [n], np.complex64, seed=21)
+    x2, y2 = H.gen_fourier_data(batch, [1024, 4], np.complex64, seed=22)
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    d1 = G.make_descriptor([n], batch=batch)
+    d2 = G.make_descriptor([1024, 4], batch=batch)
+    p1, p2 = d1.commit(s1), d2.commit(s2)
+    a1 = torch.from_numpy(x.ravel()).cuda()
+    a2 = torch.from_numpy(x2.ravel()).cuda()
+    o1, o2 = torch.empty_like(a1), torch.empty_like(a2)
+    torch.cuda.synchronize()
+    for _ in range(20):
+        p1.compute_forward(a1, o1)
+        p2.compute_forward(a2, o2)
+    p1.wait()
+    p2.wait()
+    _check(o1.cpu().numpy().reshape(batch, n), y, n, np.complex64, "stream 1")
+    _check(o2.cpu().numpy().reshape(batch, -1), y2.reshape(batch, -1), 4096, np.complex64, "stream 2")
+    # graph capture on the plan's stream
+    g = torch.cuda.CUDAGraph()
+    o1.zero_()
+    torch.cuda.synchronize()
+    with torch.cuda.graph(g, stream=s1):
+        p1.compute_forward(a1, o1)
+        p1.compute_backward(o1, a1)   # a1 <- N * a1
+    torch.cuda.synchronize()
+    a1.copy_(torch.from_numpy(x.ravel()))
+    g.replay()
+    torch.cuda.synchronize()
+    _check(o1.cpu().numpy().reshape(batch, n), y, n, np.complex64, "graph replay 1")
+    assert H.rel_l2(a1.cpu().numpy(), x.ravel().astype(np.complex128) * n) < 2e-6
+    g.replay()  # second replay consumes the first one's output: forward of (N x)
+    torch.cuda.synchronize()
+    _check(o1.cpu().numpy().reshape(batch, n), y.astype(np.complex128) * n, n, np.complex64, "graph replay 2")
+
+
 def test_full_size_config2_properties():
     """BASELINE config 2 at full size (fp32 N=4096 batch=65536, 2 GiB in / 2 GiB out): sampled batches against
     NumPy, Parseval on every batch, forward->backward round trip, linearity."""
