@@ -10,11 +10,22 @@
 // Sign convention: forward transform, W_R = exp(-2*pi*i/R).  The backward transform is obtained by the callers
 // through conjugation on load and store (same identity the reference uses, committed_descriptor_impl.hpp:469-472).
 #pragma once
+// Under hiprtc (runtime specialisation, jit.cpp) the HIP runtime declarations are pre-included and no standard
+// library is available, so these headers use none.
+#ifndef __HIPCC_RTC__
 #include <hip/hip_runtime.h>
-
-#include <type_traits>
+#endif
 
 namespace pfa {
+
+/// compile-time integer tag (what sfor hands to its body)
+template <int V>
+struct int_tag {
+  static constexpr int value = V;
+};
+/// unevaluated-operand helper
+template <typename T>
+T&& declval_of() noexcept;
 
 #define PFA_DEV __host__ __device__ __forceinline__
 #define PFA_LAMBDA __attribute__((always_inline))
@@ -111,11 +122,11 @@ PFA_DEV cx<float> mul_cs<float>(cx<float> a, float c, float s) {
 
 #include "radix_constants.inc"
 
-/// compile-time loop: f(std::integral_constant<int, I>) for I in [B, E)
+/// compile-time loop: f(int_tag<I>) for I in [B, E)
 template <int B, int E, typename F>
 PFA_DEV void sfor(F&& f) {
   if constexpr (B < E) {
-    f(std::integral_constant<int, B>{});
+    f(int_tag<B>{});
     sfor<B + 1, E>(f);
   }
 }

@@ -1,0 +1,73 @@
+// Runtime specialisation of the work-group kernels (hiprtc).
+//
+// Role in the reference: portFFT specialises its kernels at commit time through SYCL specialization constants
+// (/root/reference/src/portfft/committed_descriptor_impl.hpp:448-573, set_spec_constants) so that one source serves
+// every length.  The MI355X analogue: lengths without a pre-compiled, hand-tuned instantiation (kernels_f32.hip, ...)
+// get the same templates (stockham_wg.hpp / stockham_strided.hpp) instantiated at commit time by hiprtc for the
+// radix sequence the planner below picks, so any length with prime factors <= 31 that fits LDS runs on a
+// compile-time-radix kernel instead of the runtime-radix generic kernel (3-5x slower, profiles/r1_notes.md).
+//
+// The compiled code objects are cached per process and device, and on disk when PFFT_JIT_CACHE_DIR is set.
+// PFFT_JIT=0 disables the facility (the planner then falls back to the generic tier); PFFT_JIT_VERBOSE=1 logs
+// every compilation to stderr.
+#pragma once
+#include <string>
+#include <vector>
+
+#include "kernels.hpp"
+
+namespace pfa {
+
+/// the template arguments of wg_cfg (stockham_wg.hpp) chosen at run time
+struct wg_params {
+  int precision = 0;
+  int n = 0;
+  std::vector<int> radices;
+  int wg = 0, fpw = 0, pads = 0, padw = 0, twm = 0, occ = 1, aux = 2, staged = 0;
+  /// complex elements a lane holds in its widest pass
+  int regs = 0;
+};
+
+/// Planner of the packed work-group tier for an arbitrary length: radix sequence (fewest LDS exchanges, balanced
+/// radices), lanes per FFT (least idle lanes in ragged passes), FFTs per work-group, padding, I/O staging.
+/// Returns false when `n` has a prime factor above 31 or does not fit `max_lds`.
+bool choose_spec_params(int precision, long long n, size_t max_lds, wg_params* out);
+
+/// Same for the strided tier (FPW adjacent FFTs side by side); `inner_count` is the number of adjacent FFTs the
+/// stage offers (narrow stages get narrower groups).
+bool choose_strided_params(int precision, long long n, long long inner_count, size_t max_lds, wg_params* out);
+
+/// LDS bytes of a packed work-group kernel with these parameters (wg_cfg::LDS_BYTES)
+size_t spec_lds_bytes(const wg_params& p);
+
+/// "pfa::wg_cfg<float, pfa::radix_list<..>, ...>"
+std::string wg_cfg_type_name(const wg_params& p);
+
+bool jit_enabled();
+
+/// Runtime-compiled packed kernel for length n on the current device (cached); the requested storage variant
+/// (interleaved or split) is compiled on demand.  nullptr + *why when the length cannot be planned or hiprtc fails.
+const spec_kernel* jit_spec_kernel(int precision, long long n, bool split, size_t max_lds, std::string* why);
+
+/// Runtime-compiled strided kernel; `store_modifier` / `split` select the variants to make available.
+const strided_kernel* jit_strided_kernel(int precision, long long n, long long inner_count, bool store_modifier,
+                                         bool split, size_t max_lds, std::string* why);
+
+hipError_t jit_launch_spec(const spec_kernel* k, hipStream_t stream, unsigned grid, const void* in, void* out,
+                           const void* tw, long long nfft, double scale, int backward);
+hipError_t jit_launch_spec_split(const spec_kernel* k, hipStream_t stream, unsigned grid, const void* in_re,
+                                 const void* in_im, void* out_re, void* out_im, const void* tw, long long nfft,
+                                 double scale, int backward);
+hipError_t jit_launch_strided(const strided_kernel* k, hipStream_t stream, unsigned grid, const strided_args& args,
+                              int backward, int store_modifier);
+hipError_t jit_launch_strided_split(const strided_kernel* k, hipStream_t stream, unsigned grid,
+                                    const strided_args& args, int backward);
+
+/// Compile (do not load) the forward + backward kernels of `p` for `arch`: needs no device, used by the build check
+/// and the CPU tests.  kind 0: packed interleaved, 1: packed split, 2: strided, 3: strided with store modifier.
+bool jit_compile_only(const wg_params& p, int kind, const char* arch, size_t* code_bytes, std::string* why);
+
+/// counters for tests / plan info: kernels compiled by hiprtc and loaded from the disk cache in this process
+void jit_stats(long long* compiled, long long* from_disk);
+
+}  // namespace pfa

@@ -1,8 +1,10 @@
 // Registry of the pre-compiled gfx950 kernels (host-visible interface of kernels_f32.hip / kernels_f64.hip).
 //
 // The reference JIT-specialises its kernels at commit time through SYCL specialization constants
-// (/root/reference/src/portfft/committed_descriptor_impl.hpp:448-573).  Here every variant is an offline-compiled
-// template instantiation; commit only looks the variant up.
+// (/root/reference/src/portfft/committed_descriptor_impl.hpp:448-573).  Here the hand-tuned variants are
+// offline-compiled template instantiations that commit only looks up; every other length gets the same templates
+// instantiated at commit time by hiprtc (jit.hpp) -- those entries carry module functions (mfn) instead of host
+// symbols and launch pointers.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -32,6 +34,9 @@ struct spec_kernel {
   const void* fn_split[2];
   hipError_t (*launch_split)(hipStream_t stream, unsigned grid, const void* in_re, const void* in_im, void* out_re,
                              void* out_im, const void* tw, long long nfft, double scale, int backward);
+  /// runtime-compiled entries (jit.cpp): module functions, launched with jit_launch_spec*; fn / launch are null
+  hipFunction_t mfn[2];
+  hipFunction_t mfn_split[2];
 };
 
 /// One strided work-group kernel (stockham_strided.hpp): FPW FFTs side by side, any element stride / FFT distance.
@@ -53,6 +58,9 @@ struct strided_kernel {
   /// SPLIT_COMPLEX form on both sides (no store modifier); fn_split[backward]
   const void* fn_split[2];
   hipError_t (*launch_split)(hipStream_t stream, unsigned grid, const strided_args& args, int backward);
+  /// runtime-compiled entries (jit.cpp): mfn[backward * 2 + store_modifier], mfn_split[backward]
+  hipFunction_t mfn[4];
+  hipFunction_t mfn_split[2];
 };
 
 const strided_kernel* strided_kernels_f32(int* count);

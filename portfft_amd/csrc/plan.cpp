@@ -18,6 +18,7 @@
 #include <vector>
 
 #include "descriptor.hpp"
+#include "jit.hpp"
 #include "kernels.hpp"
 
 namespace pfa {
@@ -238,6 +239,36 @@ struct plan_t {
     return nullptr;
   }
 
+  /// FFTs per work-group of the strided kernel get_strided(n, inner_count, ...) would deliver; 0 when there is none.
+  /// Cheap: consults the registry and the runtime planner, compiles nothing.
+  int strided_fpw(long long n, long long inner_count) const {
+    const strided_kernel* k = find_strided(n);
+    if (k != nullptr) return k->fpw;
+    wg_params p;
+    if (jit_enabled() && choose_strided_params(desc.precision, n, inner_count, max_lds, &p)) return p.fpw;
+    return 0;
+  }
+
+  /// the pre-compiled strided kernel when it suits the stage, otherwise a runtime-specialised one (jit.hpp)
+  const strided_kernel* get_strided(long long n, long long inner_count, bool store_modifier, bool user_split) {
+    const strided_kernel* k = find_strided(n);
+    if (k != nullptr) return k;
+    std::string why;
+    return jit_strided_kernel(desc.precision, n, inner_count, store_modifier, user_split, max_lds, &why);
+  }
+
+  /// the pre-compiled packed kernel, otherwise a runtime-specialised one
+  const spec_kernel* get_spec(long long n) {
+    if (const spec_kernel* k = find_spec(n)) return k;
+    std::string why;
+    return jit_spec_kernel(desc.precision, n, desc.complex_storage == PFFT_SPLIT_COMPLEX, max_lds, &why);
+  }
+
+  /// work-group loop trips of a strided stage (stockham_strided.hpp: strided_ngroups)
+  static long long strided_groups(long long count, long long inner, int fpw) {
+    return ((count + inner - 1) / inner) * ((inner + fpw - 1) / fpw);
+  }
+
   /// can the strided kernel `k` address this stage?  (interleaved data, whole groups, 32-bit byte ranges)
   bool strided_fits(const strided_kernel* k, long long inner_count, int in_buf, const addressing& ia, int out_buf,
                     const addressing& oa) const {
@@ -245,7 +276,7 @@ struct plan_t {
     // split storage: both sides must be user buffers (split variant) or both scratch (interleaved variant)
     const bool split = desc.complex_storage == PFFT_SPLIT_COMPLEX;
     if (split && ((in_buf == BUF_SCRATCH) != (out_buf == BUF_SCRATCH))) return false;
-    if (inner_count % k->fpw != 0) return false;
+    (void)inner_count;
     auto range_ok = [&](const addressing& a) {
       const unsigned long long elems = static_cast<unsigned long long>(k->fpw - 1) * a.dist_inner +
                                        static_cast<unsigned long long>(k->n - 1) * a.stride + 1;
@@ -283,7 +314,7 @@ struct plan_t {
     s.lds_bytes = k->lds_bytes;
     // row-shaped side of an interleaved fp32 stage: copy it through LDS with full-line accesses
     const bool user_split = desc.complex_storage == PFFT_SPLIT_COMPLEX && in_buf != BUF_SCRATCH;
-    if (k->launch_row != nullptr && !user_split && k->lds_bytes_row <= max_lds) {
+    if (k->launch_row != nullptr && !user_split && k->lds_bytes_row <= max_lds) {  // pre-compiled entries only
       if (ia.stride == 1 && ia.dist_inner != 1 && oa.dist_inner == 1) s.row_mode = 1;
       if (oa.stride == 1 && oa.dist_inner != 1 && ia.dist_inner == 1) s.row_mode = 2;
       if (s.row_mode != 0) {
@@ -295,7 +326,7 @@ struct plan_t {
         }
       }
     }
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < 4 && k->launch != nullptr; ++i) {
       if (k->lds_bytes > 48 * 1024) {
         hip_check(hipFuncSetAttribute(k->fn[i], hipFuncAttributeMaxDynamicSharedMemorySize,
                                       static_cast<int>(k->lds_bytes)),
@@ -305,12 +336,15 @@ struct plan_t {
                   "hipFuncSetAttribute");
       }
     }
-    if (s.row_mode != 0) {
-      s.grid = persistent_grid(k->fn_row[(s.row_mode - 1) * 2 + backward], k->wg, k->lds_bytes_row,
-                               (count + k->fpw - 1) / k->fpw, 1);
+    const long long groups = strided_groups(count, a.inner, k->fpw);
+    if (k->launch == nullptr) {  // runtime-compiled: whichever variant this stage will launch
+      hipFunction_t f = user_split ? k->mfn_split[backward] : k->mfn[backward * 2];
+      if (f == nullptr) f = k->mfn[backward * 2 + 1];
+      s.grid = persistent_grid(nullptr, f, k->wg, k->lds_bytes, groups, k->groups_per_wg);
+    } else if (s.row_mode != 0) {
+      s.grid = persistent_grid(k->fn_row[(s.row_mode - 1) * 2 + backward], nullptr, k->wg, k->lds_bytes_row, groups, 1);
     } else {
-      s.grid = persistent_grid(k->fn[backward * 2], k->wg, k->lds_bytes, (count + k->fpw - 1) / k->fpw,
-                               k->groups_per_wg);
+      s.grid = persistent_grid(k->fn[backward * 2], nullptr, k->wg, k->lds_bytes, groups, k->groups_per_wg);
     }
     return s;
   }
@@ -334,9 +368,14 @@ struct plan_t {
   /// against a grid where each work-group handles only `groups_per_wg` groups (4-5 is the optimum when the kernel
   /// pre-loads its twiddles into registers, 1 when it re-reads them per FFT): staggered work-group start times smooth
   /// the HBM demand.
-  unsigned persistent_grid(const void* fn, int wg, size_t lds, long long groups, int groups_per_wg) {
+  unsigned persistent_grid(const void* fn, hipFunction_t mfn, int wg, size_t lds, long long groups,
+                           int groups_per_wg) {
     int per_cu = 0;
-    hip_check(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, wg, lds), "occupancy query");
+    if (fn != nullptr) {
+      hip_check(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, wg, lds), "occupancy query");
+    } else {
+      hip_check(hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, mfn, wg, lds), "occupancy query");
+    }
     per_cu = std::max(per_cu, 1);
     const long long resident = static_cast<long long>(per_cu) * n_cus;
     // groups_per_wg comes from the per-kernel tuning (tools/tune.hip, profiles/r1_notes.md); 0 selects the long
@@ -361,7 +400,7 @@ struct plan_t {
     s.scale = scale;
     s.backward = backward;
     s.tw = upload_twiddles(std::vector<int>(k->radices, k->radices + k->n_radices));
-    for (int d = 0; d < 2; ++d) {
+    for (int d = 0; d < 2 && k->launch != nullptr; ++d) {
       if (k->lds_bytes > 48 * 1024) {
         hip_check(hipFuncSetAttribute(k->fn[d], hipFuncAttributeMaxDynamicSharedMemorySize,
                                       static_cast<int>(k->lds_bytes)),
@@ -371,8 +410,10 @@ struct plan_t {
                   "hipFuncSetAttribute");
       }
     }
-    s.grid = persistent_grid(k->fn[backward], k->wg, k->lds_bytes, (count + k->fpw - 1) / k->fpw,
-                             k->groups_per_wg);
+    const bool split = desc.complex_storage == PFFT_SPLIT_COMPLEX;
+    s.grid = persistent_grid(k->launch != nullptr ? k->fn[backward] : nullptr,
+                             split ? k->mfn_split[backward] : k->mfn[backward], k->wg, k->lds_bytes,
+                             (count + k->fpw - 1) / k->fpw, k->groups_per_wg);
     return s;
   }
 
@@ -441,7 +482,7 @@ struct plan_t {
       hip_check(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(max_lds)),
                 "hipFuncSetAttribute");
     }
-    s.grid = persistent_grid(fn, GENERIC_WG, s.lds_bytes, (count + fpw - 1) / fpw, 1);
+    s.grid = persistent_grid(fn, nullptr, GENERIC_WG, s.lds_bytes, (count + fpw - 1) / fpw, 1);
     return s;
   }
 
@@ -451,26 +492,23 @@ struct plan_t {
   /// Only taken when a single work-group would hold fewer than 16 (fp32) / 8 (fp64) columns of the whole length.
   bool plan_batch_interleaved_two_stage(std::vector<stage>& out, long long n, long long B, const addressing& ia,
                                         const addressing& oa, double scale, int backward, pfft_dim_info_t* info) {
-    const strided_kernel* whole = find_strided(n);
     const int full_fpw = desc.precision == PFFT_PRECISION_F64 ? 8 : 16;
-    if (whole != nullptr && whole->fpw >= full_fpw) return false;
+    if (strided_fpw(n, B) >= full_fpw) return false;
     if (static_cast<unsigned long long>(n) * static_cast<unsigned long long>(B) * elem_bytes() >= 0xFFFFFFF0ull) {
       return false;  // a stage's byte offsets must fit the 32-bit buffer addressing
     }
     long long n1 = 0;
     for (long long c = static_cast<long long>(std::sqrt(static_cast<double>(n))); c >= 2; --c) {
-      const strided_kernel* k1 = find_strided(c);
-      const strided_kernel* k2 = (n % c == 0) ? find_strided(n / c) : nullptr;
-      if (k1 != nullptr && k2 != nullptr && k1->fpw >= full_fpw && k2->fpw >= full_fpw && B % k1->fpw == 0 &&
-          B % k2->fpw == 0) {
+      if (n % c != 0) continue;
+      if (strided_fpw(c, (n / c) * B) >= full_fpw && strided_fpw(n / c, B) >= full_fpw) {
         n1 = c;
         break;
       }
     }
     if (n1 == 0) return false;
     const long long n2 = n / n1;
-    const strided_kernel* ka = find_strided(n1);
-    const strided_kernel* kb = find_strided(n2);
+    const strided_kernel* ka = get_strided(n1, n2 * B, true, false);
+    const strided_kernel* kb = get_strided(n2, B, false, false);
     addressing a_in{ia.offset, n2 * B, 1, 0};
     addressing a_out{0, n2 * B, 1, 0};
     addressing b_in{0, B, 1, n2 * B};
@@ -526,7 +564,7 @@ struct plan_t {
       info->lds_bytes = lds;
     };
     if (packed_io && (interleaved || (in_buf != BUF_SCRATCH && out_buf != BUF_SCRATCH))) {
-      if (const spec_kernel* k = find_spec(n)) {
+      if (const spec_kernel* k = get_spec(n)) {
         out.push_back(make_spec_stage(k, count, in_buf, ia.offset, out_buf, oa.offset, scale, backward));
         record(k->n_radices == 1 ? PFFT_TIER_REGISTER : PFFT_TIER_WORKGROUP,
                std::vector<int>(k->radices, k->radices + k->n_radices), k->wg, k->fpw, k->lds_bytes);
@@ -541,8 +579,9 @@ struct plan_t {
     }
     // the strided tier pays when at least one side is "column" shaped (consecutive FFTs adjacent in memory)
     const bool column_shaped = ia.dist_inner == 1 || oa.dist_inner == 1;
-    if (const strided_kernel* k = find_strided(n);
-        column_shaped && strided_fits(k, inner_count, in_buf, ia, out_buf, oa)) {
+    const bool user_split = !interleaved && in_buf != BUF_SCRATCH;
+    if (const strided_kernel* k = column_shaped ? get_strided(n, inner_count, false, user_split) : nullptr;
+        strided_fits(k, inner_count, in_buf, ia, out_buf, oa)) {
       out.push_back(make_strided_stage(k, count, inner_count, in_buf, ia, out_buf, oa, scale, backward));
       record(PFFT_TIER_WORKGROUP, std::vector<int>(k->radices, k->radices + k->n_radices), k->wg, k->fpw,
              k->lds_bytes);
@@ -566,7 +605,7 @@ struct plan_t {
     long long n1 = 0;
     // most balanced split whose two lengths both have a strided work-group kernel ...
     for (long long c = static_cast<long long>(std::sqrt(static_cast<double>(n))); c >= 2; --c) {
-      if (n % c == 0 && find_strided(c) != nullptr && find_strided(n / c) != nullptr) {
+      if (n % c == 0 && strided_fpw(c, n / c) > 0 && strided_fpw(n / c, c) > 0) {
         n1 = c;
         break;
       }
@@ -601,9 +640,9 @@ struct plan_t {
     const void* stw_lo = nullptr;
     const void* stw_hi = nullptr;
     upload_store_twiddles(n, shift, &stw_lo, &stw_hi);
-    const strided_kernel* ka = find_strided(n1);
-    const strided_kernel* kb = find_strided(n2);
     const bool interleaved_user = desc.complex_storage == PFFT_INTERLEAVED_COMPLEX;
+    const strided_kernel* ka = interleaved_user ? get_strided(n1, n2, true, false) : nullptr;
+    const strided_kernel* kb = interleaved_user ? get_strided(n2, n1, false, false) : nullptr;
     const char* dbg = getenv("PFFT_DEBUG_GLOBAL");  // debugging aid: "ga" / "gb" force the generic kernel for a stage
     const bool force_generic_a = dbg != nullptr && std::strstr(dbg, "ga") != nullptr;
     const bool force_generic_b = dbg != nullptr && std::strstr(dbg, "gb") != nullptr;
@@ -731,7 +770,7 @@ struct plan_t {
     if (s.strided != nullptr) {
       strided_args a = s.sa;
       a.total = count;
-      const long long groups = (count + s.strided->fpw - 1) / s.strided->fpw;
+      const long long groups = strided_groups(count, a.inner, s.strided->fpw);
       const unsigned grid = static_cast<unsigned>(std::min<long long>(s.grid, std::max<long long>(groups, 1)));
       if (split && s.in_buf != BUF_SCRATCH) {  // strided_fits: then the output is a user buffer too
         const size_t io = static_cast<size_t>(s.in_addr.offset + in_shift) * sb;
@@ -740,7 +779,9 @@ struct plan_t {
         a.in_im = base_im(s.in_buf) + io;
         a.out = const_cast<char*>(base_re(s.out_buf, false)) + oo;
         a.out_im = const_cast<char*>(base_im(s.out_buf)) + oo;
-        hip_check(s.strided->launch_split(stream, grid, a, s.backward), "kernel launch");
+        hip_check(s.strided->launch != nullptr ? s.strided->launch_split(stream, grid, a, s.backward)
+                                               : jit_launch_strided_split(s.strided, stream, grid, a, s.backward),
+                  "kernel launch");
         return;
       }
       a.in = base_re(s.in_buf, true) + static_cast<size_t>(s.in_addr.offset + in_shift) * elem_bytes();
@@ -750,7 +791,10 @@ struct plan_t {
         hip_check(s.strided->launch_row(stream, grid, a, s.backward, s.row_mode - 1), "kernel launch");
         return;
       }
-      hip_check(s.strided->launch(stream, grid, a, s.backward, s.store_modifier), "kernel launch");
+      hip_check(s.strided->launch != nullptr
+                    ? s.strided->launch(stream, grid, a, s.backward, s.store_modifier)
+                    : jit_launch_strided(s.strided, stream, grid, a, s.backward, s.store_modifier),
+                "kernel launch");
       return;
     }
     if (!s.generic) {
@@ -758,14 +802,21 @@ struct plan_t {
         const size_t io = static_cast<size_t>(s.in_offset) * sb, oo = static_cast<size_t>(s.out_offset) * sb;
         const char* sr = static_cast<const char*>(s.in_buf == BUF_IN ? in_re : out_re);
         const char* si = static_cast<const char*>(s.in_buf == BUF_IN ? in_im : out_im);
-        hip_check(s.spec->launch_split(stream, s.grid, sr + io, si + io, static_cast<char*>(out_re) + oo,
-                                       static_cast<char*>(out_im) + oo, s.tw, s.count, s.scale, s.backward),
+        auto launch_split = s.spec->launch != nullptr ? s.spec->launch_split : nullptr;
+        hip_check(launch_split != nullptr
+                      ? launch_split(stream, s.grid, sr + io, si + io, static_cast<char*>(out_re) + oo,
+                                     static_cast<char*>(out_im) + oo, s.tw, s.count, s.scale, s.backward)
+                      : jit_launch_spec_split(s.spec, stream, s.grid, sr + io, si + io, static_cast<char*>(out_re) + oo,
+                                              static_cast<char*>(out_im) + oo, s.tw, s.count, s.scale, s.backward),
                   "kernel launch");
         return;
       }
       const char* i = base_re(s.in_buf, true) + static_cast<size_t>(s.in_offset) * elem_bytes();
       char* o = const_cast<char*>(base_re(s.out_buf, false)) + static_cast<size_t>(s.out_offset) * elem_bytes();
-      hip_check(s.spec->launch(stream, s.grid, i, o, s.tw, s.count, s.scale, s.backward), "kernel launch");
+      hip_check(s.spec->launch != nullptr
+                    ? s.spec->launch(stream, s.grid, i, o, s.tw, s.count, s.scale, s.backward)
+                    : jit_launch_spec(s.spec, stream, s.grid, i, o, s.tw, s.count, s.scale, s.backward),
+                "kernel launch");
       return;
     }
     generic_args g = s.ga;

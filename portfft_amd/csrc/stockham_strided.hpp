@@ -207,17 +207,29 @@ PFA_DEV void strided_pass0_compute(cx<typename Cfg::T> (&v)[Cfg::bpt(0)][Cfg::Se
   __syncthreads();
 }
 
+/// Groups never straddle an outer index: every outer index owns ceil(inner / FPW) groups, the last one possibly
+/// partial (its surplus lanes are masked through `live`), so `inner` need not be a multiple of FPW.
+template <typename Cfg>
+PFA_DEV long long strided_ngroups(const strided_args& a) {
+  const long long per_outer = (a.inner + Cfg::FPW - 1) / Cfg::FPW;
+  return ((a.total + a.inner - 1) / a.inner) * per_outer;
+}
+
 template <typename Cfg, bool SPLIT>
 PFA_DEV strided_io<typename Cfg::T, Cfg::AUX, SPLIT> strided_group(const strided_args& a, long long g, unsigned f,
-                                                                   bool* live, long long* c0_out) {
+                                                                   bool* live, long long* c0_out,
+                                                                   long long* nlive_out = nullptr) {
   using T = typename Cfg::T;
   using IO = strided_io<T, Cfg::AUX, SPLIT>;
   constexpr unsigned ES = IO::ES;
-  const long long t0 = g * Cfg::FPW;
-  const long long o = t0 / a.inner;
-  const long long c0 = t0 - o * a.inner;
-  *live = static_cast<long long>(f) < a.total - t0;
+  const long long per_outer = (a.inner + Cfg::FPW - 1) / Cfg::FPW;
+  const long long o = g / per_outer;
+  const long long c0 = (g - o * per_outer) * Cfg::FPW;
+  const long long t0 = o * a.inner + c0;
+  const long long nlive = (a.inner - c0 < a.total - t0) ? a.inner - c0 : a.total - t0;
+  *live = static_cast<long long>(f) < nlive;
   *c0_out = c0;
+  if (nlive_out != nullptr) *nlive_out = nlive;
   const long long ioff = o * a.in_dist_outer + c0 * a.in_fdist;
   const long long ooff = o * a.out_dist_outer + c0 * a.out_fdist;
   // ranges: last element of the last FFT of the group (the planner guarantees < 4 GiB)
@@ -253,7 +265,7 @@ __global__ __launch_bounds__(Cfg::WG, Cfg::OCC) void stockham_strided_prefetch_k
   const unsigned f = threadIdx.x % Cfg::FPW;
   const unsigned tid = threadIdx.x / Cfg::FPW;
   const cx<T>* __restrict__ tw = static_cast<const cx<T>*>(a.tw);
-  const long long ngroups = (a.total + Cfg::FPW - 1) / Cfg::FPW;
+  const long long ngroups = strided_ngroups<Cfg>(a);
   long long g = blockIdx.x;
   if (g >= ngroups) return;
   cx<T> cur[Cfg::bpt(0)][Cfg::Seq::r[0]];
@@ -295,12 +307,12 @@ __global__ __launch_bounds__(Cfg::WG, Cfg::OCC) void stockham_strided_row_kernel
   const unsigned f = threadIdx.x % Cfg::FPW;
   const unsigned tid = threadIdx.x / Cfg::FPW;
   const cx<T>* __restrict__ tw = static_cast<const cx<T>*>(a.tw);
-  const long long ngroups = (a.total + Cfg::FPW - 1) / Cfg::FPW;
+  const long long ngroups = strided_ngroups<Cfg>(a);
   for (long long g = blockIdx.x; g < ngroups; g += gridDim.x) {
     bool live;
     long long c0;
-    const auto io = strided_group<Cfg, false>(a, g, f, &live, &c0);
-    const long long left = a.total - g * Cfg::FPW;
+    long long left;
+    const auto io = strided_group<Cfg, false>(a, g, f, &live, &c0, &left);
     if constexpr (ROW_IN) {
       sfor<0, EPT>([&](auto k_) PFA_LAMBDA {
         constexpr int k = decltype(k_)::value;
@@ -357,7 +369,7 @@ __global__ __launch_bounds__(Cfg::WG, Cfg::OCC) void stockham_strided_kernel(con
   const unsigned f = threadIdx.x % Cfg::FPW;
   const unsigned tid = threadIdx.x / Cfg::FPW;
   const cx<T>* __restrict__ tw = static_cast<const cx<T>*>(a.tw);
-  const long long ngroups = (a.total + Cfg::FPW - 1) / Cfg::FPW;
+  const long long ngroups = strided_ngroups<Cfg>(a);
   for (long long g = blockIdx.x; g < ngroups; g += gridDim.x) {
     bool live;
     long long c0;

@@ -13,8 +13,6 @@
 //     loads them once from the HBM table into VGPRs and reuses them for every FFT it processes.
 //   * 256-thread work-groups (4 wave64), 16 points per lane at N=4096; LDS = N complex (+pad) per FFT in flight.
 #pragma once
-#include <utility>
-
 #include "butterflies.hpp"
 
 namespace pfa {
@@ -112,8 +110,8 @@ constexpr int pad_step(int unit) {
 
 /// Raw 16- or 8-byte buffer access: one 32-bit lane offset VGPR (voff) serves every access of a butterfly, the
 /// butterfly's stride goes into the scalar offset (soff), and the hardware range check drops out-of-range lanes.
-using buf_b64_t = decltype(__builtin_amdgcn_raw_buffer_load_b64(std::declval<__amdgpu_buffer_rsrc_t>(), 0u, 0u, 0));
-using buf_b128_t = decltype(__builtin_amdgcn_raw_buffer_load_b128(std::declval<__amdgpu_buffer_rsrc_t>(), 0u, 0u, 0));
+using buf_b64_t = decltype(__builtin_amdgcn_raw_buffer_load_b64(declval_of<__amdgpu_buffer_rsrc_t>(), 0u, 0u, 0));
+using buf_b128_t = decltype(__builtin_amdgcn_raw_buffer_load_b128(declval_of<__amdgpu_buffer_rsrc_t>(), 0u, 0u, 0));
 static_assert(sizeof(buf_b64_t) == 8 && sizeof(buf_b128_t) == 16, "unexpected raw buffer builtin types");
 
 template <typename T, int AUX>
@@ -161,7 +159,7 @@ struct packed_io {
   PFA_DEV void store(cx<T> v, unsigned voff, unsigned soff) const { buf_store<T, AUX>(v, rout, voff, soff); }
 };
 
-using buf_b32_t = decltype(__builtin_amdgcn_raw_buffer_load_b32(std::declval<__amdgpu_buffer_rsrc_t>(), 0u, 0u, 0));
+using buf_b32_t = decltype(__builtin_amdgcn_raw_buffer_load_b32(declval_of<__amdgpu_buffer_rsrc_t>(), 0u, 0u, 0));
 
 template <typename T, int AUX>
 PFA_DEV T buf_load_scalar(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff) {

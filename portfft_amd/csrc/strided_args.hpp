@@ -12,7 +12,7 @@ struct strided_args {
   void* out_im;
   const void* tw;
   long long total;  // number of FFTs
-  long long inner;  // FFTs per outer index; must be a multiple of the kernel's FPW
+  long long inner;  // FFTs per outer index (a group of FPW adjacent FFTs never straddles an outer index)
   long long in_dist_outer, out_dist_outer;
   unsigned in_stride, out_stride;  // element stride inside one FFT
   unsigned in_fdist, out_fdist;    // distance between consecutive FFTs of a group

@@ -1,0 +1,90 @@
+// Runtime-specialisation planner (portfft_amd/csrc/jit.cpp) on the host: invariants of the chosen kernel
+// parameters for every length, and hiprtc compilation of a few of them for gfx950 (no device needed).
+#include <cstdio>
+#include <cstdlib>
+#include <string>
+
+#include "../../portfft_amd/csrc/jit.hpp"
+
+static int fails = 0;
+#define EXPECT(c, ...)                 \
+  do {                                 \
+    if (!(c)) {                        \
+      ++fails;                         \
+      std::printf("FAIL %s: ", #c);    \
+      std::printf(__VA_ARGS__);        \
+      std::printf("\n");               \
+    }                                  \
+  } while (0)
+
+static bool smooth31(long long n) {
+  for (int p = 2; p <= 31; ++p) {
+    while (n % p == 0) n /= p;
+  }
+  return n == 1;
+}
+
+int main(int argc, char** argv) {
+  const size_t max_lds = 160 * 1024;
+  long long planned[2] = {0, 0};
+  for (int prec = 0; prec < 2; ++prec) {
+    const int es = prec ? 16 : 8;
+    for (long long n = 2; n <= 20000; ++n) {
+      pfa::wg_params p;
+      const bool ok = pfa::choose_spec_params(prec, n, max_lds, &p);
+      if (!smooth31(n) || static_cast<size_t>(n) * es > 128 * 1024) {
+        EXPECT(!ok, "n=%lld prec=%d should not be planned", n, prec);
+        continue;
+      }
+      EXPECT(ok, "n=%lld prec=%d not planned", n, prec);
+      if (!ok) continue;
+      ++planned[prec];
+      long long prod = 1;
+      for (int r : p.radices) {
+        prod *= r;
+        EXPECT(r >= 2 && r <= 32, "n=%lld radix %d", n, r);
+      }
+      EXPECT(prod == n, "n=%lld product %lld", n, prod);
+      EXPECT(p.radices.size() <= 6, "n=%lld passes", n);
+      EXPECT(p.wg >= 1 && p.wg <= 1024 && p.fpw >= 1 && p.wg % p.fpw == 0, "n=%lld wg=%d fpw=%d", n, p.wg, p.fpw);
+      EXPECT(pfa::spec_lds_bytes(p) <= max_lds, "n=%lld lds=%zu", n, pfa::spec_lds_bytes(p));
+      EXPECT(p.regs <= 64, "n=%lld regs=%d", n, p.regs);
+      const int tpf = p.wg / p.fpw;
+      for (int r : p.radices) {
+        const long long bpt = (n / r + tpf - 1) / tpf;
+        EXPECT(bpt * r <= p.regs, "n=%lld radix %d bpt %lld regs %d", n, r, bpt, p.regs);
+      }
+      pfa::wg_params q;
+      if (pfa::choose_strided_params(prec, n, 1000, max_lds, &q)) {
+        long long pq = 1;
+        for (int r : q.radices) pq *= r;
+        EXPECT(pq == n && q.radices.size() >= 2, "strided n=%lld", n);
+        EXPECT(q.wg >= 64 && q.wg <= 512 && q.wg % q.fpw == 0, "strided n=%lld wg=%d fpw=%d", n, q.wg, q.fpw);
+        EXPECT(static_cast<size_t>(n) * q.fpw * es <= 128 * 1024, "strided n=%lld lds", n);
+      }
+    }
+  }
+  std::printf("planned %lld fp32 and %lld fp64 lengths\n", planned[0], planned[1]);
+  // choices the measurements in profiles/r1_notes.md rest on
+  pfa::wg_params p;
+  pfa::choose_spec_params(0, 243, max_lds, &p);
+  EXPECT(p.radices.size() == 3 && p.radices[0] == 9, "243 -> 9,9,3");
+  pfa::choose_spec_params(0, 4096, max_lds, &p);
+  EXPECT(p.radices.size() == 3 && p.radices[0] == 16 && p.wg == 256 && p.fpw == 1, "4096 -> 16,16,16 / 256 lanes");
+  if (argc > 1 && std::string(argv[1]) == "compile") {
+    struct { int prec; long long n; int kind; } cases[] = {{0, 1200, 0}, {1, 625, 1}, {0, 30, 0}, {0, 120, 2}, {1, 250, 3}};
+    for (auto& c : cases) {
+      pfa::wg_params q;
+      const bool ok = c.kind < 2 ? pfa::choose_spec_params(c.prec, c.n, max_lds, &q)
+                                 : pfa::choose_strided_params(c.prec, c.n, 1024, max_lds, &q);
+      EXPECT(ok, "plan %lld", c.n);
+      size_t bytes = 0;
+      std::string why;
+      const bool built = pfa::jit_compile_only(q, c.kind, "gfx950", &bytes, &why);
+      EXPECT(built && bytes > 1000, "hiprtc n=%lld kind=%d: %s", c.n, c.kind, why.c_str());
+      std::printf("hiprtc n=%lld kind=%d %s: %zu bytes\n", c.n, c.kind, pfa::wg_cfg_type_name(q).c_str(), bytes);
+    }
+  }
+  if (fails == 0) std::printf("jit planner OK\n");
+  return fails == 0 ? 0 : 1;
+}

@@ -1,0 +1,79 @@
+// Yardstick for the column passes: copy a [images][1024 rows][row_bytes] array where every work-group moves a
+// "column group" = 1024 segments of SEG bytes at a stride of row_bytes (the access shape of the strided FFT kernels).
+// Variants: strided -> strided (stage A/B without row staging), strided -> contiguous, contiguous -> strided.
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s line %d\n", hipGetErrorString(e_), __LINE__); exit(1);} } while (0)
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+// MODE 0: strided in, strided out; 1: strided in, contiguous out; 2: contiguous in, strided out
+template <int SEG, int WG, int MODE, int ROWS>
+__global__ __launch_bounds__(WG) void copy_cols(const char* __restrict__ in, char* __restrict__ out, long long groups,
+                                                long long row_bytes) {
+  constexpr int LPS = SEG / 16;            // lanes per segment
+  constexpr int RPI = WG / LPS;            // rows per iteration
+  constexpr int IT = ROWS / RPI;
+  const int tid = threadIdx.x;
+  const long long gpi = row_bytes / SEG;   // groups per image
+  for (long long g = blockIdx.x; g < groups; g += gridDim.x) {
+    const long long img = g / gpi, cg = g % gpi;
+    const char* src = in + img * ROWS * row_bytes;
+    char* dst = out + img * ROWS * row_bytes;
+    v4f v[IT];
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+      const long long r = tid / LPS + (long long)i * RPI;
+      const long long so = (MODE == 2) ? (cg * ROWS * SEG + r * SEG + (tid % LPS) * 16) : (r * row_bytes + cg * SEG + (tid % LPS) * 16);
+      v[i] = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(src + so));
+    }
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+      const long long r = tid / LPS + (long long)i * RPI;
+      const long long d_ = (MODE == 1) ? (cg * ROWS * SEG + r * SEG + (tid % LPS) * 16) : (r * row_bytes + cg * SEG + (tid % LPS) * 16);
+      __builtin_nontemporal_store(v[i], reinterpret_cast<v4f*>(dst + d_));
+    }
+  }
+}
+
+template <int SEG, int WG, int MODE, int ROWS>
+void run(const char* name, char* in, char* out, size_t bytes, long long row_bytes, int cus) {
+  const long long groups = (long long)(bytes / ((size_t)ROWS * SEG));
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  printf("%-34s seg=%4d wg=%4d rowB=%6lld", name, SEG, WG, row_bytes);
+  for (int mult : {1, 2, 4, 8, 16, 0}) {
+    long long grid = mult ? (long long)mult * cus : groups;
+    grid = std::min(grid, groups);
+    std::vector<float> t;
+    for (int r = 0; r < 6; ++r) {
+      CK(hipEventRecord(e0));
+      hipLaunchKernelGGL((copy_cols<SEG, WG, MODE, ROWS>), dim3((unsigned)grid), dim3(WG), 0, 0, in, out, groups, row_bytes);
+      CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+      float ms; CK(hipEventElapsedTime(&ms, e0, e1)); if (r) t.push_back(ms);
+    }
+    std::sort(t.begin(), t.end());
+    printf("  x%-2d %.2f", mult, 2.0 * bytes / t[t.size() / 2] * 1e-9);
+  }
+  printf("  TB/s\n");
+  CK(hipGetLastError());
+}
+
+int main() {
+  const size_t bytes = (size_t)2 << 30;
+  char *in, *out; CK(hipMalloc(&in, bytes)); CK(hipMalloc(&out, bytes)); CK(hipMemset(in, 1, bytes));
+  hipDeviceProp_t prop; CK(hipGetDeviceProperties(&prop, 0)); const int cus = prop.multiProcessorCount;
+  // C3 shape: rows of 1024 complex128 = 16 KiB; C5 shape: rows of 1024 complex64 = 8 KiB
+  for (long long rb : {16384ll, 8192ll}) {
+    run<64, 256, 0, 1024>("strided->strided", in, out, bytes, rb, cus);
+    run<128, 512, 0, 1024>("strided->strided", in, out, bytes, rb, cus);
+    run<256, 512, 0, 1024>("strided->strided", in, out, bytes, rb, cus);
+    run<512, 1024, 0, 1024>("strided->strided", in, out, bytes, rb, cus);
+    run<128, 512, 1, 1024>("strided->contiguous", in, out, bytes, rb, cus);
+    run<256, 512, 1, 1024>("strided->contiguous", in, out, bytes, rb, cus);
+    run<128, 512, 2, 1024>("contiguous->strided", in, out, bytes, rb, cus);
+    run<256, 512, 2, 1024>("contiguous->strided", in, out, bytes, rb, cus);
+  }
+  return 0;
+}

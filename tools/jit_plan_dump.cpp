@@ -1,0 +1,17 @@
+// prints the runtime planner's choice for a list of lengths (no GPU needed)
+#include <cstdio>
+#include <cstdlib>
+#include "../portfft_amd/csrc/jit.hpp"
+int main(int argc, char** argv) {
+  for (int prec = 0; prec < 2; ++prec)
+    for (int i = 1; i < argc; ++i) {
+      long long n = atoll(argv[i]);
+      pfa::wg_params p;
+      if (pfa::choose_spec_params(prec, n, 160 * 1024, &p)) {
+        printf("%s spec    n=%-6lld %-70s lds=%zu regs=%d\n", prec ? "f64" : "f32", n, pfa::wg_cfg_type_name(p).c_str(), pfa::spec_lds_bytes(p), p.regs);
+      } else printf("%s spec    n=%-6lld none\n", prec ? "f64" : "f32", n);
+      if (pfa::choose_strided_params(prec, n, 1 << 20, 160 * 1024, &p)) {
+        printf("%s strided n=%-6lld %-70s regs=%d\n", prec ? "f64" : "f32", n, pfa::wg_cfg_type_name(p).c_str(), p.regs);
+      } else printf("%s strided n=%-6lld none\n", prec ? "f64" : "f32", n);
+    }
+}
