@@ -679,6 +679,25 @@ struct plan_t {
     sb.ffts_per_batch = n1;
     sb.in_batch_dist = 0;
     sb.out_batch_dist = n;
+    // Group-major intermediate: stage A's work-group (FPW_A adjacent columns, all n1 rows) writes its n1 x FPW_A
+    // block contiguously; stage B then reads row k1 as n2 / FPW_A tiles of FPW_A elements, and its FPW_B adjacent rows
+    // share FPW_A * FPW_B contiguous elements per tile.  Measured on the C3 stages (tools/tune_strided.hip): column
+    // kernel with a contiguous instead of a strided side 4.9 -> 5.3 (output) / 5.8 (input) TB/s.
+    if (sa.strided != nullptr && sb.strided != nullptr && sb.row_mode == 0 && getenv("PFFT_NO_TILED_SCRATCH") == nullptr) {
+      const int t = sa.strided->fpw;
+      int sh = 0;
+      while ((1 << sh) < t) ++sh;
+      const long long nb0 = n2 / sb.strided->radices[0];
+      if ((1 << sh) == t && n2 % t == 0 && nb0 % t == 0 &&
+          static_cast<unsigned long long>(n) * elem_bytes() < 0xFFFFFFF0ull) {
+        out.back().sa.out_gdist = n1 * t;  // stage A (already pushed)
+        out.back().sa.out_stride = static_cast<unsigned>(t);
+        out.back().sa.out_fdist = 1;
+        sb.sa.in_tile_shift = sh;
+        sb.sa.in_stride = static_cast<unsigned>(n1 * t);
+        sb.sa.in_fdist = static_cast<unsigned>(t);
+      }
+    }
     out.push_back(sb);
     record(PFFT_TIER_GLOBAL, {static_cast<int>(n1), static_cast<int>(n2)}, sb.generic ? GENERIC_WG : kb->wg,
            sb.generic ? sb.ga.fpw : kb->fpw, std::max(sa.lds_bytes, sb.lds_bytes));

@@ -72,10 +72,12 @@ PFA_DEV void strided_pass(const IO& io, const strided_args& a, unsigned f,
     if (!ragged || j < NB) {
       if constexpr (first) {
         // dead lanes (FFT beyond the end) get an out-of-range offset: the buffer range check returns zeros
-        const unsigned voff = live ? (f * a.in_fdist + j * a.in_stride) * ES : 0xFFFFFFF0u;
+        const unsigned tsh = static_cast<unsigned>(a.in_tile_shift);
+        const unsigned voff =
+            live ? (f * a.in_fdist + (j >> tsh) * a.in_stride + (j & ((1u << tsh) - 1u))) * ES : 0xFFFFFFF0u;
         sfor<0, R>([&](auto t_) PFA_LAMBDA {
           constexpr int t = decltype(t_)::value;
-          cx<T> x = io.load(voff, static_cast<unsigned>(t * NB) * a.in_stride * ES);
+          cx<T> x = io.load(voff, (static_cast<unsigned>(t * NB) >> tsh) * a.in_stride * ES);
           if constexpr (BWD) x.im = -x.im;
           v[i][t] = x;
         });
@@ -104,7 +106,9 @@ PFA_DEV void strided_pass(const IO& io, const strided_args& a, unsigned f,
       dft<R>(v[i]);
       const unsigned base = (j / Ns) * (Ns * R) + q;
       if constexpr (last) {
-        const unsigned voff = live ? (f * a.out_fdist + base * a.out_stride) * ES : 0xFFFFFFF0u;
+        const unsigned osh = static_cast<unsigned>(a.out_tile_shift);
+        const unsigned voff =
+            live ? (f * a.out_fdist + (base >> osh) * a.out_stride + (base & ((1u << osh) - 1u))) * ES : 0xFFFFFFF0u;
         const T scale = static_cast<T>(a.scale);
         // store modifier W_M^{k*c}, k = base + u*Ns: W^{base*c} and the step W^{Ns*c} come from the hi/lo tables
         // (4 loads per butterfly instead of 2 per output), the powers of the step by squaring / one multiply
@@ -139,7 +143,7 @@ PFA_DEV void strided_pass(const IO& io, const strided_args& a, unsigned f,
           if constexpr (BWD) y.im = -y.im;
           y.re *= scale;
           y.im *= scale;
-          io.store(y, voff, static_cast<unsigned>(u * Ns) * a.out_stride * ES);
+          io.store(y, voff, (static_cast<unsigned>(u * Ns) >> osh) * a.out_stride * ES);
         });
       } else {
         cx<T>* p = lds + base * FPW + f;
@@ -175,10 +179,12 @@ PFA_DEV void strided_pass0_load(const IO& io, const strided_args& a, unsigned f,
     constexpr int i = decltype(i_)::value;
     const unsigned j = tid + i * Cfg::TPF;
     if (!ragged || j < NB) {
-      const unsigned voff = live ? (f * a.in_fdist + j * a.in_stride) * ES : 0xFFFFFFF0u;
+      const unsigned tsh = static_cast<unsigned>(a.in_tile_shift);
+      const unsigned voff =
+          live ? (f * a.in_fdist + (j >> tsh) * a.in_stride + (j & ((1u << tsh) - 1u))) * ES : 0xFFFFFFF0u;
       sfor<0, R>([&](auto t_) PFA_LAMBDA {
         constexpr int t = decltype(t_)::value;
-        cx<T> x = io.load(voff, static_cast<unsigned>(t * NB) * a.in_stride * ES);
+        cx<T> x = io.load(voff, (static_cast<unsigned>(t * NB) >> tsh) * a.in_stride * ES);
         if constexpr (BWD) x.im = -x.im;
         v[i][t] = x;
       });
@@ -230,13 +236,15 @@ PFA_DEV strided_io<typename Cfg::T, Cfg::AUX, SPLIT> strided_group(const strided
   *live = static_cast<long long>(f) < nlive;
   *c0_out = c0;
   if (nlive_out != nullptr) *nlive_out = nlive;
-  const long long ioff = o * a.in_dist_outer + c0 * a.in_fdist;
-  const long long ooff = o * a.out_dist_outer + c0 * a.out_fdist;
+  const long long ioff = a.in_gdist != 0 ? g * a.in_gdist : o * a.in_dist_outer + c0 * a.in_fdist;
+  const long long ooff = a.out_gdist != 0 ? g * a.out_gdist : o * a.out_dist_outer + c0 * a.out_fdist;
   // ranges: last element of the last FFT of the group (the planner guarantees < 4 GiB)
-  const unsigned in_bytes =
-      (static_cast<unsigned>(Cfg::FPW - 1) * a.in_fdist + static_cast<unsigned>(Cfg::N - 1) * a.in_stride + 1) * ES;
-  const unsigned out_bytes =
-      (static_cast<unsigned>(Cfg::FPW - 1) * a.out_fdist + static_cast<unsigned>(Cfg::N - 1) * a.out_stride + 1) * ES;
+  const unsigned in_bytes = (static_cast<unsigned>(Cfg::FPW - 1) * a.in_fdist +
+                             (static_cast<unsigned>(Cfg::N - 1) >> a.in_tile_shift) * a.in_stride +
+                             (1u << a.in_tile_shift)) * ES;
+  const unsigned out_bytes = (static_cast<unsigned>(Cfg::FPW - 1) * a.out_fdist +
+                              (static_cast<unsigned>(Cfg::N - 1) >> a.out_tile_shift) * a.out_stride +
+                              (1u << a.out_tile_shift)) * ES;
   IO io;
   char* ip = const_cast<char*>(static_cast<const char*>(a.in)) + ioff * ES;
   char* op = static_cast<char*>(a.out) + ooff * ES;

@@ -21,6 +21,13 @@ struct strided_args {
   const void* stw_hi;
   int stw_shift;
   long long stw_cdiv;  // store-modifier column index c = (inner index) / stw_cdiv  (1 for packed data)
+  /// group-major ("tiled") sides: when non-zero, group g of that side starts at g * gdist and (o, c) play no role in
+  /// its address -- an intermediate written by one stage for the next can then be contiguous per work-group
+  long long in_gdist, out_gdist;
+  /// two-level element stride ("tiles" of 2^shift consecutive elements): element i of an FFT lives at
+  /// (i >> shift) * stride + (i & (2^shift - 1)); shift 0 = plain element stride.  Requires the first-pass (input)
+  /// / last-pass (output) butterfly stride of the kernel to be a multiple of the tile.
+  int in_tile_shift, out_tile_shift;
 };
 
 }  // namespace pfa
