@@ -43,6 +43,26 @@ size_t spec_lds_bytes(const wg_params& p);
 /// "pfa::wg_cfg<float, pfa::radix_list<..>, ...>"
 std::string wg_cfg_type_name(const wg_params& p);
 
+/// A fused N-D kernel (stockham_nd.hpp): `k` has the launch interface of a packed kernel of length prod(dims);
+/// radices[d] are the passes of dimension d (their twiddle tables follow each other, last dimension first).
+struct nd_kernel {
+  spec_kernel k{};
+  std::vector<int> dims;
+  std::vector<std::vector<int>> radices;
+  int pads = 0, padw = 0, occ = 1, regs = 0;
+};
+
+/// Planner of the fused N-D tier: all of the (rank >= 2) transform in LDS.  False when it does not fit (64 KiB)
+/// or a dimension has a prime factor above 31.
+bool choose_nd_params(int precision, const std::vector<long long>& dims, size_t max_lds, nd_kernel* out);
+
+/// "pfa::nd_cfg<float, 4096, 256, 1, ..., pfa::nd_pass<...>, ...>"
+std::string nd_cfg_type_name(const nd_kernel& p);
+
+/// Runtime-compiled fused N-D kernel on the current device (cached), interleaved or split variant on demand.
+const nd_kernel* jit_nd_kernel(int precision, const std::vector<long long>& dims, bool split, size_t max_lds,
+                               std::string* why);
+
 bool jit_enabled();
 
 /// Runtime-compiled packed kernel for length n on the current device (cached); the requested storage variant
@@ -66,6 +86,7 @@ hipError_t jit_launch_strided_split(const strided_kernel* k, hipStream_t stream,
 /// Compile (do not load) the forward + backward kernels of `p` for `arch`: needs no device, used by the build check
 /// and the CPU tests.  kind 0: packed interleaved, 1: packed split, 2: strided, 3: strided with store modifier.
 bool jit_compile_only(const wg_params& p, int kind, const char* arch, size_t* code_bytes, std::string* why);
+bool jit_compile_only_nd(const nd_kernel& p, bool split, const char* arch, size_t* code_bytes, std::string* why);
 
 /// counters for tests / plan info: kernels compiled by hiprtc and loaded from the disk cache in this process
 void jit_stats(long long* compiled, long long* from_disk);

@@ -195,6 +195,23 @@ struct plan_t {
     return upload(t.data(), t.size() * sizeof(float));
   }
 
+  /// fused N-D kernel: the per-dimension tables one after the other, last dimension first (nd_cfg_type_name)
+  void* upload_nd_twiddles(const nd_kernel& nk) {
+    auto build = [&](auto tag) {
+      using T = decltype(tag);
+      std::vector<T> all;
+      for (int d = static_cast<int>(nk.dims.size()) - 1; d >= 0; --d) {
+        const std::vector<int>& r = nk.radices[static_cast<size_t>(d)];
+        if (r.size() < 2) continue;  // a single pass has no twiddles
+        const std::vector<T> t = host_twiddles<T>(r);
+        all.insert(all.end(), t.begin(), t.end());
+      }
+      if (all.empty()) all = {T(1), T(0)};
+      return upload(all.data(), all.size() * sizeof(T));
+    };
+    return desc.precision == PFFT_PRECISION_F64 ? build(double{}) : build(float{});
+  }
+
   /// W_M^m split in two tables (see generic_args::stw_*)
   void upload_store_twiddles(long long M, int shift, const void** lo, const void** hi) {
     const long long nlo = 1ll << shift;
@@ -387,7 +404,7 @@ struct plan_t {
   }
 
   stage make_spec_stage(const spec_kernel* k, long long count, int in_buf, long long in_off, int out_buf,
-                        long long out_off, double scale, int backward) {
+                        long long out_off, double scale, int backward, const void* twiddles = nullptr) {
     stage s;
     s.generic = false;
     s.spec = k;
@@ -399,7 +416,8 @@ struct plan_t {
     s.count = count;
     s.scale = scale;
     s.backward = backward;
-    s.tw = upload_twiddles(std::vector<int>(k->radices, k->radices + k->n_radices));
+    s.tw = twiddles != nullptr ? twiddles
+                               : upload_twiddles(std::vector<int>(k->radices, k->radices + k->n_radices));
     for (int d = 0; d < 2 && k->launch != nullptr; ++d) {
       if (k->lds_bytes > 48 * 1024) {
         hip_check(hipFuncSetAttribute(k->fn[d], hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -727,6 +745,28 @@ struct plan_t {
     // N-D, packed (validated): contiguous dimension first, then every outer dimension in place on the output,
     // as strided FFTs (reference: dispatch_dimensions, committed_descriptor_impl.hpp:923-948; there one launch per
     // (batch, outer index), here one launch per dimension).
+    // ... unless the whole transform fits LDS: then one fused launch does every dimension (stockham_nd.hpp)
+    {
+      const std::vector<long long> dims(desc.lengths, desc.lengths + rank);
+      std::string why;
+      if (const nd_kernel* nk = jit_nd_kernel(desc.precision, dims, desc.complex_storage == PFFT_SPLIT_COMPLEX, max_lds,
+                                              &why)) {
+        st.push_back(make_spec_stage(&nk->k, B, BUF_IN, static_cast<long long>(vin.offset), BUF_OUT,
+                                     static_cast<long long>(vout.offset), scale, backward, upload_nd_twiddles(*nk)));
+        for (int i = 0; record && i < rank; ++i) {
+          pfft_dim_info_t& di = info.dims[i];
+          const std::vector<int>& r = nk->radices[static_cast<size_t>(i)];
+          di.length = desc.lengths[i];
+          di.tier = PFFT_TIER_WORKGROUP;
+          di.n_factors = static_cast<int>(std::min<size_t>(r.size(), PFFT_MAX_FACTORS));
+          for (int f = 0; f < di.n_factors; ++f) di.factors[f] = r[static_cast<size_t>(f)];
+          di.workgroup_size = nk->k.wg;
+          di.ffts_per_workgroup = nk->k.fpw;
+          di.lds_bytes = nk->k.lds_bytes;
+        }
+        return;
+      }
+    }
     const long long last = static_cast<long long>(desc.lengths[rank - 1]);
     {
       addressing ia{static_cast<long long>(vin.offset), 1, last, 0};

@@ -3,6 +3,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <string>
+#include <vector>
 
 #include "../../portfft_amd/csrc/jit.hpp"
 
@@ -83,6 +84,34 @@ int main(int argc, char** argv) {
       const bool built = pfa::jit_compile_only(q, c.kind, "gfx950", &bytes, &why);
       EXPECT(built && bytes > 1000, "hiprtc n=%lld kind=%d: %s", c.n, c.kind, why.c_str());
       std::printf("hiprtc n=%lld kind=%d %s: %zu bytes\n", c.n, c.kind, pfa::wg_cfg_type_name(q).c_str(), bytes);
+    }
+  }
+  // fused N-D tier: fits-in-LDS rule, pass products, and (with "compile") the nd kernel templates under hiprtc
+  {
+    struct { int prec; std::vector<long long> dims; bool ok; } shapes[] = {
+        {0, {64, 64}, true}, {1, {16, 16, 16}, true}, {0, {30, 50}, true}, {0, {128, 128}, false},
+        {1, {64, 128}, false}, {0, {37, 8}, false},   {0, {4, 1, 8}, true}};
+    for (auto& sh : shapes) {
+      pfa::nd_kernel nk;
+      const bool ok = pfa::choose_nd_params(sh.prec, sh.dims, max_lds, &nk);
+      EXPECT(ok == sh.ok, "nd shape %lldx%lld.. planned=%d", sh.dims[0], sh.dims[1], int(ok));
+      if (!ok) continue;
+      long long tot = 1;
+      for (size_t d = 0; d < sh.dims.size(); ++d) {
+        long long pd = 1;
+        for (int r : nk.radices[d]) pd *= r;
+        EXPECT(pd == sh.dims[d], "nd dim product");
+        tot *= sh.dims[d];
+      }
+      EXPECT(nk.k.n == tot && nk.k.wg % nk.k.fpw == 0 && nk.k.wg <= 1024 && nk.k.lds_bytes <= 64 * 1024 + 4096,
+             "nd kernel shape n=%d wg=%d fpw=%d lds=%zu", nk.k.n, nk.k.wg, nk.k.fpw, nk.k.lds_bytes);
+      if (argc > 1 && std::string(argv[1]) == "compile" && tot >= 512) {
+        size_t bytes = 0;
+        std::string why;
+        const bool built = pfa::jit_compile_only_nd(nk, sh.prec == 1, "gfx950", &bytes, &why);
+        EXPECT(built && bytes > 1000, "hiprtc nd: %s", why.c_str());
+        std::printf("hiprtc nd %s: %zu bytes\n", pfa::nd_cfg_type_name(nk).c_str(), bytes);
+      }
     }
   }
   if (fails == 0) std::printf("jit planner OK\n");

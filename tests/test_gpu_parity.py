@@ -418,6 +418,40 @@ def test_runtime_specialised_lengths():
         _check(back, x.astype(np.complex128) * n, n, dtype, ("jit four-step bwd", prec, n))
 
 
+def test_fused_multidimensional():
+    """N-D transforms that fit LDS run as ONE launch (csrc/stockham_nd.hpp, specialised at commit); the reference
+    launches per dimension and per (batch, outer index) (committed_descriptor_impl.hpp:923-948).  Parity with NumPy,
+    agreement with the per-dimension path (PFFT_FUSED_ND=0), both storages and placements, offsets, ragged batches"""
+    import os
+    import gpu_utils as G
+    pf = _pf()
+    shapes = [("f32", [64, 64]), ("f32", [16, 16, 16]), ("f32", [2, 3]), ("f32", [30, 50]), ("f32", [4, 2, 8]),
+              ("f32", [3, 4, 5, 6]), ("f64", [64, 64]), ("f64", [27, 125]), ("f64", [5, 7])]
+    for prec, dims in shapes:
+        dtype = np.complex64 if prec == "f32" else np.complex128
+        n = int(np.prod(dims))
+        for batch in (1, 7, 130):
+            x, y = H.gen_fourier_data(batch, dims, dtype, seed=n + batch)
+            for storage in (0, 1):
+                for place in (0, 1):
+                    d = G.make_descriptor(dims, prec, batch=batch, storage=storage, placement=place, fwd_scale=0.25,
+                                          fwd_offset=3, bwd_offset=3 if place == 0 else 9)
+                    got, _ = G.transform_packed(d, pf.direction.FORWARD, x)
+                    _check(got.reshape(batch, -1), 0.25 * y.reshape(batch, -1), n, dtype, ("fused nd", prec, dims, batch))
+                    back, _ = G.transform_packed(d, pf.direction.BACKWARD, y)
+                    _check(back.reshape(batch, -1), x.reshape(batch, -1).astype(np.complex128) * n, n, dtype,
+                           ("fused nd bwd", prec, dims, batch))
+        d = G.make_descriptor(dims, prec, batch=7)
+        fused, _ = G.transform_packed(d, pf.direction.FORWARD, H.gen_fourier_data(7, dims, dtype, seed=1)[0])
+        os.environ["PFFT_FUSED_ND"] = "0"
+        try:
+            d2 = G.make_descriptor(dims, prec, batch=7)
+            per_dim, _ = G.transform_packed(d2, pf.direction.FORWARD, H.gen_fourier_data(7, dims, dtype, seed=1)[0])
+        finally:
+            del os.environ["PFFT_FUSED_ND"]
+        assert H.rel_l2(fused, per_dim) < (2e-6 if prec == "f32" else 5e-15), (prec, dims)
+
+
 def test_error_behaviour_and_plan_info():
     import gpu_utils as G
     pf = _pf()

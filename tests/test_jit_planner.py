@@ -25,3 +25,4 @@ def test_planner_invariants_and_hiprtc_compile():
     assert p.returncode == 0, p.stdout + p.stderr
     assert "jit planner OK" in p.stdout
     assert p.stdout.count("hiprtc n=") == 5
+    assert p.stdout.count("hiprtc nd ") == 3

@@ -82,5 +82,11 @@ if __name__ == "__main__":
         ok &= check(0, "f64", lengths=[243, 625])
         ok &= check(30000); ok &= check(62500); ok &= check(1000000); ok &= check(30000, "f64"); ok &= check(2985984)  # 12^6
         ok &= check(4800, layout="BI"); ok &= check(16000, layout="BI")
+    if which in ("all", "nd"):
+        for dims in ([64, 64], [32, 32], [8, 8], [16, 16, 16], [128, 32], [32, 128], [30, 50], [4, 4, 4, 4], [2, 3], [90, 90]):
+            ok &= check(0, lengths=dims)
+            ok &= check(0, lengths=dims, split=True)
+        for dims in ([64, 64], [16, 16, 16], [27, 125], [8, 8]):
+            ok &= check(0, "f64", lengths=dims)
     print("ALL OK" if ok else "FAILURES")
     sys.exit(0 if ok else 1)
