@@ -371,7 +371,7 @@ constexpr size_t strided_lds_bytes() {
 template <typename Cfg, bool BWD, bool STW, bool SPLIT = false>
 __global__ __launch_bounds__(Cfg::WG, Cfg::OCC) void stockham_strided_kernel(const strided_args a) {
   using T = typename Cfg::T;
-  static_assert(Cfg::NP >= 2, "the strided tier needs at least two passes (LDS exchange)");
+  // (a single-pass plan -- one lane per FFT, the reference's WORKITEM tier on strided data -- uses no LDS at all)
   extern __shared__ __attribute__((aligned(16))) char pfa_smem_strided[];
   cx<T>* lds = reinterpret_cast<cx<T>*>(pfa_smem_strided);
   const unsigned f = threadIdx.x % Cfg::FPW;

@@ -82,6 +82,14 @@ if __name__ == "__main__":
         ok &= check(0, "f64", lengths=[243, 625])
         ok &= check(30000); ok &= check(62500); ok &= check(1000000); ok &= check(30000, "f64"); ok &= check(2985984)  # 12^6
         ok &= check(4800, layout="BI"); ok &= check(16000, layout="BI")
+    if which in ("all", "small"):
+        for n in (4, 8, 16, 31, 32):
+            ok &= check(n, layout="BI")
+            ok &= check(n, "f64", layout="BI")
+        ok &= check(0, lengths=[16, 16, 1024])
+        ok &= check(0, lengths=[8, 12, 2048])
+        ok &= check(0, "f64", lengths=[16, 16, 512])
+        ok &= check(0, lengths=[16, 16, 16, 16])
     if which in ("all", "nd"):
         for dims in ([64, 64], [32, 32], [8, 8], [16, 16, 16], [128, 32], [32, 128], [30, 50], [4, 4, 4, 4], [2, 3], [90, 90]):
             ok &= check(0, lengths=dims)
