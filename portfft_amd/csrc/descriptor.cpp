@@ -190,13 +190,11 @@ void validate(const pfft_desc_t& d) {
   if (d.rank > 1 && !(fl == PFFT_LAYOUT_PACKED && bl == PFFT_LAYOUT_PACKED)) {
     fail(PFFT_UNSUPPORTED_CONFIGURATION, "Multi-dimensional transforms are only supported with default data layout");
   }
-  if (fl == PFFT_LAYOUT_UNPACKED || bl == PFFT_LAYOUT_UNPACKED) {
-    const int scalar_bytes = d.precision == PFFT_PRECISION_F64 ? 8 : 4;
-    if (!fits_wavefront_registers(static_cast<int64_t>(d.lengths[d.rank - 1]), scalar_bytes)) {
-      fail(PFFT_UNSUPPORTED_CONFIGURATION,
-           "Arbitrary strides and distances are only supported for sizes that fit in the registers of a subgroup");
-    }
-  }
+  // The reference rejects UNPACKED layouts for lengths beyond its subgroup tier ("Arbitrary strides and distances are
+  // only supported for sizes that fit in the registers of a subgroup", committed_descriptor_impl.hpp:757-764).  That
+  // is a limit of its kernels, not of the interface: here every length a single work-group can hold takes any
+  // stride / distance (stockham_wg_unpacked_kernel, generic tier), so the check is not mirrored; only lengths that
+  // need the multi-kernel tier still require the default layout (plan.cpp).
 }
 
 }  // namespace pfa

@@ -67,11 +67,27 @@ bool jit_enabled();
 
 /// Runtime-compiled packed kernel for length n on the current device (cached); the requested storage variant
 /// (interleaved or split) is compiled on demand.  nullptr + *why when the length cannot be planned or hiprtc fails.
-const spec_kernel* jit_spec_kernel(int precision, long long n, bool split, size_t max_lds, std::string* why);
+/// plan_only: return the entry with its parameters without compiling the packed form (other forms of the same
+/// configuration are built from it: jit_unpacked_kernel).
+const spec_kernel* jit_spec_kernel(int precision, long long n, bool split, size_t max_lds, std::string* why,
+                                   bool plan_only = false);
 
 /// Runtime-compiled strided kernel; `store_modifier` / `split` select the variants to make available.
 const strided_kernel* jit_strided_kernel(int precision, long long n, long long inner_count, bool store_modifier,
                                          bool split, size_t max_lds, std::string* why);
+
+/// UNPACKED-layout form (stockham_wg_unpacked_kernel) of the packed configuration `like` (a pre-compiled or a
+/// runtime-specialised entry): forward/backward module functions for interleaved or split storage.
+struct unpacked_kernel {
+  const spec_kernel* base = nullptr;
+  hipFunction_t fn[2] = {nullptr, nullptr};        // interleaved
+  hipFunction_t fn_split[2] = {nullptr, nullptr};  // split
+};
+const unpacked_kernel* jit_unpacked_kernel(const spec_kernel* like, bool split, std::string* why);
+hipError_t jit_launch_unpacked(const unpacked_kernel* k, bool split, hipStream_t stream, unsigned grid, const void* in,
+                               const void* in_im, void* out, void* out_im, const void* tw, long long nfft,
+                               double scale, int backward, unsigned in_stride, unsigned in_dist, unsigned out_stride,
+                               unsigned out_dist);
 
 hipError_t jit_launch_spec(const spec_kernel* k, hipStream_t stream, unsigned grid, const void* in, void* out,
                            const void* tw, long long nfft, double scale, int backward);

@@ -37,6 +37,9 @@ struct spec_kernel {
   /// runtime-compiled entries (jit.cpp): module functions, launched with jit_launch_spec*; fn / launch are null
   hipFunction_t mfn[2];
   hipFunction_t mfn_split[2];
+  /// the remaining wg_cfg arguments, so that other forms of the same configuration (UNPACKED layouts) can be
+  /// instantiated at run time
+  int pads, padw, twm, occ, aux, staged;
 };
 
 /// One strided work-group kernel (stockham_strided.hpp): FPW FFTs side by side, any element stride / FFT distance.

@@ -86,6 +86,12 @@ spec_kernel make_spec_entry(int groups_per_wg) {
   for (int i = 0; i < Cfg::NP; ++i) k.radices[i] = Cfg::Seq::r[i];
   k.tw_total = Cfg::Seq::tw_total;
   k.tw_in_regs = Cfg::TWM == TW_REGS ? 1 : 0;
+  k.pads = Cfg::PADS;
+  k.padw = Cfg::PADW;
+  k.twm = Cfg::TWM;
+  k.occ = Cfg::OCC;
+  k.aux = Cfg::AUX;
+  k.staged = Cfg::STAGED;
   k.fn[0] = reinterpret_cast<const void*>(&stockham_wg_kernel<Cfg, false>);
   k.fn[1] = reinterpret_cast<const void*>(&stockham_wg_kernel<Cfg, true>);
   k.launch = &launch_spec<Cfg>;

@@ -43,6 +43,7 @@ struct addressing {
 struct stage {
   bool generic = false;
   const spec_kernel* spec = nullptr;
+  const unpacked_kernel* unpacked = nullptr;  // spec + UNPACKED layout: in_addr / out_addr hold strides and distances
   const strided_kernel* strided = nullptr;
   strided_args sa{};
   int store_modifier = 0;
@@ -404,7 +405,8 @@ struct plan_t {
   }
 
   stage make_spec_stage(const spec_kernel* k, long long count, int in_buf, long long in_off, int out_buf,
-                        long long out_off, double scale, int backward, const void* twiddles = nullptr) {
+                        long long out_off, double scale, int backward, const void* twiddles = nullptr,
+                        const unpacked_kernel* unpacked = nullptr) {
     stage s;
     s.generic = false;
     s.spec = k;
@@ -429,6 +431,12 @@ struct plan_t {
       }
     }
     const bool split = desc.complex_storage == PFFT_SPLIT_COMPLEX;
+    s.unpacked = unpacked;
+    if (unpacked != nullptr) {
+      s.grid = persistent_grid(nullptr, (split ? unpacked->fn_split : unpacked->fn)[backward], k->wg, k->lds_bytes,
+                               (count + k->fpw - 1) / k->fpw, k->groups_per_wg);
+      return s;
+    }
     s.grid = persistent_grid(k->launch != nullptr ? k->fn[backward] : nullptr,
                              split ? k->mfn_split[backward] : k->mfn[backward], k->wg, k->lds_bytes,
                              (count + k->fpw - 1) / k->fpw, k->groups_per_wg);
@@ -587,6 +595,40 @@ struct plan_t {
         record(k->n_radices == 1 ? PFFT_TIER_REGISTER : PFFT_TIER_WORKGROUP,
                std::vector<int>(k->radices, k->radices + k->n_radices), k->wg, k->fpw, k->lds_bytes);
         return PFFT_TIER_WORKGROUP;
+      }
+    }
+    // UNPACKED layouts whose transforms do not interleave (padded rows, every k-th sample): the packed kernel's
+    // configuration with runtime strides, lanes element-fastest
+    {
+      auto row_like = [&](const addressing& a) {
+        return a.stride >= 1 && a.dist_inner >= (n - 1) * a.stride + 1 && a.stride < (1ll << 20) &&
+               a.dist_inner < (1ll << 31);
+      };
+      const bool user_bufs = in_buf != BUF_SCRATCH && out_buf != BUF_SCRATCH;
+      if (!packed_io && inner_count == count && row_like(ia) && row_like(oa) && (interleaved || user_bufs) &&
+          !(ia.stride == 1 && ia.dist_inner == n && oa.stride == 1 && oa.dist_inner == n)) {
+        const spec_kernel* k = find_spec(n);
+        if (k == nullptr) {
+          std::string why;
+          k = jit_spec_kernel(desc.precision, n, !interleaved, max_lds, &why, true);
+        }
+        auto fits = [&](const addressing& a) {
+          const unsigned long long elems = static_cast<unsigned long long>(k->fpw - 1) * a.dist_inner +
+                                           static_cast<unsigned long long>(n - 1) * a.stride + 1;
+          return elems * elem_bytes() < 0xFFFFFFF0ull;
+        };
+        std::string why;
+        const unpacked_kernel* u = (k != nullptr && fits(ia) && fits(oa)) ? jit_unpacked_kernel(k, !interleaved, &why)
+                                                                          : nullptr;
+        if (u != nullptr) {
+          stage s = make_spec_stage(k, count, in_buf, ia.offset, out_buf, oa.offset, scale, backward, nullptr, u);
+          s.in_addr = ia;
+          s.out_addr = oa;
+          out.push_back(s);
+          record(k->n_radices == 1 ? PFFT_TIER_REGISTER : PFFT_TIER_WORKGROUP,
+                 std::vector<int>(k->radices, k->radices + k->n_radices), k->wg, k->fpw, k->lds_bytes);
+          return PFFT_TIER_WORKGROUP;
+        }
       }
     }
     // Long batch-interleaved transforms: one work-group could hold only a few columns (narrow HBM segments), so
@@ -853,6 +895,21 @@ struct plan_t {
       hip_check(s.strided->launch != nullptr
                     ? s.strided->launch(stream, grid, a, s.backward, s.store_modifier)
                     : jit_launch_strided(s.strided, stream, grid, a, s.backward, s.store_modifier),
+                "kernel launch");
+      return;
+    }
+    if (!s.generic && s.unpacked != nullptr) {
+      const bool user_split = split && s.in_buf != BUF_SCRATCH;
+      const size_t unit = user_split ? sb : elem_bytes();
+      const char* i_re = base_re(s.in_buf, true) + static_cast<size_t>(s.in_offset) * unit;
+      const char* i_im = base_im(s.in_buf) + static_cast<size_t>(s.in_offset) * unit;
+      char* o_re = const_cast<char*>(base_re(s.out_buf, false)) + static_cast<size_t>(s.out_offset) * unit;
+      char* o_im = const_cast<char*>(base_im(s.out_buf)) + static_cast<size_t>(s.out_offset) * unit;
+      hip_check(jit_launch_unpacked(s.unpacked, user_split, stream, s.grid, i_re, i_im, o_re, o_im, s.tw, s.count,
+                                    s.scale, s.backward, static_cast<unsigned>(s.in_addr.stride),
+                                    static_cast<unsigned>(s.in_addr.dist_inner),
+                                    static_cast<unsigned>(s.out_addr.stride),
+                                    static_cast<unsigned>(s.out_addr.dist_inner)),
                 "kernel launch");
       return;
     }

@@ -109,12 +109,11 @@ PFA_DEV void stockham_nd_body(MakeIO&& make_io, const cx<typename Cfg::T>* __res
   const long long ngroups = (nfft + Cfg::FPW - 1) / Cfg::FPW;
   for (long long g = blockIdx.x; g < ngroups; g += gridDim.x) {
     const auto io = make_io(g);
-    using IO = decltype(io);
     sfor<0, EPT>([&](auto k_) PFA_LAMBDA {
       constexpr int k = decltype(k_)::value;
       const unsigned e = threadIdx.x + k * Cfg::WG;
       if (CH % Cfg::WG == 0 || e < CH) {
-        cx<T> x = io.load(e * IO::ES, 0);
+        cx<T> x = io.load(io.in_elem(e), 0);
         if constexpr (BWD) x.im = -x.im;
         all[(e / Cfg::N) * Cfg::LDS_PER_FFT + lds_pad<Cfg>(e % Cfg::N)] = x;
       }
@@ -131,7 +130,7 @@ PFA_DEV void stockham_nd_body(MakeIO&& make_io, const cx<typename Cfg::T>* __res
         if constexpr (BWD) y.im = -y.im;
         y.re *= scale;
         y.im *= scale;
-        io.store(y, e * IO::ES, 0);
+        io.store(y, io.out_elem(e), 0);
       }
     });
     __syncthreads();  // the next group's copy-in overwrites the images

@@ -155,6 +155,14 @@ struct packed_io {
   static PFA_DEV unsigned lane_off(unsigned f, unsigned j) { return (f * N + j) * sizeof(cx<T>); }
   /// uniform byte offset of k elements
   static constexpr unsigned step(int k) { return k * sizeof(cx<T>); }
+  // the interface the passes use (input and output side may differ: unpacked_io)
+  static PFA_DEV unsigned in_off(unsigned f, unsigned j) { return lane_off(f, j); }
+  static PFA_DEV unsigned out_off(unsigned f, unsigned j) { return lane_off(f, j); }
+  static constexpr unsigned in_step(int k) { return step(k); }
+  static constexpr unsigned out_step(int k) { return step(k); }
+  /// element e of the group's FPW * N contiguous elements (staged copies)
+  static PFA_DEV unsigned in_elem(unsigned e) { return e * ES; }
+  static PFA_DEV unsigned out_elem(unsigned e) { return e * ES; }
   PFA_DEV cx<T> load(unsigned voff, unsigned soff) const { return buf_load<T, AUX>(rin, voff, soff); }
   PFA_DEV void store(cx<T> v, unsigned voff, unsigned soff) const { buf_store<T, AUX>(v, rout, voff, soff); }
 };
@@ -195,12 +203,72 @@ struct packed_split_io {
   }
   static PFA_DEV unsigned lane_off(unsigned f, unsigned j) { return (f * N + j) * ES; }
   static constexpr unsigned step(int k) { return k * ES; }
+  static PFA_DEV unsigned in_off(unsigned f, unsigned j) { return lane_off(f, j); }
+  static PFA_DEV unsigned out_off(unsigned f, unsigned j) { return lane_off(f, j); }
+  static constexpr unsigned in_step(int k) { return step(k); }
+  static constexpr unsigned out_step(int k) { return step(k); }
+  static PFA_DEV unsigned in_elem(unsigned e) { return e * ES; }
+  static PFA_DEV unsigned out_elem(unsigned e) { return e * ES; }
   PFA_DEV cx<T> load(unsigned voff, unsigned soff) const {
     return {buf_load_scalar<T, AUX>(rin_re, voff, soff), buf_load_scalar<T, AUX>(rin_im, voff, soff)};
   }
   PFA_DEV void store(cx<T> v, unsigned voff, unsigned soff) const {
     buf_store_scalar<T, AUX>(v.re, rout_re, voff, soff);
     buf_store_scalar<T, AUX>(v.im, rout_im, voff, soff);
+  }
+};
+
+/// UNPACKED layouts (reference: detail::layout::UNPACKED, enums.hpp:47-50; the strided branches of the dispatchers,
+/// workitem_dispatcher.hpp:178-204, subgroup_dispatcher.hpp:441-466): element i of transform t at
+/// t * dist + i * stride, with dist >= (N - 1) * stride + 1 (transforms do not interleave: rows of a padded
+/// matrix, every other sample, ...).  Lanes stay element-fastest, so stride 1 keeps full coalescing.
+/// SPLIT: separate real / imaginary planes.
+template <typename T, int N, int FPW, int AUX, bool SPLIT>
+struct unpacked_io {
+  static constexpr unsigned ES = SPLIT ? sizeof(T) : sizeof(cx<T>);
+  __amdgpu_buffer_rsrc_t rin, rin_im, rout, rout_im;
+  unsigned is, id, os, od;
+  PFA_DEV unpacked_io(const void* in, const void* in_im, void* out, void* out_im, long long g, long long nfft,
+                      unsigned is_, unsigned id_, unsigned os_, unsigned od_)
+      : is(is_), id(id_), os(os_), od(od_) {
+    const long long first = g * FPW;
+    const long long left = nfft - first;
+    const unsigned live = static_cast<unsigned>(left < FPW ? left : FPW);
+    const unsigned ibytes = ((live - 1) * id + (N - 1) * is + 1) * ES;
+    const unsigned obytes = ((live - 1) * od + (N - 1) * os + 1) * ES;
+    const long long ioff = first * static_cast<long long>(id) * ES, ooff = first * static_cast<long long>(od) * ES;
+    rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(static_cast<const char*>(in)) + ioff, 0, ibytes,
+                                            0x00020000);
+    rout = __builtin_amdgcn_make_buffer_rsrc(static_cast<char*>(out) + ooff, 0, obytes, 0x00020000);
+    if constexpr (SPLIT) {
+      rin_im = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(static_cast<const char*>(in_im)) + ioff, 0, ibytes,
+                                                 0x00020000);
+      rout_im = __builtin_amdgcn_make_buffer_rsrc(static_cast<char*>(out_im) + ooff, 0, obytes, 0x00020000);
+    } else {
+      rin_im = rin;
+      rout_im = rout;
+    }
+  }
+  PFA_DEV unsigned in_off(unsigned f, unsigned j) const { return (f * id + j * is) * ES; }
+  PFA_DEV unsigned out_off(unsigned f, unsigned j) const { return (f * od + j * os) * ES; }
+  PFA_DEV unsigned in_step(int k) const { return static_cast<unsigned>(k) * is * ES; }
+  PFA_DEV unsigned out_step(int k) const { return static_cast<unsigned>(k) * os * ES; }
+  PFA_DEV unsigned in_elem(unsigned e) const { return ((e / N) * id + (e % N) * is) * ES; }
+  PFA_DEV unsigned out_elem(unsigned e) const { return ((e / N) * od + (e % N) * os) * ES; }
+  PFA_DEV cx<T> load(unsigned voff, unsigned soff) const {
+    if constexpr (SPLIT) {
+      return {buf_load_scalar<T, AUX>(rin, voff, soff), buf_load_scalar<T, AUX>(rin_im, voff, soff)};
+    } else {
+      return buf_load<T, AUX>(rin, voff, soff);
+    }
+  }
+  PFA_DEV void store(cx<T> v, unsigned voff, unsigned soff) const {
+    if constexpr (SPLIT) {
+      buf_store_scalar<T, AUX>(v.re, rout, voff, soff);
+      buf_store_scalar<T, AUX>(v.im, rout_im, voff, soff);
+    } else {
+      buf_store<T, AUX>(v, rout, voff, soff);
+    }
   }
 };
 
@@ -230,7 +298,7 @@ PFA_DEV void wg_pass(const IO& io, unsigned f, cx<typename Cfg::T>* lds, int tid
       if constexpr (from_global) {
         sfor<0, R>([&](auto t_) PFA_LAMBDA {
           constexpr int t = decltype(t_)::value;
-          cx<T> x = io.load(IO::lane_off(f, j), IO::step(t * NB));
+          cx<T> x = io.load(io.in_off(f, j), io.in_step(t * NB));
           if constexpr (BWD) x.im = -x.im;
           v[i][t] = x;
         });
@@ -277,7 +345,7 @@ PFA_DEV void wg_pass(const IO& io, unsigned f, cx<typename Cfg::T>* lds, int tid
           if constexpr (BWD) y.im = -y.im;
           y.re *= scale;
           y.im *= scale;
-          io.store(y, IO::lane_off(f, base), IO::step(u * Ns));
+          io.store(y, io.out_off(f, base), io.out_step(u * Ns));
         });
       } else if constexpr (pad_is_linear<Cfg>(Ns, R, Ns * R)) {
         cx<T>* p = lds + lds_pad<Cfg>(base);
@@ -321,7 +389,7 @@ PFA_DEV void wg_pass0_load(const IO& io, unsigned f, int tid,
     if (!ragged || j < NB) {
       sfor<0, R>([&](auto t_) PFA_LAMBDA {
         constexpr int t = decltype(t_)::value;
-        cx<T> x = io.load(IO::lane_off(f, j), IO::step(t * NB));
+        cx<T> x = io.load(io.in_off(f, j), io.in_step(t * NB));
         if constexpr (BWD) x.im = -x.im;
         v[i][t] = x;
       });
@@ -453,7 +521,6 @@ PFA_DEV void stockham_wg_body(MakeIO&& make_io, const cx<typename Cfg::T>* __res
   const long long ngroups = (nfft + Cfg::FPW - 1) / Cfg::FPW;
   for (long long g = blockIdx.x; g < ngroups; g += gridDim.x) {
     const auto io = make_io(g);
-    using IO = decltype(io);
     if constexpr (Cfg::STAGED) {
       // coalesced copy of the group's FPW*N contiguous elements into the (padded) per-FFT LDS images
       constexpr int CH = Cfg::FPW * Cfg::N;
@@ -463,7 +530,7 @@ PFA_DEV void stockham_wg_body(MakeIO&& make_io, const cx<typename Cfg::T>* __res
         constexpr int k = decltype(k_)::value;
         const unsigned e = threadIdx.x + k * Cfg::WG;
         if (CH % Cfg::WG == 0 || e < CH) {
-          cx<T> x = io.load(e * IO::ES, 0);
+          cx<T> x = io.load(io.in_elem(e), 0);
           if constexpr (BWD) x.im = -x.im;
           all[(e / Cfg::N) * Cfg::LDS_PER_FFT + lds_pad<Cfg>(e % Cfg::N)] = x;
         }
@@ -488,7 +555,7 @@ PFA_DEV void stockham_wg_body(MakeIO&& make_io, const cx<typename Cfg::T>* __res
           if constexpr (BWD) y.im = -y.im;
           y.re *= scale;
           y.im *= scale;
-          io.store(y, e * IO::ES, 0);
+          io.store(y, io.out_elem(e), 0);
         }
       });
       __syncthreads();  // the next group's copy-in overwrites the images
@@ -518,6 +585,21 @@ __global__ __launch_bounds__(Cfg::WG, Cfg::OCC) void stockham_wg_split_kernel(
   stockham_wg_body<Cfg, BWD>(
       [&](long long g) PFA_LAMBDA {
         return packed_split_io<T, Cfg::N, Cfg::FPW, Cfg::AUX>(in_re, in_im, out_re, out_im, g, nfft);
+      },
+      tw, nfft, scale);
+}
+
+/// UNPACKED layouts, interleaved or split storage (strides and distances in elements; in_im / out_im only for SPLIT)
+template <typename Cfg, bool BWD, bool SPLIT>
+__global__ __launch_bounds__(Cfg::WG, Cfg::OCC) void stockham_wg_unpacked_kernel(
+    const void* __restrict__ in, const void* __restrict__ in_im, void* __restrict__ out, void* __restrict__ out_im,
+    const cx<typename Cfg::T>* __restrict__ tw, long long nfft, typename Cfg::T scale, unsigned in_stride,
+    unsigned in_dist, unsigned out_stride, unsigned out_dist) {
+  using T = typename Cfg::T;
+  stockham_wg_body<Cfg, BWD>(
+      [&](long long g) PFA_LAMBDA {
+        return unpacked_io<T, Cfg::N, Cfg::FPW, Cfg::AUX, SPLIT>(in, in_im, out, out_im, g, nfft, in_stride, in_dist,
+                                                                 out_stride, out_dist);
       },
       tw, nfft, scale);
 }

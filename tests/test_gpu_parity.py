@@ -418,6 +418,34 @@ def test_runtime_specialised_lengths():
         _check(back, x.astype(np.complex128) * n, n, dtype, ("jit four-step bwd", prec, n))
 
 
+def test_unpacked_layouts_any_length():
+    """UNPACKED layouts (arbitrary stride / distance, instantiate_fft_tests.hpp:237-320) beyond the reference's
+    subgroup-sized limit: rows of a padded matrix, every k-th sample, different layouts on the two sides, both
+    storages, in place -- on the packed kernels' configurations with runtime strides (stockham_wg_unpacked_kernel)"""
+    import gpu_utils as G
+    pf = _pf()
+    cases = [("f32", 4096, 1, 4160, 1, 4160), ("f32", 4096, 1, 4160, 1, 4096), ("f32", 4096, 2, 8200, 1, 4096),
+             ("f32", 1200, 1, 1280, 3, 3700), ("f32", 64, 1, 80, 1, 80), ("f32", 16, 3, 50, 1, 16),
+             ("f64", 4096, 1, 4100, 1, 4100), ("f64", 625, 2, 1300, 1, 640), ("f32", 8192, 1, 8200, 1, 8200)]
+    for prec, n, fs, fd, bs, bd in cases:
+        dtype = np.complex64 if prec == "f32" else np.complex128
+        for batch in (1, 6, 33):
+            x, y = H.gen_fourier_data(batch, [n], dtype, seed=n + batch)
+            for storage in (0, 1):
+                d = G.make_descriptor([n], prec, batch=batch, storage=storage, fwd_strides=[fs], fwd_distance=fd,
+                                      bwd_strides=[bs], bwd_distance=bd, fwd_offset=5, bwd_offset=2, bwd_scale=1.0 / n)
+                got, _ = G.transform_packed(d, pf.direction.FORWARD, x)
+                _check(got, y, n, dtype, ("unpacked fwd", prec, n, fs, fd, bs, bd, batch, storage))
+                back, _ = G.transform_packed(d, pf.direction.BACKWARD, y)
+                _check(back, x, n, dtype, ("unpacked bwd", prec, n, fs, fd, bs, bd, batch, storage))
+                assert d.commit().info().dims[0].tier in (0, 1)
+            if (fs, fd) == (bs, bd):
+                d = G.make_descriptor([n], prec, batch=batch, placement=0, fwd_strides=[fs], fwd_distance=fd,
+                                      bwd_strides=[bs], bwd_distance=bd)
+                got, _ = G.transform_packed(d, pf.direction.FORWARD, x)
+                _check(got, y, n, dtype, ("unpacked in place", prec, n, fs, fd, batch))
+
+
 def test_fused_multidimensional():
     """N-D transforms that fit LDS run as ONE launch (csrc/stockham_nd.hpp, specialised at commit); the reference
     launches per dimension and per (batch, outer index) (committed_descriptor_impl.hpp:923-948).  Parity with NumPy,
