@@ -72,9 +72,11 @@ bool jit_enabled();
 const spec_kernel* jit_spec_kernel(int precision, long long n, bool split, size_t max_lds, std::string* why,
                                    bool plan_only = false);
 
-/// Runtime-compiled strided kernel; `store_modifier` / `split` select the variants to make available.
+/// Runtime-compiled strided kernel; `store_modifier` / `split_mode` select the variant to make available
+/// (split_mode: 0 interleaved, 1 split on both sides, 2 split input + store modifier (four-step stage A on
+/// SPLIT_COMPLEX data), 3 split output (stage B); see stockham_strided.hpp).
 const strided_kernel* jit_strided_kernel(int precision, long long n, long long inner_count, bool store_modifier,
-                                         bool split, size_t max_lds, std::string* why);
+                                         int split_mode, size_t max_lds, std::string* why);
 
 /// UNPACKED-layout form (stockham_wg_unpacked_kernel) of the packed configuration `like` (a pre-compiled or a
 /// runtime-specialised entry): forward/backward module functions for interleaved or split storage.
@@ -98,6 +100,8 @@ hipError_t jit_launch_strided(const strided_kernel* k, hipStream_t stream, unsig
                               int backward, int store_modifier);
 hipError_t jit_launch_strided_split(const strided_kernel* k, hipStream_t stream, unsigned grid,
                                     const strided_args& args, int backward);
+hipError_t jit_launch_strided_mixed(const strided_kernel* k, hipStream_t stream, unsigned grid,
+                                    const strided_args& args, int backward, int split_mode);
 
 /// Compile (do not load) the forward + backward kernels of `p` for `arch`: needs no device, used by the build check
 /// and the CPU tests.  kind 0: packed interleaved, 1: packed split, 2: strided, 3: strided with store modifier.

@@ -272,7 +272,13 @@ struct plan_t {
     const strided_kernel* k = find_strided(n);
     if (k != nullptr) return k;
     std::string why;
-    return jit_strided_kernel(desc.precision, n, inner_count, store_modifier, user_split, max_lds, &why);
+    return jit_strided_kernel(desc.precision, n, inner_count, store_modifier, user_split ? 1 : 0, max_lds, &why);
+  }
+
+  /// four-step stages on SPLIT_COMPLEX data: split user side, interleaved scratch side (runtime-specialised only)
+  const strided_kernel* get_strided_mixed(long long n, long long inner_count, int split_mode) {
+    std::string why;
+    return jit_strided_kernel(desc.precision, n, inner_count, split_mode == 2, split_mode, max_lds, &why);
   }
 
   /// the pre-compiled packed kernel, otherwise a runtime-specialised one
@@ -291,9 +297,12 @@ struct plan_t {
   bool strided_fits(const strided_kernel* k, long long inner_count, int in_buf, const addressing& ia, int out_buf,
                     const addressing& oa) const {
     if (k == nullptr) return false;
-    // split storage: both sides must be user buffers (split variant) or both scratch (interleaved variant)
+    // split storage: both sides user buffers (split variant), both scratch (interleaved variant), or one of each
+    // when the entry carries the mixed forms
     const bool split = desc.complex_storage == PFFT_SPLIT_COMPLEX;
-    if (split && ((in_buf == BUF_SCRATCH) != (out_buf == BUF_SCRATCH))) return false;
+    if (split && ((in_buf == BUF_SCRATCH) != (out_buf == BUF_SCRATCH))) {
+      if (k->mfn_mixed[in_buf == BUF_SCRATCH ? 2 : 0] == nullptr) return false;
+    }
     (void)inner_count;
     auto range_ok = [&](const addressing& a) {
       const unsigned long long elems = static_cast<unsigned long long>(k->fpw - 1) * a.dist_inner +
@@ -331,7 +340,8 @@ struct plan_t {
     a.stw_cdiv = 1;
     s.lds_bytes = k->lds_bytes;
     // row-shaped side of an interleaved fp32 stage: copy it through LDS with full-line accesses
-    const bool user_split = desc.complex_storage == PFFT_SPLIT_COMPLEX && in_buf != BUF_SCRATCH;
+    const bool user_split =
+        desc.complex_storage == PFFT_SPLIT_COMPLEX && in_buf != BUF_SCRATCH && out_buf != BUF_SCRATCH;
     if (k->launch_row != nullptr && !user_split && k->lds_bytes_row <= max_lds) {  // pre-compiled entries only
       if (ia.stride == 1 && ia.dist_inner != 1 && oa.dist_inner == 1) s.row_mode = 1;
       if (oa.stride == 1 && oa.dist_inner != 1 && ia.dist_inner == 1) s.row_mode = 2;
@@ -356,7 +366,11 @@ struct plan_t {
     }
     const long long groups = strided_groups(count, a.inner, k->fpw);
     if (k->launch == nullptr) {  // runtime-compiled: whichever variant this stage will launch
+      const bool split_storage = desc.complex_storage == PFFT_SPLIT_COMPLEX;
       hipFunction_t f = user_split ? k->mfn_split[backward] : k->mfn[backward * 2];
+      if (split_storage && (in_buf == BUF_SCRATCH) != (out_buf == BUF_SCRATCH)) {
+        f = k->mfn_mixed[(in_buf == BUF_SCRATCH ? 2 : 0) + backward];
+      }
       if (f == nullptr) f = k->mfn[backward * 2 + 1];
       s.grid = persistent_grid(nullptr, f, k->wg, k->lds_bytes, groups, k->groups_per_wg);
     } else if (s.row_mode != 0) {
@@ -701,13 +715,16 @@ struct plan_t {
     const void* stw_hi = nullptr;
     upload_store_twiddles(n, shift, &stw_lo, &stw_hi);
     const bool interleaved_user = desc.complex_storage == PFFT_INTERLEAVED_COMPLEX;
-    const strided_kernel* ka = interleaved_user ? get_strided(n1, n2, true, false) : nullptr;
-    const strided_kernel* kb = interleaved_user ? get_strided(n2, n1, false, false) : nullptr;
+    const bool user_io = in_buf != BUF_SCRATCH && out_buf != BUF_SCRATCH;
+    const strided_kernel* ka = interleaved_user ? get_strided(n1, n2, true, false)
+                                                : (user_io ? get_strided_mixed(n1, n2, 2) : nullptr);
+    const strided_kernel* kb = interleaved_user ? get_strided(n2, n1, false, false)
+                                                : (user_io ? get_strided_mixed(n2, n1, 3) : nullptr);
     const char* dbg = getenv("PFFT_DEBUG_GLOBAL");  // debugging aid: "ga" / "gb" force the generic kernel for a stage
     const bool force_generic_a = dbg != nullptr && std::strstr(dbg, "ga") != nullptr;
     const bool force_generic_b = dbg != nullptr && std::strstr(dbg, "gb") != nullptr;
     stage sa;
-    if (!force_generic_a && interleaved_user && strided_fits(ka, n2, in_buf, a_in, BUF_SCRATCH, a_out)) {
+    if (!force_generic_a && strided_fits(ka, n2, in_buf, a_in, BUF_SCRATCH, a_out)) {
       // conjugating on load and store in both stages is the identity in between, so the backward transform can use
       // the kernels' BWD form on both
       sa = make_strided_stage(ka, count * n2, n2, in_buf, a_in, BUF_SCRATCH, a_out, 1.0, backward);
@@ -730,7 +747,7 @@ struct plan_t {
     addressing b_in{0, 1, n2, n};
     addressing b_out{oa.offset, n1, 1, n};
     stage sb;
-    if (!force_generic_b && interleaved_user && strided_fits(kb, n1, BUF_SCRATCH, b_in, out_buf, b_out)) {
+    if (!force_generic_b && strided_fits(kb, n1, BUF_SCRATCH, b_in, out_buf, b_out)) {
       sb = make_strided_stage(kb, count * n1, n1, BUF_SCRATCH, b_in, out_buf, b_out, scale, backward);
     } else {
       sb = make_generic_stage(n2, count * n1, n1, BUF_SCRATCH, b_in, out_buf, b_out, scale, backward, backward);
@@ -873,7 +890,19 @@ struct plan_t {
       a.total = count;
       const long long groups = strided_groups(count, a.inner, s.strided->fpw);
       const unsigned grid = static_cast<unsigned>(std::min<long long>(s.grid, std::max<long long>(groups, 1)));
-      if (split && s.in_buf != BUF_SCRATCH) {  // strided_fits: then the output is a user buffer too
+      if (split && (s.in_buf == BUF_SCRATCH) != (s.out_buf == BUF_SCRATCH)) {  // mixed storage (four-step stages)
+        const bool in_user = s.in_buf != BUF_SCRATCH;
+        const size_t iu = in_user ? sb : elem_bytes(), ou = in_user ? elem_bytes() : sb;
+        const size_t io = static_cast<size_t>(s.in_addr.offset + in_shift) * iu;
+        const size_t oo = static_cast<size_t>(s.out_addr.offset + out_shift) * ou;
+        a.in = base_re(s.in_buf, true) + io;
+        a.in_im = in_user ? base_im(s.in_buf) + io : nullptr;
+        a.out = const_cast<char*>(base_re(s.out_buf, false)) + oo;
+        a.out_im = in_user ? nullptr : const_cast<char*>(base_im(s.out_buf)) + oo;
+        hip_check(jit_launch_strided_mixed(s.strided, stream, grid, a, s.backward, in_user ? 2 : 3), "kernel launch");
+        return;
+      }
+      if (split && s.in_buf != BUF_SCRATCH) {  // both sides are user buffers
         const size_t io = static_cast<size_t>(s.in_addr.offset + in_shift) * sb;
         const size_t oo = static_cast<size_t>(s.out_addr.offset + out_shift) * sb;
         a.in = base_re(s.in_buf, true) + io;

@@ -18,20 +18,27 @@
 
 namespace pfa {
 
+/// Storage of the two sides of a strided stage: SPLIT is 0 (both interleaved), 1 (both split: real + imaginary
+/// plane), 2 (split input, interleaved output) or 3 (interleaved input, split output) -- the mixed forms connect
+/// SPLIT_COMPLEX user buffers to the interleaved scratch of the four-step tier.
+constexpr bool split_in(int mode) { return mode == 1 || mode == 2; }
+constexpr bool split_out(int mode) { return mode == 1 || mode == 3; }
+
 /// The descriptors of one group: interleaved (one per side) or split (real + imaginary plane per side).
-template <typename T, int AUX, bool SPLIT>
+template <typename T, int AUX, int SPLIT>
 struct strided_io {
-  static constexpr unsigned ES = SPLIT ? sizeof(T) : sizeof(cx<T>);
+  static constexpr unsigned ES_IN = split_in(SPLIT) ? sizeof(T) : sizeof(cx<T>);
+  static constexpr unsigned ES_OUT = split_out(SPLIT) ? sizeof(T) : sizeof(cx<T>);
   __amdgpu_buffer_rsrc_t rin, rout, rin_im, rout_im;
   PFA_DEV cx<T> load(unsigned voff, unsigned soff) const {
-    if constexpr (SPLIT) {
+    if constexpr (split_in(SPLIT)) {
       return {buf_load_scalar<T, AUX>(rin, voff, soff), buf_load_scalar<T, AUX>(rin_im, voff, soff)};
     } else {
       return buf_load<T, AUX>(rin, voff, soff);
     }
   }
   PFA_DEV void store(cx<T> v, unsigned voff, unsigned soff) const {
-    if constexpr (SPLIT) {
+    if constexpr (split_out(SPLIT)) {
       buf_store_scalar<T, AUX>(v.re, rout, voff, soff);
       buf_store_scalar<T, AUX>(v.im, rout_im, voff, soff);
     } else {
@@ -63,7 +70,7 @@ PFA_DEV void strided_pass(const IO& io, const strided_args& a, unsigned f,
   constexpr bool first = P == 0 && !ROW_IN;   // reads HBM directly
   constexpr bool last = P == Cfg::NP - 1 && !ROW_OUT;  // writes HBM directly
   constexpr int FPW = strided_pitch<Cfg, ROW_IN || ROW_OUT>();
-  constexpr unsigned ES = IO::ES;
+  constexpr unsigned ES_IN = IO::ES_IN, ES_OUT = IO::ES_OUT;
 
   cx<T> v[BPT][R];
   sfor<0, BPT>([&](auto i_) PFA_LAMBDA {
@@ -74,10 +81,10 @@ PFA_DEV void strided_pass(const IO& io, const strided_args& a, unsigned f,
         // dead lanes (FFT beyond the end) get an out-of-range offset: the buffer range check returns zeros
         const unsigned tsh = static_cast<unsigned>(a.in_tile_shift);
         const unsigned voff =
-            live ? (f * a.in_fdist + (j >> tsh) * a.in_stride + (j & ((1u << tsh) - 1u))) * ES : 0xFFFFFFF0u;
+            live ? (f * a.in_fdist + (j >> tsh) * a.in_stride + (j & ((1u << tsh) - 1u))) * ES_IN : 0xFFFFFFF0u;
         sfor<0, R>([&](auto t_) PFA_LAMBDA {
           constexpr int t = decltype(t_)::value;
-          cx<T> x = io.load(voff, (static_cast<unsigned>(t * NB) >> tsh) * a.in_stride * ES);
+          cx<T> x = io.load(voff, (static_cast<unsigned>(t * NB) >> tsh) * a.in_stride * ES_IN);
           if constexpr (BWD) x.im = -x.im;
           v[i][t] = x;
         });
@@ -108,7 +115,8 @@ PFA_DEV void strided_pass(const IO& io, const strided_args& a, unsigned f,
       if constexpr (last) {
         const unsigned osh = static_cast<unsigned>(a.out_tile_shift);
         const unsigned voff =
-            live ? (f * a.out_fdist + (base >> osh) * a.out_stride + (base & ((1u << osh) - 1u))) * ES : 0xFFFFFFF0u;
+            live ? (f * a.out_fdist + (base >> osh) * a.out_stride + (base & ((1u << osh) - 1u))) * ES_OUT
+                 : 0xFFFFFFF0u;
         const T scale = static_cast<T>(a.scale);
         // store modifier W_M^{k*c}, k = base + u*Ns: W^{base*c} and the step W^{Ns*c} come from the hi/lo tables
         // (4 loads per butterfly instead of 2 per output), the powers of the step by squaring / one multiply
@@ -143,7 +151,7 @@ PFA_DEV void strided_pass(const IO& io, const strided_args& a, unsigned f,
           if constexpr (BWD) y.im = -y.im;
           y.re *= scale;
           y.im *= scale;
-          io.store(y, voff, (static_cast<unsigned>(u * Ns) >> osh) * a.out_stride * ES);
+          io.store(y, voff, (static_cast<unsigned>(u * Ns) >> osh) * a.out_stride * ES_OUT);
         });
       } else {
         cx<T>* p = lds + base * FPW + f;
@@ -174,7 +182,7 @@ PFA_DEV void strided_pass0_load(const IO& io, const strided_args& a, unsigned f,
   constexpr int R = Cfg::Seq::r[0];
   constexpr int NB = Cfg::N / R;
   constexpr bool ragged = (NB % Cfg::TPF) != 0;
-  constexpr unsigned ES = IO::ES;
+  constexpr unsigned ES = IO::ES_IN;
   sfor<0, Cfg::bpt(0)>([&](auto i_) PFA_LAMBDA {
     constexpr int i = decltype(i_)::value;
     const unsigned j = tid + i * Cfg::TPF;
@@ -221,13 +229,13 @@ PFA_DEV long long strided_ngroups(const strided_args& a) {
   return ((a.total + a.inner - 1) / a.inner) * per_outer;
 }
 
-template <typename Cfg, bool SPLIT>
+template <typename Cfg, int SPLIT>
 PFA_DEV strided_io<typename Cfg::T, Cfg::AUX, SPLIT> strided_group(const strided_args& a, long long g, unsigned f,
                                                                    bool* live, long long* c0_out,
                                                                    long long* nlive_out = nullptr) {
   using T = typename Cfg::T;
   using IO = strided_io<T, Cfg::AUX, SPLIT>;
-  constexpr unsigned ES = IO::ES;
+  constexpr unsigned ES_IN = IO::ES_IN, ES_OUT = IO::ES_OUT;
   const long long per_outer = (a.inner + Cfg::FPW - 1) / Cfg::FPW;
   const long long o = g / per_outer;
   const long long c0 = (g - o * per_outer) * Cfg::FPW;
@@ -241,22 +249,25 @@ PFA_DEV strided_io<typename Cfg::T, Cfg::AUX, SPLIT> strided_group(const strided
   // ranges: last element of the last FFT of the group (the planner guarantees < 4 GiB)
   const unsigned in_bytes = (static_cast<unsigned>(Cfg::FPW - 1) * a.in_fdist +
                              (static_cast<unsigned>(Cfg::N - 1) >> a.in_tile_shift) * a.in_stride +
-                             (1u << a.in_tile_shift)) * ES;
+                             (1u << a.in_tile_shift)) * ES_IN;
   const unsigned out_bytes = (static_cast<unsigned>(Cfg::FPW - 1) * a.out_fdist +
                               (static_cast<unsigned>(Cfg::N - 1) >> a.out_tile_shift) * a.out_stride +
-                              (1u << a.out_tile_shift)) * ES;
+                              (1u << a.out_tile_shift)) * ES_OUT;
   IO io;
-  char* ip = const_cast<char*>(static_cast<const char*>(a.in)) + ioff * ES;
-  char* op = static_cast<char*>(a.out) + ooff * ES;
+  char* ip = const_cast<char*>(static_cast<const char*>(a.in)) + ioff * ES_IN;
+  char* op = static_cast<char*>(a.out) + ooff * ES_OUT;
   io.rin = __builtin_amdgcn_make_buffer_rsrc(ip, 0, in_bytes, 0x00020000);
   io.rout = __builtin_amdgcn_make_buffer_rsrc(op, 0, out_bytes, 0x00020000);
-  if constexpr (SPLIT) {
-    char* ipi = const_cast<char*>(static_cast<const char*>(a.in_im)) + ioff * ES;
-    char* opi = static_cast<char*>(a.out_im) + ooff * ES;
+  if constexpr (split_in(SPLIT)) {
+    char* ipi = const_cast<char*>(static_cast<const char*>(a.in_im)) + ioff * ES_IN;
     io.rin_im = __builtin_amdgcn_make_buffer_rsrc(ipi, 0, in_bytes, 0x00020000);
-    io.rout_im = __builtin_amdgcn_make_buffer_rsrc(opi, 0, out_bytes, 0x00020000);
   } else {
     io.rin_im = io.rin;
+  }
+  if constexpr (split_out(SPLIT)) {
+    char* opi = static_cast<char*>(a.out_im) + ooff * ES_OUT;
+    io.rout_im = __builtin_amdgcn_make_buffer_rsrc(opi, 0, out_bytes, 0x00020000);
+  } else {
     io.rout_im = io.rout;
   }
   return io;
@@ -264,7 +275,7 @@ PFA_DEV strided_io<typename Cfg::T, Cfg::AUX, SPLIT> strided_group(const strided
 
 /// Software-pipelined strided kernel: the loads of the work-group's next group are in flight during the LDS passes
 /// of the current one (see stockham_wg_prefetch_kernel).
-template <typename Cfg, bool BWD, bool STW, bool SPLIT = false>
+template <typename Cfg, bool BWD, bool STW, int SPLIT = 0>
 __global__ __launch_bounds__(Cfg::WG, Cfg::OCC) void stockham_strided_prefetch_kernel(const strided_args a) {
   using T = typename Cfg::T;
   static_assert(Cfg::NP >= 2, "the strided tier needs at least two passes (LDS exchange)");
@@ -320,7 +331,7 @@ __global__ __launch_bounds__(Cfg::WG, Cfg::OCC) void stockham_strided_row_kernel
     bool live;
     long long c0;
     long long left;
-    const auto io = strided_group<Cfg, false>(a, g, f, &live, &c0, &left);
+    const auto io = strided_group<Cfg, 0>(a, g, f, &live, &c0, &left);
     if constexpr (ROW_IN) {
       sfor<0, EPT>([&](auto k_) PFA_LAMBDA {
         constexpr int k = decltype(k_)::value;
@@ -368,7 +379,7 @@ constexpr size_t strided_lds_bytes() {
   return Cfg::NP > 1 ? size_t(Cfg::N) * Cfg::FPW * sizeof(cx<typename Cfg::T>) : 0;
 }
 
-template <typename Cfg, bool BWD, bool STW, bool SPLIT = false>
+template <typename Cfg, bool BWD, bool STW, int SPLIT = 0>
 __global__ __launch_bounds__(Cfg::WG, Cfg::OCC) void stockham_strided_kernel(const strided_args a) {
   using T = typename Cfg::T;
   // (a single-pass plan -- one lane per FFT, the reference's WORKITEM tier on strided data -- uses no LDS at all)
