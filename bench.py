@@ -69,7 +69,16 @@ def cpu_baseline(sample_seconds=12.0):
         total += run(batch)
         reps += 1
     gflops = 5.0 * N * math.log2(N) * batch * reps / total / 1e9
+    # sanity row: NumPy's pocketfft on one core, same transform, ~1 s
+    xs = (rng.uniform(-1, 1, (256, N)) + 1j * rng.uniform(-1, 1, (256, N))).astype(np.complex64)
+    np.fft.fft(xs)
+    t0, nrep = time.perf_counter(), 0
+    while time.perf_counter() - t0 < 1.0:
+        np.fft.fft(xs)
+        nrep += 1
+    numpy_gflops = 5.0 * N * math.log2(N) * 256 * nrep / (time.perf_counter() - t0) / 1e9
     return {"value": round(gflops, 3), "unit": "GFLOP/s", "cores": cores, "kind": "port",
+            "numpy_1core_gflops": round(numpy_gflops, 3),
             "sample": "oracle/ (reference algorithm restated in C, OpenMP over transforms), fp32 C2C forward N=%d, "
                       "batch=%d of the 65536 x %d passes, %.1f s" % (N, batch, reps, total)}
 

@@ -12,6 +12,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <memory>
@@ -272,7 +273,9 @@ struct plan_t {
     const strided_kernel* k = find_strided(n);
     if (k != nullptr) return k;
     std::string why;
-    return jit_strided_kernel(desc.precision, n, inner_count, store_modifier, user_split ? 1 : 0, max_lds, &why);
+    k = jit_strided_kernel(desc.precision, n, inner_count, store_modifier, user_split ? 1 : 0, max_lds, &why);
+    if (k == nullptr) jit_note("strided", n, why);
+    return k;
   }
 
   /// four-step stages on SPLIT_COMPLEX data: split user side, interleaved scratch side (runtime-specialised only)
@@ -281,11 +284,21 @@ struct plan_t {
     return jit_strided_kernel(desc.precision, n, inner_count, split_mode == 2, split_mode, max_lds, &why);
   }
 
+  /// PFFT_JIT_VERBOSE: say why a configuration stayed on the slower tier
+  static void jit_note(const char* what, long long n, const std::string& why) {
+    const char* e = getenv("PFFT_JIT_VERBOSE");
+    if (e != nullptr && e[0] != '\0' && e[0] != '0' && !why.empty()) {
+      std::fprintf(stderr, "[portfft_amd jit] %s n=%lld not specialised: %s\n", what, n, why.c_str());
+    }
+  }
+
   /// the pre-compiled packed kernel, otherwise a runtime-specialised one
   const spec_kernel* get_spec(long long n) {
     if (const spec_kernel* k = find_spec(n)) return k;
     std::string why;
-    return jit_spec_kernel(desc.precision, n, desc.complex_storage == PFFT_SPLIT_COMPLEX, max_lds, &why);
+    const spec_kernel* k = jit_spec_kernel(desc.precision, n, desc.complex_storage == PFFT_SPLIT_COMPLEX, max_lds, &why);
+    if (k == nullptr) jit_note("packed", n, why);
+    return k;
   }
 
   /// work-group loop trips of a strided stage (stockham_strided.hpp: strided_ngroups)
