@@ -40,7 +40,7 @@ struct nd_cfg {
   static constexpr int PADW = PADW_;
   static constexpr int OCC = OCC_;
   static constexpr int AUX = AUX_;
-  static constexpr int pad(int i) { return PADS_ == 0 ? i : i + ((i >> PADS_) * PADW_); }
+  static constexpr int pad(int i) { return PADS_ == 0 ? i : i + ((i / PADS_) * PADW_); }
   static constexpr int LDS_PER_FFT = pad(N - 1) + 1 + (PADS_ == 0 ? 0 : PADW_);
   static constexpr size_t LDS_BYTES = size_t(LDS_PER_FFT) * FPW_ * sizeof(cx<T_>);
   template <typename F>

@@ -44,7 +44,10 @@ enum : int { TW_GLOBAL = 0, TW_REGS = 1 };
 ///  Seq     radix_list<...>
 ///  WG      threads per work-group
 ///  FPW     FFTs processed concurrently by one work-group (threads per FFT = WG / FPW)
-///  PADS    LDS padding: one extra PADW complex elements every 2^PADS elements (PADS = 0 disables)
+///  PADS    LDS padding period: PADW extra complex elements after every PADS elements (0 disables).  A period equal
+///          to the first radix turns the pass-0 scatter (lane stride R0 elements, a multiple of many banks when R0
+///          is even) into a stride of R0 + PADW, and -- every later butterfly stride being a multiple of R0 -- keeps
+///          all LDS addresses of a butterfly linear in its index (one address VGPR + immediates).
 ///  TWM     TW_GLOBAL: twiddles re-read from the table (L1/L2 resident) at every use
 ///          TW_REGS  : twiddles loaded once per work-group lifetime into VGPRs
 ///  OCC     waves per SIMD to keep resident (bounds the VGPR budget: 512 / OCC)
@@ -68,7 +71,7 @@ struct wg_cfg {
   static constexpr int AUX = AUX_;  // cache-policy bits of the HBM accesses (0 default, 2 = nt streaming)
   static constexpr int STAGED = STAGED_;
   static constexpr int NP = Seq_::count;
-  static constexpr int pad(int i) { return PADS_ == 0 ? i : i + ((i >> PADS_) * PADW_); }
+  static constexpr int pad(int i) { return PADS_ == 0 ? i : i + ((i / PADS_) * PADW_); }
   static constexpr int LDS_PER_FFT = pad(N - 1) + 1 + (PADS_ == 0 ? 0 : PADW_);
   static constexpr int LDS_ELEMS = (NP > 1 || STAGED_) ? LDS_PER_FFT * FPW_ : 0;
   static constexpr size_t LDS_BYTES = size_t(LDS_ELEMS) * sizeof(cx<T_>);
@@ -87,7 +90,7 @@ PFA_DEV int lds_pad(int i) {
   if constexpr (Cfg::PADS == 0) {
     return i;
   } else {
-    return i + ((i >> Cfg::PADS) * Cfg::PADW);
+    return i + ((i / Cfg::PADS) * Cfg::PADW);
   }
 }
 
@@ -97,15 +100,15 @@ PFA_DEV int lds_pad(int i) {
 template <typename Cfg>
 constexpr bool pad_is_linear(int unit, int count, int a_multiple_of) {
   if (Cfg::PADS == 0) return true;
-  const int period = 1 << Cfg::PADS;
+  const int period = Cfg::PADS;
   if (unit % period == 0) return true;
   return (a_multiple_of % period == 0) && (unit * (count - 1) < period);
 }
 template <typename Cfg>
 constexpr int pad_step(int unit) {
   if (Cfg::PADS == 0) return unit;
-  const int period = 1 << Cfg::PADS;
-  return unit % period == 0 ? unit + (unit >> Cfg::PADS) * Cfg::PADW : unit;
+  const int period = Cfg::PADS;
+  return unit % period == 0 ? unit + (unit / Cfg::PADS) * Cfg::PADW : unit;
 }
 
 /// Raw 16- or 8-byte buffer access: one 32-bit lane offset VGPR (voff) serves every access of a butterfly, the

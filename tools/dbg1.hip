@@ -48,10 +48,10 @@ template <typename Cfg> void run(const char* name, long long batch, int grid) {
 int main() {
   run<wg_cfg<float, radix_list<16>, 64, 64, 0, 0, TW_GLOBAL, 1>>("r16 single", 130, 2);
   run<wg_cfg<float, radix_list<16, 16>, 64, 4, 0, 0, TW_GLOBAL, 1>>("r16x2 fpw4 nopad", 7, 1);
-  run<wg_cfg<float, radix_list<16, 16>, 64, 4, 4, 1, TW_REGS, 1>>("r16x2 fpw4 pad twR", 7, 1);
+  run<wg_cfg<float, radix_list<16, 16>, 64, 4, 16, 1, TW_REGS, 1>>("r16x2 fpw4 pad twR", 7, 1);
   run<wg_cfg<float, radix_list<16, 16, 16>, 256, 1, 0, 0, TW_GLOBAL, 1>>("r16x3 nopad", 3, 2);
-  run<wg_cfg<float, radix_list<16, 16, 16>, 256, 1, 4, 1, TW_REGS, 4>>("r16x3 pad16 twR", 3, 2);
-  run<wg_cfg<float, radix_list<8, 8, 8, 8>, 512, 1, 4, 1, TW_GLOBAL, 1>>("r8x4", 3, 2);
+  run<wg_cfg<float, radix_list<16, 16, 16>, 256, 1, 16, 1, TW_REGS, 4>>("r16x3 pad16 twR", 3, 2);
+  run<wg_cfg<float, radix_list<8, 8, 8, 8>, 512, 1, 16, 1, TW_GLOBAL, 1>>("r8x4", 3, 2);
   run<wg_cfg<float, radix_list<4, 3, 5>, 64, 4, 0, 0, TW_GLOBAL, 1>>("r4.3.5 N=60", 9, 2);
   run<wg_cfg<double, radix_list<16, 8>, 64, 2, 0, 0, TW_GLOBAL, 1>>("f64 r16.8", 5, 2);
   return 0;

@@ -205,17 +205,17 @@ int main(int argc, char** argv) {
 
   // ---- FFT variants: interleaved rounds, medians ----
   using S16 = radix_list<16, 16, 16>;
-  using CfgR = wg_cfg<float, S16, 256, 1, 4, 1, TW_REGS, 4, 2>;
-  using CfgG = wg_cfg<float, S16, 256, 1, 4, 1, TW_GLOBAL, 4, 2>;
+  using CfgR = wg_cfg<float, S16, 256, 1, 16, 1, TW_REGS, 4, 2>;
+  using CfgG = wg_cfg<float, S16, 256, 1, 16, 1, TW_GLOBAL, 4, 2>;
   auto tw = make_twiddles<S16, float>();
   cx<float>* d_tw;
   CK(hipMalloc(&d_tw, tw.size() * sizeof(cx<float>)));
   CK(hipMemcpy(d_tw, tw.data(), tw.size() * sizeof(cx<float>), hipMemcpyHostToDevice));
   auto kr = stockham_wg_kernel<CfgR, false>;
 #ifdef PF_TWR
-  using CfgP = wg_cfg<float, S16, 256, 1, 4, 1, TW_REGS, 3, 2>;
+  using CfgP = wg_cfg<float, S16, 256, 1, 16, 1, TW_REGS, 3, 2>;
 #else
-  using CfgP = wg_cfg<float, S16, 256, 1, 4, 1, TW_GLOBAL, 4, 2>;
+  using CfgP = wg_cfg<float, S16, 256, 1, 16, 1, TW_GLOBAL, 4, 2>;
 #endif
   auto kg = stockham_wg_prefetch_kernel<CfgP, false>;
   CK(hipFuncSetAttribute((const void*)kr, hipFuncAttributeMaxDynamicSharedMemorySize, (int)CfgR::LDS_BYTES));

@@ -54,93 +54,93 @@ int main() {
   constexpr int NT = 2;
 #if TUNE_CASE == 2048
   using S = radix_list<16, 16, 8>; using T = f; const int N = 2048;
-  add<wg_cfg<f, S, 256, 2, 4, 1, TW_GLOBAL, 4, NT>, false>("twG fpw2 o4");
-  add<wg_cfg<f, S, 256, 2, 4, 1, TW_REGS, 4, NT>, false>("twR fpw2 o4");
-  add<wg_cfg<f, S, 256, 2, 4, 1, TW_REGS, 3, NT>, true>("twR fpw2 o3 PF");
-  add<wg_cfg<f, S, 256, 2, 4, 1, TW_GLOBAL, 4, NT>, true>("twG fpw2 o4 PF");
-  add<wg_cfg<f, S, 128, 1, 4, 1, TW_REGS, 4, NT>, false>("twR wg128 fpw1 o4");
-  add<wg_cfg<f, S, 128, 1, 4, 1, TW_REGS, 3, NT>, true>("twR wg128 fpw1 o3 PF");
+  add<wg_cfg<f, S, 256, 2, 16, 1, TW_GLOBAL, 4, NT>, false>("twG fpw2 o4");
+  add<wg_cfg<f, S, 256, 2, 16, 1, TW_REGS, 4, NT>, false>("twR fpw2 o4");
+  add<wg_cfg<f, S, 256, 2, 16, 1, TW_REGS, 3, NT>, true>("twR fpw2 o3 PF");
+  add<wg_cfg<f, S, 256, 2, 16, 1, TW_GLOBAL, 4, NT>, true>("twG fpw2 o4 PF");
+  add<wg_cfg<f, S, 128, 1, 16, 1, TW_REGS, 4, NT>, false>("twR wg128 fpw1 o4");
+  add<wg_cfg<f, S, 128, 1, 16, 1, TW_REGS, 3, NT>, true>("twR wg128 fpw1 o3 PF");
 #elif TUNE_CASE == 1024
   using S = radix_list<16, 8, 8>; using T = f; const int N = 1024;
-  add<wg_cfg<f, S, 256, 4, 4, 1, TW_GLOBAL, 4, NT>, false>("twG fpw4 o4");
-  add<wg_cfg<f, S, 256, 4, 4, 1, TW_REGS, 4, NT>, false>("twR fpw4 o4");
-  add<wg_cfg<f, S, 256, 4, 4, 1, TW_REGS, 3, NT>, true>("twR fpw4 o3 PF");
-  add<wg_cfg<f, radix_list<32, 32>, 256, 8, 5, 1, TW_REGS, 2, NT>, false>("r32x32 twR fpw8 o2");
-  add<wg_cfg<f, radix_list<32, 32>, 256, 8, 5, 1, TW_GLOBAL, 2, NT>, false>("r32x32 twG fpw8 o2");
-  add<wg_cfg<f, S, 64, 1, 4, 1, TW_REGS, 4, NT>, false>("twR wg64 fpw1 o4");
+  add<wg_cfg<f, S, 256, 4, 16, 1, TW_GLOBAL, 4, NT>, false>("twG fpw4 o4");
+  add<wg_cfg<f, S, 256, 4, 16, 1, TW_REGS, 4, NT>, false>("twR fpw4 o4");
+  add<wg_cfg<f, S, 256, 4, 16, 1, TW_REGS, 3, NT>, true>("twR fpw4 o3 PF");
+  add<wg_cfg<f, radix_list<32, 32>, 256, 8, 32, 1, TW_REGS, 2, NT>, false>("r32x32 twR fpw8 o2");
+  add<wg_cfg<f, radix_list<32, 32>, 256, 8, 32, 1, TW_GLOBAL, 2, NT>, false>("r32x32 twG fpw8 o2");
+  add<wg_cfg<f, S, 64, 1, 16, 1, TW_REGS, 4, NT>, false>("twR wg64 fpw1 o4");
 #elif TUNE_CASE == 8192
   using S = radix_list<32, 16, 16>; using T = f; const int N = 8192;
-  add<wg_cfg<f, S, 256, 1, 4, 1, TW_GLOBAL, 2, NT>, false>("r32.16.16 twG wg256 o2");
-  add<wg_cfg<f, S, 256, 1, 4, 1, TW_REGS, 2, NT>, false>("r32.16.16 twR wg256 o2");
-  add<wg_cfg<f, radix_list<16, 16, 32>, 256, 1, 4, 1, TW_GLOBAL, 2, NT>, false>("r16.16.32 twG wg256 o2");
-  add<wg_cfg<f, radix_list<16, 16, 16, 2>, 512, 1, 4, 1, TW_GLOBAL, 4, NT>, false>("r16.16.16.2 twG wg512 o4");
-  add<wg_cfg<f, radix_list<8, 8, 8, 16>, 512, 1, 4, 1, TW_GLOBAL, 4, NT>, false>("r8.8.8.16 twG wg512 o4");
-  add<wg_cfg<f, radix_list<16, 8, 8, 8>, 512, 1, 4, 1, TW_GLOBAL, 4, NT>, false>("r16.8.8.8 twG wg512 o4");
+  add<wg_cfg<f, S, 256, 1, 16, 1, TW_GLOBAL, 2, NT>, false>("r32.16.16 twG wg256 o2");
+  add<wg_cfg<f, S, 256, 1, 16, 1, TW_REGS, 2, NT>, false>("r32.16.16 twR wg256 o2");
+  add<wg_cfg<f, radix_list<16, 16, 32>, 256, 1, 16, 1, TW_GLOBAL, 2, NT>, false>("r16.16.32 twG wg256 o2");
+  add<wg_cfg<f, radix_list<16, 16, 16, 2>, 512, 1, 16, 1, TW_GLOBAL, 4, NT>, false>("r16.16.16.2 twG wg512 o4");
+  add<wg_cfg<f, radix_list<8, 8, 8, 16>, 512, 1, 16, 1, TW_GLOBAL, 4, NT>, false>("r8.8.8.16 twG wg512 o4");
+  add<wg_cfg<f, radix_list<16, 8, 8, 8>, 512, 1, 16, 1, TW_GLOBAL, 4, NT>, false>("r16.8.8.8 twG wg512 o4");
 #elif TUNE_CASE == 16384
   using S = radix_list<32, 32, 16>; using T = f; const int N = 16384;
-  add<wg_cfg<f, S, 512, 1, 4, 1, TW_GLOBAL, 2, NT>, false>("r32.32.16 twG wg512 o2");
-  add<wg_cfg<f, radix_list<16, 16, 8, 8>, 1024, 1, 4, 1, TW_GLOBAL, 4, NT>, false>("r16.16.8.8 twG wg1024 o4");
-  add<wg_cfg<f, radix_list<16, 16, 16, 4>, 1024, 1, 4, 1, TW_GLOBAL, 4, NT>, false>("r16.16.16.4 twG wg1024 o4");
+  add<wg_cfg<f, S, 512, 1, 16, 1, TW_GLOBAL, 2, NT>, false>("r32.32.16 twG wg512 o2");
+  add<wg_cfg<f, radix_list<16, 16, 8, 8>, 1024, 1, 16, 1, TW_GLOBAL, 4, NT>, false>("r16.16.8.8 twG wg1024 o4");
+  add<wg_cfg<f, radix_list<16, 16, 16, 4>, 1024, 1, 16, 1, TW_GLOBAL, 4, NT>, false>("r16.16.16.4 twG wg1024 o4");
   add<wg_cfg<f, radix_list<32, 32, 16>, 512, 1, 0, 0, TW_GLOBAL, 2, NT>, false>("r32.32.16 twG wg512 nopad");
 #elif TUNE_CASE == 4096064
   using S = radix_list<16, 16, 16>; using T = d; const int N = 4096;
-  add<wg_cfg<d, S, 256, 1, 4, 1, TW_GLOBAL, 2, NT>, false>("f64 twG o2");
-  add<wg_cfg<d, S, 256, 1, 4, 1, TW_GLOBAL, 1, NT>, true>("f64 twG o1 PF");
-  add<wg_cfg<d, S, 256, 1, 4, 1, TW_REGS, 1, NT>, false>("f64 twR o1");
-  add<wg_cfg<d, radix_list<8, 8, 8, 8>, 512, 1, 4, 1, TW_GLOBAL, 2, NT>, false>("f64 r8x4 wg512 o2");
+  add<wg_cfg<d, S, 256, 1, 16, 1, TW_GLOBAL, 2, NT>, false>("f64 twG o2");
+  add<wg_cfg<d, S, 256, 1, 16, 1, TW_GLOBAL, 1, NT>, true>("f64 twG o1 PF");
+  add<wg_cfg<d, S, 256, 1, 16, 1, TW_REGS, 1, NT>, false>("f64 twR o1");
+  add<wg_cfg<d, radix_list<8, 8, 8, 8>, 512, 1, 16, 1, TW_GLOBAL, 2, NT>, false>("f64 r8x4 wg512 o2");
 #elif TUNE_CASE == 16385
   using S = radix_list<32, 32, 16>; using T = f; const int N = 16384;
   add<wg_cfg<f, S, 512, 1, 0, 0, TW_GLOBAL, 2, NT>, false>("r32.32.16 twG wg512 nopad");
   add<wg_cfg<f, S, 512, 1, 0, 0, TW_REGS, 2, NT>, false>("r32.32.16 twR wg512 nopad");
-  add<wg_cfg<f, S, 512, 1, 4, 1, TW_REGS, 2, NT>, false>("r32.32.16 twR wg512 pad");
+  add<wg_cfg<f, S, 512, 1, 16, 1, TW_REGS, 2, NT>, false>("r32.32.16 twR wg512 pad");
   add<wg_cfg<f, radix_list<32, 16, 32>, 512, 1, 0, 0, TW_REGS, 2, NT>, false>("r32.16.32 twR wg512 nopad");
 #elif TUNE_CASE == 1024064
   using S = radix_list<16, 8, 8>; using T = d; const int N = 1024;
-  add<wg_cfg<d, S, 256, 4, 4, 1, TW_GLOBAL, 2, NT>, false>("f64 1024 twG fpw4 o2");
-  add<wg_cfg<d, S, 256, 4, 4, 1, TW_REGS, 2, NT>, false>("f64 1024 twR fpw4 o2");
-  add<wg_cfg<d, S, 64, 1, 4, 1, TW_REGS, 2, NT>, false>("f64 1024 twR wg64 fpw1 o2");
-  add<wg_cfg<d, S, 128, 2, 4, 1, TW_REGS, 2, NT>, false>("f64 1024 twR wg128 fpw2 o2");
+  add<wg_cfg<d, S, 256, 4, 16, 1, TW_GLOBAL, 2, NT>, false>("f64 1024 twG fpw4 o2");
+  add<wg_cfg<d, S, 256, 4, 16, 1, TW_REGS, 2, NT>, false>("f64 1024 twR fpw4 o2");
+  add<wg_cfg<d, S, 64, 1, 16, 1, TW_REGS, 2, NT>, false>("f64 1024 twR wg64 fpw1 o2");
+  add<wg_cfg<d, S, 128, 2, 16, 1, TW_REGS, 2, NT>, false>("f64 1024 twR wg128 fpw2 o2");
 #elif TUNE_CASE == 2048064
   using S = radix_list<16, 16, 8>; using T = d; const int N = 2048;
-  add<wg_cfg<d, S, 256, 2, 4, 1, TW_GLOBAL, 2, NT>, false>("f64 2048 twG fpw2 o2");
-  add<wg_cfg<d, S, 256, 2, 4, 1, TW_REGS, 2, NT>, false>("f64 2048 twR fpw2 o2");
-  add<wg_cfg<d, S, 128, 1, 4, 1, TW_REGS, 2, NT>, false>("f64 2048 twR wg128 fpw1 o2");
+  add<wg_cfg<d, S, 256, 2, 16, 1, TW_GLOBAL, 2, NT>, false>("f64 2048 twG fpw2 o2");
+  add<wg_cfg<d, S, 256, 2, 16, 1, TW_REGS, 2, NT>, false>("f64 2048 twR fpw2 o2");
+  add<wg_cfg<d, S, 128, 1, 16, 1, TW_REGS, 2, NT>, false>("f64 2048 twR wg128 fpw1 o2");
 #elif TUNE_CASE == 8192064
   using S = radix_list<16, 16, 16, 2>; using T = d; const int N = 8192;
-  add<wg_cfg<d, S, 512, 1, 4, 1, TW_GLOBAL, 2, NT>, false>("f64 8192 r16.16.16.2 twG wg512");
-  add<wg_cfg<d, radix_list<32, 16, 16>, 256, 1, 4, 1, TW_GLOBAL, 1, NT>, false>("f64 8192 r32.16.16 twG wg256 o1");
+  add<wg_cfg<d, S, 512, 1, 16, 1, TW_GLOBAL, 2, NT>, false>("f64 8192 r16.16.16.2 twG wg512");
+  add<wg_cfg<d, radix_list<32, 16, 16>, 256, 1, 16, 1, TW_GLOBAL, 1, NT>, false>("f64 8192 r32.16.16 twG wg256 o1");
   add<wg_cfg<d, radix_list<32, 16, 16>, 256, 1, 0, 0, TW_GLOBAL, 1, NT>, false>("f64 8192 r32.16.16 twG wg256 nopad");
-  add<wg_cfg<d, radix_list<16, 8, 8, 8>, 512, 1, 4, 1, TW_GLOBAL, 2, NT>, false>("f64 8192 r16.8.8.8 twG wg512");
+  add<wg_cfg<d, radix_list<16, 8, 8, 8>, 512, 1, 16, 1, TW_GLOBAL, 2, NT>, false>("f64 8192 r16.8.8.8 twG wg512");
 #elif TUNE_CASE == 256
   using S = radix_list<16, 16>; using T = f; const int N = 256;
-  add<wg_cfg<f, S, 256, 16, 4, 1, TW_GLOBAL, 4, NT>, false>("256 twG fpw16 o4");
-  add<wg_cfg<f, S, 256, 16, 4, 1, TW_REGS, 4, NT>, false>("256 twR fpw16 o4");
-  add<wg_cfg<f, S, 256, 16, 4, 1, TW_GLOBAL, 4, NT, 1>, false>("256 twG fpw16 o4 STAGED");
-  add<wg_cfg<f, S, 64, 4, 4, 1, TW_REGS, 4, NT>, false>("256 twR wg64 fpw4 o4");
+  add<wg_cfg<f, S, 256, 16, 16, 1, TW_GLOBAL, 4, NT>, false>("256 twG fpw16 o4");
+  add<wg_cfg<f, S, 256, 16, 16, 1, TW_REGS, 4, NT>, false>("256 twR fpw16 o4");
+  add<wg_cfg<f, S, 256, 16, 16, 1, TW_GLOBAL, 4, NT, 1>, false>("256 twG fpw16 o4 STAGED");
+  add<wg_cfg<f, S, 64, 4, 16, 1, TW_REGS, 4, NT>, false>("256 twR wg64 fpw4 o4");
 #elif TUNE_CASE == 4096
   using S = radix_list<16, 16, 16>; using T = f; const int N = 4096;
-  add<wg_cfg<f, S, 256, 1, 4, 1, TW_REGS, 3, NT>, true>("twR o3 PF (current)");
-  add<wg_cfg<f, S, 256, 1, 4, 1, TW_REGS, 4, NT>, true>("twR o4 PF");
-  add<wg_cfg<f, S, 256, 1, 4, 1, TW_REGS, 4, NT>, false>("twR o4");
-  add<wg_cfg<f, S, 256, 1, 4, 1, TW_GLOBAL, 4, NT>, true>("twG o4 PF");
-  add<wg_cfg<f, S, 256, 1, 4, 1, TW_GLOBAL, 4, NT>, false>("twG o4");
-  add<wg_cfg<f, S, 256, 1, 4, 1, TW_GLOBAL, 5, NT>, false>("twG o5");
+  add<wg_cfg<f, S, 256, 1, 16, 1, TW_REGS, 3, NT>, true>("twR o3 PF (current)");
+  add<wg_cfg<f, S, 256, 1, 16, 1, TW_REGS, 4, NT>, true>("twR o4 PF");
+  add<wg_cfg<f, S, 256, 1, 16, 1, TW_REGS, 4, NT>, false>("twR o4");
+  add<wg_cfg<f, S, 256, 1, 16, 1, TW_GLOBAL, 4, NT>, true>("twG o4 PF");
+  add<wg_cfg<f, S, 256, 1, 16, 1, TW_GLOBAL, 4, NT>, false>("twG o4");
+  add<wg_cfg<f, S, 256, 1, 16, 1, TW_GLOBAL, 5, NT>, false>("twG o5");
 #elif TUNE_CASE == 4097
   using S = radix_list<16, 16, 16>; using T = f; const int N = 4096;
-  add<wg_cfg<f, S, 256, 1, 4, 1, TW_REGS, 3, NT>, true>("twR o3 PF (current)");
-  add<wg_cfg<f, S, 512, 2, 4, 1, TW_REGS, 3, NT>, true>("twR wg512 fpw2 o3 PF");
-  add<wg_cfg<f, S, 512, 2, 4, 1, TW_REGS, 4, NT>, false>("twR wg512 fpw2 o4");
-  add<wg_cfg<f, S, 1024, 4, 4, 1, TW_REGS, 4, NT>, false>("twR wg1024 fpw4 o4");
-  add<wg_cfg<f, S, 1024, 4, 4, 1, TW_REGS, 3, NT>, true>("twR wg1024 fpw4 o3 PF");
-  add<wg_cfg<f, S, 128, 1, 4, 1, TW_REGS, 2, NT>, false>("twR wg128 (32pt) o2");
+  add<wg_cfg<f, S, 256, 1, 16, 1, TW_REGS, 3, NT>, true>("twR o3 PF (current)");
+  add<wg_cfg<f, S, 512, 2, 16, 1, TW_REGS, 3, NT>, true>("twR wg512 fpw2 o3 PF");
+  add<wg_cfg<f, S, 512, 2, 16, 1, TW_REGS, 4, NT>, false>("twR wg512 fpw2 o4");
+  add<wg_cfg<f, S, 1024, 4, 16, 1, TW_REGS, 4, NT>, false>("twR wg1024 fpw4 o4");
+  add<wg_cfg<f, S, 1024, 4, 16, 1, TW_REGS, 3, NT>, true>("twR wg1024 fpw4 o3 PF");
+  add<wg_cfg<f, S, 128, 1, 16, 1, TW_REGS, 2, NT>, false>("twR wg128 (32pt) o2");
 #elif TUNE_CASE == 512
   using S = radix_list<8, 8, 8>; using T = f; const int N = 512;
-  add<wg_cfg<f, S, 256, 4, 4, 1, TW_GLOBAL, 4, NT>, false>("twG fpw4 o4");
-  add<wg_cfg<f, S, 256, 4, 4, 1, TW_REGS, 4, NT>, false>("twR fpw4 o4");
-  add<wg_cfg<f, S, 256, 4, 4, 1, TW_REGS, 4, NT>, true>("twR fpw4 o4 PF");
-  add<wg_cfg<f, radix_list<32, 16>, 256, 16, 4, 1, TW_GLOBAL, 2, NT>, false>("r32x16 twG fpw16 o2");
-  add<wg_cfg<f, radix_list<16, 32>, 256, 16, 4, 1, TW_GLOBAL, 2, NT>, false>("r16x32 twG fpw16 o2");
-  add<wg_cfg<f, S, 256, 4, 4, 1, TW_GLOBAL, 4, NT, 1>, false>("twG fpw4 o4 STAGED");
+  add<wg_cfg<f, S, 256, 4, 16, 1, TW_GLOBAL, 4, NT>, false>("twG fpw4 o4");
+  add<wg_cfg<f, S, 256, 4, 16, 1, TW_REGS, 4, NT>, false>("twR fpw4 o4");
+  add<wg_cfg<f, S, 256, 4, 16, 1, TW_REGS, 4, NT>, true>("twR fpw4 o4 PF");
+  add<wg_cfg<f, radix_list<32, 16>, 256, 16, 16, 1, TW_GLOBAL, 2, NT>, false>("r32x16 twG fpw16 o2");
+  add<wg_cfg<f, radix_list<16, 32>, 256, 16, 16, 1, TW_GLOBAL, 2, NT>, false>("r16x32 twG fpw16 o2");
+  add<wg_cfg<f, S, 256, 4, 16, 1, TW_GLOBAL, 4, NT, 1>, false>("twG fpw4 o4 STAGED");
 #endif
   const long long nfft = (long long)(bytes / (sizeof(cx<T>) * N));
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
