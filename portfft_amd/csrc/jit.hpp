@@ -23,7 +23,7 @@ struct wg_params {
   int precision = 0;
   int n = 0;
   std::vector<int> radices;
-  int wg = 0, fpw = 0, pads = 0, padw = 0, twm = 0, occ = 1, aux = 2, staged = 0;
+  int wg = 0, fpw = 0, pads = 0, padw = 0, twm = 0, occ = 1, aux = 2, staged = 0, twl = 0;
   /// complex elements a lane holds in its widest pass
   int regs = 0;
 };

@@ -39,7 +39,7 @@ struct spec_kernel {
   hipFunction_t mfn_split[2];
   /// the remaining wg_cfg arguments, so that other forms of the same configuration (UNPACKED layouts) can be
   /// instantiated at run time
-  int pads, padw, twm, occ, aux, staged;
+  int pads, padw, twm, occ, aux, staged, twl;
 };
 
 /// One strided work-group kernel (stockham_strided.hpp): FPW FFTs side by side, any element stride / FFT distance.

@@ -92,6 +92,7 @@ spec_kernel make_spec_entry(int groups_per_wg) {
   k.occ = Cfg::OCC;
   k.aux = Cfg::AUX;
   k.staged = Cfg::STAGED;
+  k.twl = Cfg::TWL;
   k.fn[0] = reinterpret_cast<const void*>(&stockham_wg_kernel<Cfg, false>);
   k.fn[1] = reinterpret_cast<const void*>(&stockham_wg_kernel<Cfg, true>);
   k.launch = &launch_spec<Cfg>;
