@@ -14,36 +14,36 @@ const spec_kernel g_spec_f32[] = {
     make_spec_entry<wg_cfg<f, radix_list<4>, 256, 256, 4, 1, TW_GLOBAL, 4, NT, 1>>(),          // 4
     make_spec_entry<wg_cfg<f, radix_list<8>, 256, 256, 8, 1, TW_GLOBAL, 4, NT, 1>>(),          // 8
     make_spec_entry<wg_cfg<f, radix_list<16>, 256, 256, 16, 1, TW_GLOBAL, 4, NT, 1>>(),         // 16
-    make_spec_entry<wg_cfg<f, radix_list<8, 4>, 256, 64, 8, 1, TW_GLOBAL, 4, NT, 1>>(),        // 32
-    make_spec_entry<wg_cfg<f, radix_list<8, 8>, 256, 32, 8, 1, TW_GLOBAL, 4, NT, 1>>(),        // 64
-    make_spec_entry<wg_cfg<f, radix_list<16, 8>, 256, 32, 16, 1, TW_GLOBAL, 4, NT, 1>>(),       // 128
-    make_spec_entry<wg_cfg<f, radix_list<16, 16>, 256, 16, 16, 1, TW_GLOBAL, 4, NT>>(),         // 256
+    make_spec_entry<wg_cfg_twl<f, radix_list<8, 4>, 256, 64, 8, 1, 4, NT, 1>>(),        // 32
+    make_spec_entry<wg_cfg_twl<f, radix_list<8, 8>, 256, 32, 8, 1, 4, NT, 1>>(),        // 64
+    make_spec_entry<wg_cfg_twl<f, radix_list<16, 8>, 256, 32, 16, 1, 4, NT, 1>>(),       // 128
+    make_spec_entry<wg_cfg_twl<f, radix_list<16, 16>, 256, 16, 16, 1, 4, NT>>(),         // 256
     make_spec_entry<wg_cfg<f, radix_list<8, 8, 8>, 256, 4, 16, 1, TW_REGS, 4, NT>>(2),           // 512
-    make_spec_entry<wg_cfg<f, radix_list<16, 8, 8>, 256, 4, 16, 1, TW_GLOBAL, 4, NT>>(),        // 1024
+    make_spec_entry<wg_cfg_twl<f, radix_list<16, 8, 8>, 256, 4, 16, 1, 4, NT>>(),        // 1024
     make_spec_entry<wg_cfg<f, radix_list<16, 16, 8>, 256, 2, 16, 1, TW_REGS, 4, NT>>(4),        // 2048
     // the headline shape: register-resident twiddles + software-pipelined loads (3 work-groups per CU)
     make_spec_entry_prefetch<wg_cfg<f, radix_list<16, 16, 16>, 256, 1, 16, 1, TW_REGS, 3, NT>>(4),  // 4096
     make_spec_entry<wg_cfg<f, radix_list<32, 16, 16>, 256, 1, 16, 1, TW_REGS, 2, NT>>(4),       // 8192
     make_spec_entry<wg_cfg<f, radix_list<32, 16, 32>, 512, 1, 0, 0, TW_REGS, 2, NT>>(0),       // 16384
     // 3 * 2^k and 5 * 2^k families, powers of ten
-    make_spec_entry<wg_cfg<f, radix_list<12, 8>, 256, 32, 0, 0, TW_GLOBAL, 4, NT, 1>>(),       // 96
-    make_spec_entry<wg_cfg<f, radix_list<16, 12>, 256, 16, 16, 1, TW_GLOBAL, 4, NT>>(),         // 192
-    make_spec_entry<wg_cfg<f, radix_list<8, 8, 6>, 256, 4, 16, 1, TW_GLOBAL, 4, NT>>(),         // 384
-    make_spec_entry<wg_cfg<f, radix_list<16, 8, 6>, 256, 4, 16, 1, TW_GLOBAL, 4, NT>>(),        // 768
-    make_spec_entry<wg_cfg<f, radix_list<16, 12, 8>, 256, 2, 16, 1, TW_GLOBAL, 4, NT>>(),       // 1536
-    make_spec_entry<wg_cfg<f, radix_list<16, 16, 12>, 256, 1, 16, 1, TW_GLOBAL, 4, NT>>(),      // 3072
-    make_spec_entry<wg_cfg<f, radix_list<24, 16, 16>, 256, 1, 16, 1, TW_GLOBAL, 2, NT>>(),      // 6144
-    make_spec_entry<wg_cfg<f, radix_list<32, 24, 16>, 512, 1, 16, 1, TW_GLOBAL, 2, NT>>(),      // 12288
-    make_spec_entry<wg_cfg<f, radix_list<10, 8>, 256, 32, 0, 0, TW_GLOBAL, 4, NT, 1>>(),       // 80
-    make_spec_entry<wg_cfg<f, radix_list<10, 10>, 250, 25, 0, 0, TW_GLOBAL, 4, NT, 1>>(),      // 100
-    make_spec_entry<wg_cfg<f, radix_list<16, 10>, 256, 16, 16, 1, TW_GLOBAL, 4, NT>>(),         // 160
-    make_spec_entry<wg_cfg<f, radix_list<8, 8, 5>, 256, 4, 16, 1, TW_GLOBAL, 4, NT>>(),         // 320
-    make_spec_entry<wg_cfg<f, radix_list<16, 8, 5>, 256, 4, 16, 1, TW_GLOBAL, 4, NT>>(),        // 640
-    make_spec_entry<wg_cfg<f, radix_list<16, 10, 8>, 256, 2, 16, 1, TW_GLOBAL, 4, NT>>(),       // 1280
-    make_spec_entry<wg_cfg<f, radix_list<16, 16, 10>, 256, 1, 16, 1, TW_GLOBAL, 4, NT>>(),      // 2560
-    make_spec_entry<wg_cfg<f, radix_list<20, 16, 16>, 256, 1, 16, 1, TW_GLOBAL, 2, NT>>(),      // 5120
-    make_spec_entry<wg_cfg<f, radix_list<10, 10, 10>, 200, 2, 0, 0, TW_GLOBAL, 4, NT>>(),      // 1000
-    make_spec_entry<wg_cfg<f, radix_list<10, 10, 10, 10>, 250, 1, 0, 0, TW_GLOBAL, 2, NT>>(),  // 10000
+    make_spec_entry<wg_cfg_twl<f, radix_list<12, 8>, 256, 32, 0, 0, 4, NT, 1>>(),       // 96
+    make_spec_entry<wg_cfg_twl<f, radix_list<16, 12>, 256, 16, 16, 1, 4, NT>>(),         // 192
+    make_spec_entry<wg_cfg_twl<f, radix_list<8, 8, 6>, 256, 4, 16, 1, 4, NT>>(),         // 384
+    make_spec_entry<wg_cfg_twl<f, radix_list<16, 8, 6>, 256, 4, 16, 1, 4, NT>>(),        // 768
+    make_spec_entry<wg_cfg_twl<f, radix_list<16, 12, 8>, 256, 2, 16, 1, 4, NT>>(),       // 1536
+    make_spec_entry<wg_cfg_twl<f, radix_list<16, 16, 12>, 256, 1, 16, 1, 4, NT>>(),      // 3072
+    make_spec_entry<wg_cfg_twl<f, radix_list<24, 16, 16>, 256, 1, 16, 1, 2, NT>>(),      // 6144
+    make_spec_entry<wg_cfg_twl<f, radix_list<32, 24, 16>, 512, 1, 16, 1, 2, NT>>(),      // 12288
+    make_spec_entry<wg_cfg_twl<f, radix_list<10, 8>, 256, 32, 0, 0, 4, NT, 1>>(),       // 80
+    make_spec_entry<wg_cfg_twl<f, radix_list<10, 10>, 250, 25, 0, 0, 4, NT, 1>>(),      // 100
+    make_spec_entry<wg_cfg_twl<f, radix_list<16, 10>, 256, 16, 16, 1, 4, NT>>(),         // 160
+    make_spec_entry<wg_cfg_twl<f, radix_list<8, 8, 5>, 256, 4, 16, 1, 4, NT>>(),         // 320
+    make_spec_entry<wg_cfg_twl<f, radix_list<16, 8, 5>, 256, 4, 16, 1, 4, NT>>(),        // 640
+    make_spec_entry<wg_cfg_twl<f, radix_list<16, 10, 8>, 256, 2, 16, 1, 4, NT>>(),       // 1280
+    make_spec_entry<wg_cfg_twl<f, radix_list<16, 16, 10>, 256, 1, 16, 1, 4, NT>>(),      // 2560
+    make_spec_entry<wg_cfg_twl<f, radix_list<20, 16, 16>, 256, 1, 16, 1, 2, NT>>(),      // 5120
+    make_spec_entry<wg_cfg_twl<f, radix_list<10, 10, 10>, 200, 2, 0, 0, 4, NT>>(),      // 1000
+    make_spec_entry<wg_cfg_twl<f, radix_list<10, 10, 10, 10>, 250, 1, 0, 0, 2, NT>>(),  // 10000
 };
 }  // namespace
 

@@ -11,25 +11,25 @@ const spec_kernel g_spec_f64[] = {
     make_spec_entry<wg_cfg<d, radix_list<4>, 256, 256, 4, 1, TW_GLOBAL, 2, NT, 1>>(),          // 4
     make_spec_entry<wg_cfg<d, radix_list<8>, 256, 256, 8, 1, TW_GLOBAL, 2, NT, 1>>(),          // 8
     make_spec_entry<wg_cfg<d, radix_list<16>, 256, 128, 16, 1, TW_GLOBAL, 2, NT, 1>>(),         // 16
-    make_spec_entry<wg_cfg<d, radix_list<8, 4>, 256, 64, 8, 1, TW_GLOBAL, 2, NT, 1>>(),        // 32
-    make_spec_entry<wg_cfg<d, radix_list<8, 8>, 256, 32, 8, 1, TW_GLOBAL, 2, NT, 1>>(),        // 64
-    make_spec_entry<wg_cfg<d, radix_list<16, 8>, 256, 32, 16, 1, TW_GLOBAL, 2, NT, 1>>(),       // 128
-    make_spec_entry<wg_cfg<d, radix_list<16, 16>, 256, 16, 16, 1, TW_GLOBAL, 2, NT>>(),       // 256
-    make_spec_entry<wg_cfg<d, radix_list<8, 8, 8>, 256, 4, 16, 1, TW_GLOBAL, 2, NT>>(),       // 512
-    make_spec_entry<wg_cfg<d, radix_list<16, 8, 8>, 256, 4, 16, 1, TW_GLOBAL, 2, NT>>(),      // 1024
-    make_spec_entry<wg_cfg<d, radix_list<16, 16, 8>, 256, 2, 16, 1, TW_GLOBAL, 2, NT>>(2),    // 2048
+    make_spec_entry<wg_cfg_twl<d, radix_list<8, 4>, 256, 64, 8, 1, 2, NT, 1>>(),        // 32
+    make_spec_entry<wg_cfg_twl<d, radix_list<8, 8>, 256, 32, 8, 1, 2, NT, 1>>(),        // 64
+    make_spec_entry<wg_cfg_twl<d, radix_list<16, 8>, 256, 32, 16, 1, 2, NT, 1>>(),       // 128
+    make_spec_entry<wg_cfg_twl<d, radix_list<16, 16>, 256, 16, 16, 1, 2, NT>>(),       // 256
+    make_spec_entry<wg_cfg_twl<d, radix_list<8, 8, 8>, 256, 4, 16, 1, 2, NT>>(),       // 512
+    make_spec_entry<wg_cfg_twl<d, radix_list<16, 8, 8>, 256, 4, 16, 1, 2, NT>>(),      // 1024
+    make_spec_entry<wg_cfg_twl<d, radix_list<16, 16, 8>, 256, 2, 16, 1, 2, NT>>(2),    // 2048
     make_spec_entry<wg_cfg<d, radix_list<16, 16, 16>, 256, 1, 16, 1, TW_REGS, 1, NT>>(1),      // 4096
-    make_spec_entry<wg_cfg<d, radix_list<16, 8, 8, 8>, 512, 1, 16, 1, TW_GLOBAL, 2, NT>>(1),   // 8192
-    make_spec_entry<wg_cfg<d, radix_list<12, 8>, 256, 32, 0, 0, TW_GLOBAL, 2, NT, 1>>(),       // 96
-    make_spec_entry<wg_cfg<d, radix_list<16, 12>, 256, 16, 16, 1, TW_GLOBAL, 2, NT>>(),         // 192
-    make_spec_entry<wg_cfg<d, radix_list<8, 8, 6>, 256, 4, 16, 1, TW_GLOBAL, 2, NT>>(),         // 384
-    make_spec_entry<wg_cfg<d, radix_list<16, 8, 6>, 256, 4, 16, 1, TW_GLOBAL, 2, NT>>(),        // 768
-    make_spec_entry<wg_cfg<d, radix_list<16, 12, 8>, 256, 2, 16, 1, TW_GLOBAL, 2, NT>>(),       // 1536
-    make_spec_entry<wg_cfg<d, radix_list<16, 16, 12>, 256, 1, 16, 1, TW_GLOBAL, 2, NT>>(),      // 3072
-    make_spec_entry<wg_cfg<d, radix_list<24, 16, 16>, 256, 1, 16, 1, TW_GLOBAL, 2, NT>>(),      // 6144
-    make_spec_entry<wg_cfg<d, radix_list<10, 8>, 256, 32, 0, 0, TW_GLOBAL, 2, NT, 1>>(),       // 80
-    make_spec_entry<wg_cfg<d, radix_list<10, 10>, 250, 25, 0, 0, TW_GLOBAL, 2, NT, 1>>(),      // 100
-    make_spec_entry<wg_cfg<d, radix_list<10, 10, 10>, 200, 2, 0, 0, TW_GLOBAL, 2, NT>>(),      // 1000
+    make_spec_entry<wg_cfg_twl<d, radix_list<16, 8, 8, 8>, 512, 1, 16, 1, 2, NT>>(1),   // 8192
+    make_spec_entry<wg_cfg_twl<d, radix_list<12, 8>, 256, 32, 0, 0, 2, NT, 1>>(),       // 96
+    make_spec_entry<wg_cfg_twl<d, radix_list<16, 12>, 256, 16, 16, 1, 2, NT>>(),         // 192
+    make_spec_entry<wg_cfg_twl<d, radix_list<8, 8, 6>, 256, 4, 16, 1, 2, NT>>(),         // 384
+    make_spec_entry<wg_cfg_twl<d, radix_list<16, 8, 6>, 256, 4, 16, 1, 2, NT>>(),        // 768
+    make_spec_entry<wg_cfg_twl<d, radix_list<16, 12, 8>, 256, 2, 16, 1, 2, NT>>(),       // 1536
+    make_spec_entry<wg_cfg_twl<d, radix_list<16, 16, 12>, 256, 1, 16, 1, 2, NT>>(),      // 3072
+    make_spec_entry<wg_cfg_twl<d, radix_list<24, 16, 16>, 256, 1, 16, 1, 2, NT>>(),      // 6144
+    make_spec_entry<wg_cfg_twl<d, radix_list<10, 8>, 256, 32, 0, 0, 2, NT, 1>>(),       // 80
+    make_spec_entry<wg_cfg_twl<d, radix_list<10, 10>, 250, 25, 0, 0, 2, NT, 1>>(),      // 100
+    make_spec_entry<wg_cfg_twl<d, radix_list<10, 10, 10>, 200, 2, 0, 0, 2, NT>>(),      // 1000
 };
 }  // namespace
 

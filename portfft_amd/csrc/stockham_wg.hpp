@@ -90,6 +90,29 @@ struct wg_cfg {
   static constexpr int TWR_TOTAL = twr_off(NP) > 0 ? twr_off(NP) : 1;
 };
 
+/// The TWL a kernel should use: the most leading passes whose tables fit 16 KiB of LDS without pushing the CU below
+/// 16 resident waves (or below what it had).  Same rule as the runtime planner (jit.cpp); measured in
+/// profiles/r1_notes.md.
+template <typename T, typename Seq, int WG, int FPW, int PADS, int PADW, int STAGED = 0>
+constexpr int auto_twl() {
+  using base = wg_cfg<T, Seq, WG, FPW, PADS, PADW, TW_GLOBAL, 1, 0, STAGED, 0>;
+  constexpr long long cu_lds = 160 * 1024;
+  const long long base_bytes = base::LDS_BYTES > 0 ? static_cast<long long>(base::LDS_BYTES) : 1;
+  const long long waves = (WG + 63) / 64;
+  const long long before = cu_lds / base_bytes;
+  for (int k = Seq::count - 1; k >= 1; --k) {
+    const long long extra = static_cast<long long>(Seq::tw_off(k + 1)) * static_cast<long long>(sizeof(cx<T>));
+    const long long after = cu_lds / (base_bytes + extra);
+    if (extra <= 16 * 1024 && after >= 1 && (after == before || after * waves >= 16)) return k;
+  }
+  return 0;
+}
+
+/// wg_cfg with TW_GLOBAL and the automatic TWL
+template <typename T, typename Seq, int WG, int FPW, int PADS, int PADW, int OCC, int AUX, int STAGED = 0>
+using wg_cfg_twl =
+    wg_cfg<T, Seq, WG, FPW, PADS, PADW, TW_GLOBAL, OCC, AUX, STAGED, auto_twl<T, Seq, WG, FPW, PADS, PADW, STAGED>()>;
+
 template <typename Cfg>
 PFA_DEV int lds_pad(int i) {
   if constexpr (Cfg::PADS == 0) {

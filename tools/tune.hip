@@ -125,6 +125,28 @@ int main() {
   add<wg_cfg<f, S, 256, 1, 16, 1, TW_GLOBAL, 4, NT>, true>("twG o4 PF");
   add<wg_cfg<f, S, 256, 1, 16, 1, TW_GLOBAL, 4, NT>, false>("twG o4");
   add<wg_cfg<f, S, 256, 1, 16, 1, TW_GLOBAL, 5, NT>, false>("twG o5");
+#elif TUNE_CASE == 1025
+  using S = radix_list<16, 8, 8>; using T = f; const int N = 1024;
+  add<wg_cfg<f, S, 256, 4, 16, 1, TW_GLOBAL, 4, NT>, false>("1024 twG (current)");
+  add<wg_cfg<f, S, 256, 4, 16, 1, TW_GLOBAL, 4, NT, 0, 1>, false>("1024 twG TWL1");
+  add<wg_cfg<f, S, 256, 4, 16, 1, TW_GLOBAL, 4, NT, 0, 2>, false>("1024 twG TWL2");
+  add<wg_cfg<f, S, 256, 4, 16, 1, TW_REGS, 4, NT>, false>("1024 twR");
+#elif TUNE_CASE == 3072
+  using S = radix_list<16, 16, 12>; using T = f; const int N = 3072;
+  add<wg_cfg<f, S, 256, 1, 16, 1, TW_GLOBAL, 4, NT>, false>("3072 twG (current)");
+  add<wg_cfg<f, S, 256, 1, 16, 1, TW_GLOBAL, 4, NT, 0, 1>, false>("3072 twG TWL1");
+  add<wg_cfg<f, S, 256, 1, 16, 1, TW_GLOBAL, 4, NT, 0, 2>, false>("3072 twG TWL2");
+  add<wg_cfg<f, radix_list<16, 16, 12>, 192, 1, 16, 1, TW_GLOBAL, 4, NT, 0, 1>, false>("3072 wg192 TWL1");
+#elif TUNE_CASE == 1000
+  using S = radix_list<10, 10, 10>; using T = f; const int N = 1000;
+  add<wg_cfg<f, S, 200, 2, 0, 0, TW_GLOBAL, 4, NT>, false>("1000 twG (current)");
+  add<wg_cfg<f, S, 200, 2, 0, 0, TW_GLOBAL, 4, NT, 0, 1>, false>("1000 twG TWL1");
+  add<wg_cfg<f, S, 200, 2, 0, 0, TW_GLOBAL, 4, NT, 0, 2>, false>("1000 twG TWL2");
+#elif TUNE_CASE == 1024066
+  using S = radix_list<16, 8, 8>; using T = d; const int N = 1024;
+  add<wg_cfg<d, S, 256, 4, 16, 1, TW_GLOBAL, 2, NT>, false>("f64 1024 twG (current)");
+  add<wg_cfg<d, S, 256, 4, 16, 1, TW_GLOBAL, 2, NT, 0, 1>, false>("f64 1024 TWL1");
+  add<wg_cfg<d, S, 256, 4, 16, 1, TW_GLOBAL, 2, NT, 0, 2>, false>("f64 1024 TWL2");
 #elif TUNE_CASE == 4097
   using S = radix_list<16, 16, 16>; using T = f; const int N = 4096;
   add<wg_cfg<f, S, 256, 1, 16, 1, TW_REGS, 3, NT>, true>("twR o3 PF (current)");
