@@ -6,15 +6,15 @@ namespace pfa {
 namespace {
 using f = float;
 constexpr int NT = 2;
-// strided tier: wg_cfg<T, radices, WG, FPW, 0, 0, TW_GLOBAL, OCC, AUX>; threads per FFT = WG / FPW
+// strided tier: strided_cfg<T, radices, WG, FPW, OCC, AUX> (TW_GLOBAL + automatic TWL); threads per FFT = WG / FPW
 const strided_kernel g_strided_f32[] = {
-    with_rows<wg_cfg<f, radix_list<8, 8>, 256, 32, 0, 0, TW_GLOBAL, 2, NT>>(make_strided_entry<wg_cfg<f, radix_list<8, 8>, 256, 32, 0, 0, TW_GLOBAL, 2, NT>>()),          // 64
-    with_rows<wg_cfg<f, radix_list<16, 8>, 256, 32, 0, 0, TW_GLOBAL, 2, NT>>(make_strided_entry<wg_cfg<f, radix_list<16, 8>, 256, 32, 0, 0, TW_GLOBAL, 2, NT>>()),         // 128
-    with_rows<wg_cfg<f, radix_list<16, 16>, 256, 16, 0, 0, TW_GLOBAL, 2, NT>>(make_strided_entry<wg_cfg<f, radix_list<16, 16>, 256, 16, 0, 0, TW_GLOBAL, 2, NT>>()),        // 256
-    with_rows<wg_cfg<f, radix_list<8, 8, 8>, 1024, 16, 0, 0, TW_GLOBAL, 4, NT>>(make_strided_entry<wg_cfg<f, radix_list<8, 8, 8>, 1024, 16, 0, 0, TW_GLOBAL, 4, NT>>()),      // 512
-    with_rows<wg_cfg<f, radix_list<32, 32>, 512, 16, 0, 0, TW_GLOBAL, 2, NT>>(make_strided_entry_prefetch<wg_cfg<f, radix_list<32, 32>, 512, 16, 0, 0, TW_GLOBAL, 2, NT>>(4)),  // 1024
-    with_rows<wg_cfg<f, radix_list<16, 16, 8>, 1024, 8, 0, 0, TW_GLOBAL, 4, NT>>(make_strided_entry<wg_cfg<f, radix_list<16, 16, 8>, 1024, 8, 0, 0, TW_GLOBAL, 4, NT>>()),     // 2048
-    with_rows<wg_cfg<f, radix_list<16, 16, 16>, 1024, 4, 0, 0, TW_GLOBAL, 4, NT>>(make_strided_entry<wg_cfg<f, radix_list<16, 16, 16>, 1024, 4, 0, 0, TW_GLOBAL, 4, NT>>()),    // 4096
+    with_rows<strided_cfg<f, radix_list<8, 8>, 256, 32, 2, NT>>(make_strided_entry<strided_cfg<f, radix_list<8, 8>, 256, 32, 2, NT>>()),          // 64
+    with_rows<strided_cfg<f, radix_list<16, 8>, 256, 32, 2, NT>>(make_strided_entry<strided_cfg<f, radix_list<16, 8>, 256, 32, 2, NT>>()),         // 128
+    with_rows<strided_cfg<f, radix_list<16, 16>, 256, 16, 2, NT>>(make_strided_entry<strided_cfg<f, radix_list<16, 16>, 256, 16, 2, NT>>()),        // 256
+    with_rows<strided_cfg<f, radix_list<8, 8, 8>, 1024, 16, 4, NT>>(make_strided_entry<strided_cfg<f, radix_list<8, 8, 8>, 1024, 16, 4, NT>>()),      // 512
+    with_rows<strided_cfg<f, radix_list<32, 32>, 512, 16, 2, NT>>(make_strided_entry_prefetch<strided_cfg<f, radix_list<32, 32>, 512, 16, 2, NT>>(4)),  // 1024
+    with_rows<strided_cfg<f, radix_list<16, 16, 8>, 1024, 8, 4, NT>>(make_strided_entry<strided_cfg<f, radix_list<16, 16, 8>, 1024, 8, 4, NT>>()),     // 2048
+    with_rows<strided_cfg<f, radix_list<16, 16, 16>, 1024, 4, 4, NT>>(make_strided_entry<strided_cfg<f, radix_list<16, 16, 16>, 1024, 4, 4, NT>>()),    // 4096
 };
 }  // namespace
 

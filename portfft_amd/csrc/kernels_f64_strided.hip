@@ -7,12 +7,12 @@ namespace {
 using d = double;
 constexpr int NT = 2;
 const strided_kernel g_strided_f64[] = {
-    make_strided_entry<wg_cfg<d, radix_list<8, 8>, 128, 16, 0, 0, TW_GLOBAL, 2, NT>>(),         // 64
-    make_strided_entry<wg_cfg<d, radix_list<16, 8>, 128, 16, 0, 0, TW_GLOBAL, 2, NT>>(),        // 128
-    make_strided_entry<wg_cfg<d, radix_list<16, 16>, 128, 8, 0, 0, TW_GLOBAL, 2, NT>>(),        // 256
-    make_strided_entry<wg_cfg<d, radix_list<8, 8, 8>, 512, 8, 0, 0, TW_GLOBAL, 2, NT>>(),       // 512
-    make_strided_entry<wg_cfg<d, radix_list<16, 8, 8>, 512, 8, 0, 0, TW_GLOBAL, 2, NT>>(),      // 1024
-    make_strided_entry<wg_cfg<d, radix_list<16, 16, 8>, 512, 4, 0, 0, TW_GLOBAL, 2, NT>>(),     // 2048
+    make_strided_entry<strided_cfg<d, radix_list<8, 8>, 128, 16, 2, NT>>(),         // 64
+    make_strided_entry<strided_cfg<d, radix_list<16, 8>, 128, 16, 2, NT>>(),        // 128
+    make_strided_entry<strided_cfg<d, radix_list<16, 16>, 128, 8, 2, NT>>(),        // 256
+    make_strided_entry<strided_cfg<d, radix_list<8, 8, 8>, 512, 8, 2, NT>>(),       // 512
+    make_strided_entry<strided_cfg<d, radix_list<16, 8, 8>, 512, 8, 2, NT>>(),      // 1024
+    make_strided_entry<strided_cfg<d, radix_list<16, 16, 8>, 512, 4, 2, NT>>(),     // 2048
 };
 }  // namespace
 

@@ -106,7 +106,12 @@ PFA_DEV void strided_pass(const IO& io, const strided_args& a, unsigned f,
       if constexpr (P != 0) {
         sfor<1, R>([&](auto t_) PFA_LAMBDA {
           constexpr int t = decltype(t_)::value;
-          const cx<T> w = (tw + Seq::tw_off(P) + (t - 1) * Ns)[q];
+          cx<T> w;
+          if constexpr (P <= Cfg::TWL && !ROW_IN && !ROW_OUT) {
+            w = (lds + N * FPW + Seq::tw_off(P) + (t - 1) * Ns)[q];  // LDS copy behind the image (wg_cfg TWL)
+          } else {
+            w = (tw + Seq::tw_off(P) + (t - 1) * Ns)[q];
+          }
           v[i][t] = cmul(v[i][t], w);
         });
       }
@@ -273,6 +278,9 @@ PFA_DEV strided_io<typename Cfg::T, Cfg::AUX, SPLIT> strided_group(const strided
   return io;
 }
 
+template <typename Cfg>
+PFA_DEV void strided_copy_twiddles(cx<typename Cfg::T>* lds, const cx<typename Cfg::T>* __restrict__ tw);
+
 /// Software-pipelined strided kernel: the loads of the work-group's next group are in flight during the LDS passes
 /// of the current one (see stockham_wg_prefetch_kernel).
 template <typename Cfg, bool BWD, bool STW, int SPLIT = 0>
@@ -287,6 +295,7 @@ __global__ __launch_bounds__(Cfg::WG, Cfg::OCC) void stockham_strided_prefetch_k
   const long long ngroups = strided_ngroups<Cfg>(a);
   long long g = blockIdx.x;
   if (g >= ngroups) return;
+  strided_copy_twiddles<Cfg>(lds, tw);
   cx<T> cur[Cfg::bpt(0)][Cfg::Seq::r[0]];
   cx<T> nxt[Cfg::bpt(0)][Cfg::Seq::r[0]];
   bool live, live_n = false;
@@ -373,10 +382,39 @@ constexpr size_t strided_row_lds_bytes() {
   return size_t(Cfg::N) * (Cfg::FPW + 1) * sizeof(cx<typename Cfg::T>);
 }
 
-/// LDS bytes of the strided kernel for a wg_cfg (unpadded [element][f] image)
+/// LDS bytes of the strided kernel for a wg_cfg (unpadded [element][f] image, then the TWL twiddle copy)
 template <typename Cfg>
 constexpr size_t strided_lds_bytes() {
-  return Cfg::NP > 1 ? size_t(Cfg::N) * Cfg::FPW * sizeof(cx<typename Cfg::T>) : 0;
+  return Cfg::NP > 1 ? (size_t(Cfg::N) * Cfg::FPW + Cfg::TWL_ELEMS) * sizeof(cx<typename Cfg::T>) : 0;
+}
+
+/// TWL of a strided kernel: leading tables of at most 16 KiB that still fit the CU's LDS next to the image and do
+/// not cost residency below 16 waves (same rule as auto_twl; measured on the C5 column kernel: 4.6 -> 5.0 TB/s)
+template <typename T, typename Seq, int WG, int FPW>
+constexpr int auto_twl_strided() {
+  constexpr long long cu_lds = 160 * 1024;
+  const long long base = static_cast<long long>(Seq::n) * FPW * static_cast<long long>(sizeof(cx<T>));
+  const long long waves = (WG + 63) / 64;
+  const long long before = cu_lds / base;
+  for (int k = Seq::count - 1; k >= 1; --k) {
+    const long long extra = static_cast<long long>(Seq::tw_off(k + 1)) * static_cast<long long>(sizeof(cx<T>));
+    if (base + extra > cu_lds) continue;
+    const long long after = cu_lds / (base + extra);
+    if (extra <= 16 * 1024 && (after == before || after * waves >= 16)) return k;
+  }
+  return 0;
+}
+template <typename T, typename Seq, int WG, int FPW, int OCC, int AUX>
+using strided_cfg = wg_cfg<T, Seq, WG, FPW, 0, 0, TW_GLOBAL, OCC, AUX, 0, auto_twl_strided<T, Seq, WG, FPW>()>;
+
+/// copy the leading twiddle tables behind the image once per work-group lifetime
+template <typename Cfg>
+PFA_DEV void strided_copy_twiddles(cx<typename Cfg::T>* lds, const cx<typename Cfg::T>* __restrict__ tw) {
+  if constexpr (Cfg::TWL > 0) {
+    cx<typename Cfg::T>* twl = lds + Cfg::N * Cfg::FPW;
+    for (int i = threadIdx.x; i < Cfg::TWL_ELEMS; i += Cfg::WG) twl[i] = tw[i];
+    __syncthreads();
+  }
 }
 
 template <typename Cfg, bool BWD, bool STW, int SPLIT = 0>
@@ -389,6 +427,7 @@ __global__ __launch_bounds__(Cfg::WG, Cfg::OCC) void stockham_strided_kernel(con
   const unsigned tid = threadIdx.x / Cfg::FPW;
   const cx<T>* __restrict__ tw = static_cast<const cx<T>*>(a.tw);
   const long long ngroups = strided_ngroups<Cfg>(a);
+  strided_copy_twiddles<Cfg>(lds, tw);
   for (long long g = blockIdx.x; g < ngroups; g += gridDim.x) {
     bool live;
     long long c0;
