@@ -239,6 +239,7 @@ struct plan_t {
   }
 
   const spec_kernel* find_spec(long long n) const {
+    if (getenv("PFFT_NO_PRECOMPILED") != nullptr) return nullptr;  // experiments: planner-chosen kernels everywhere
     int count = 0;
     const spec_kernel* k =
         desc.precision == PFFT_PRECISION_F64 ? spec_kernels_f64(&count) : spec_kernels_f32(&count);
