@@ -36,14 +36,14 @@ const spec_kernel g_spec_f32[] = {
     make_spec_entry<wg_cfg_twl<f, radix_list<32, 24, 16>, 512, 1, 16, 1, 2, NT>>(),      // 12288
     make_spec_entry<wg_cfg_twl<f, radix_list<10, 8>, 256, 32, 0, 0, 4, NT, 1>>(),       // 80
     make_spec_entry<wg_cfg_twl<f, radix_list<10, 10>, 250, 25, 0, 0, 4, NT, 1>>(),      // 100
-    make_spec_entry<wg_cfg_twl<f, radix_list<16, 10>, 256, 16, 16, 1, 4, NT>>(),         // 160
+    make_spec_entry<wg_cfg_twl<f, radix_list<16, 10>, 256, 16, 0, 0, 4, NT, 1>>(),       // 160
     make_spec_entry<wg_cfg_twl<f, radix_list<8, 8, 5>, 256, 4, 16, 1, 4, NT>>(),         // 320
     make_spec_entry<wg_cfg_twl<f, radix_list<16, 8, 5>, 256, 4, 16, 1, 4, NT>>(),        // 640
     make_spec_entry<wg_cfg_twl<f, radix_list<16, 10, 8>, 256, 2, 16, 1, 4, NT>>(),       // 1280
     make_spec_entry<wg_cfg_twl<f, radix_list<16, 16, 10>, 256, 1, 16, 1, 4, NT>>(),      // 2560
     make_spec_entry<wg_cfg_twl<f, radix_list<20, 16, 16>, 256, 1, 16, 1, 2, NT>>(),      // 5120
     make_spec_entry<wg_cfg_twl<f, radix_list<10, 10, 10>, 200, 2, 0, 0, 4, NT>>(),      // 1000
-    make_spec_entry<wg_cfg_twl<f, radix_list<10, 10, 10, 10>, 250, 1, 0, 0, 2, NT>>(),  // 10000
+    make_spec_entry<wg_cfg_twl<f, radix_list<10, 10, 10, 10>, 512, 1, 0, 0, 3, NT>>(),  // 10000
 };
 }  // namespace
 
