@@ -818,38 +818,48 @@ struct plan_t {
     // N-D, packed (validated): contiguous dimension first, then every outer dimension in place on the output,
     // as strided FFTs (reference: dispatch_dimensions, committed_descriptor_impl.hpp:923-948; there one launch per
     // (batch, outer index), here one launch per dimension).
-    // ... unless the whole transform fits LDS: then one fused launch does every dimension (stockham_nd.hpp)
-    {
-      const std::vector<long long> dims(desc.lengths, desc.lengths + rank);
+    // ... unless a suffix of the dimensions fits LDS: one fused launch (stockham_nd.hpp) does lengths[s..rank) for
+    // every index of the dimensions before it -- the whole transform when s == 0 -- and only lengths[0..s) remain
+    // as strided passes
+    int fused_from = rank;  // first dimension covered by the fused stage
+    for (int s0 = 0; s0 + 2 <= rank && fused_from == rank; ++s0) {
+      const std::vector<long long> dims(desc.lengths + s0, desc.lengths + rank);
       std::string why;
-      if (const nd_kernel* nk = jit_nd_kernel(desc.precision, dims, desc.complex_storage == PFFT_SPLIT_COMPLEX, max_lds,
-                                              &why)) {
-        st.push_back(make_spec_stage(&nk->k, B, BUF_IN, static_cast<long long>(vin.offset), BUF_OUT,
-                                     static_cast<long long>(vout.offset), scale, backward, upload_nd_twiddles(*nk)));
-        for (int i = 0; record && i < rank; ++i) {
-          pfft_dim_info_t& di = info.dims[i];
-          const std::vector<int>& r = nk->radices[static_cast<size_t>(i)];
-          di.length = desc.lengths[i];
-          di.tier = PFFT_TIER_WORKGROUP;
-          di.n_factors = static_cast<int>(std::min<size_t>(r.size(), PFFT_MAX_FACTORS));
-          for (int f = 0; f < di.n_factors; ++f) di.factors[f] = r[static_cast<size_t>(f)];
-          di.workgroup_size = nk->k.wg;
-          di.ffts_per_workgroup = nk->k.fpw;
-          di.lds_bytes = nk->k.lds_bytes;
-        }
-        return;
+      const nd_kernel* nk =
+          jit_nd_kernel(desc.precision, dims, desc.complex_storage == PFFT_SPLIT_COMPLEX, max_lds, &why);
+      if (nk == nullptr) continue;
+      long long outer = 1;
+      for (int i = 0; i < s0; ++i) outer *= static_cast<long long>(desc.lengths[i]);
+      st.push_back(make_spec_stage(&nk->k, B * outer, BUF_IN, static_cast<long long>(vin.offset), BUF_OUT,
+                                   static_cast<long long>(vout.offset), scale, backward, upload_nd_twiddles(*nk)));
+      for (int i = s0; record && i < rank; ++i) {
+        pfft_dim_info_t& di = info.dims[i];
+        const std::vector<int>& r = nk->radices[static_cast<size_t>(i - s0)];
+        di.length = desc.lengths[i];
+        di.tier = PFFT_TIER_WORKGROUP;
+        di.n_factors = static_cast<int>(std::min<size_t>(r.size(), PFFT_MAX_FACTORS));
+        for (int f = 0; f < di.n_factors; ++f) di.factors[f] = r[static_cast<size_t>(f)];
+        di.workgroup_size = nk->k.wg;
+        di.ffts_per_workgroup = nk->k.fpw;
+        di.lds_bytes = nk->k.lds_bytes;
       }
+      fused_from = s0;
     }
-    const long long last = static_cast<long long>(desc.lengths[rank - 1]);
-    {
+    if (fused_from == 0) return;
+    long long inner = 1;
+    if (fused_from == rank) {
+      const long long last = static_cast<long long>(desc.lengths[rank - 1]);
       addressing ia{static_cast<long long>(vin.offset), 1, last, 0};
       addressing oa{static_cast<long long>(vout.offset), 1, last, 0};
       const long long count = B * (total / last);
       plan_1d(st, last, count, count, BUF_IN, ia, BUF_OUT, oa, true, scale, backward,
               record ? &info.dims[rank - 1] : nullptr);
+      inner = last;
+      fused_from = rank - 1;
+    } else {
+      for (int i = fused_from; i < rank; ++i) inner *= static_cast<long long>(desc.lengths[i]);
     }
-    long long inner = last;
-    for (int i = rank - 2; i >= 0; --i) {
+    for (int i = fused_from - 1; i >= 0; --i) {
       const long long n = static_cast<long long>(desc.lengths[i]);
       const long long outer_count = B * (total / (inner * n));
       addressing a{static_cast<long long>(vout.offset), inner, 1, inner * n};

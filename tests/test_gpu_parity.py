@@ -454,11 +454,13 @@ def test_fused_multidimensional():
     import gpu_utils as G
     pf = _pf()
     shapes = [("f32", [64, 64]), ("f32", [16, 16, 16]), ("f32", [2, 3]), ("f32", [30, 50]), ("f32", [4, 2, 8]),
-              ("f32", [3, 4, 5, 6]), ("f64", [64, 64]), ("f64", [27, 125]), ("f64", [5, 7])]
+              ("f32", [3, 4, 5, 6]), ("f64", [64, 64]), ("f64", [27, 125]), ("f64", [5, 7]),
+              # only a suffix of the dimensions fits LDS: fused suffix + strided passes for the rest
+              ("f32", [16, 16, 16, 16]), ("f32", [30, 50, 70]), ("f64", [5, 6, 7, 8, 9]), ("f32", [12, 64, 64])]
     for prec, dims in shapes:
         dtype = np.complex64 if prec == "f32" else np.complex128
         n = int(np.prod(dims))
-        for batch in (1, 7, 130):
+        for batch in ((1, 7, 130) if n <= 8192 else (1, 5)):
             x, y = H.gen_fourier_data(batch, dims, dtype, seed=n + batch)
             for storage in (0, 1):
                 for place in (0, 1):

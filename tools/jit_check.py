@@ -90,6 +90,9 @@ if __name__ == "__main__":
         ok &= check(0, lengths=[8, 12, 2048])
         ok &= check(0, "f64", lengths=[16, 16, 512])
         ok &= check(0, lengths=[16, 16, 16, 16])
+        ok &= check(0, lengths=[30, 50, 70])
+        ok &= check(0, lengths=[12, 64, 64], split=True)
+        ok &= check(0, "f64", lengths=[5, 6, 7, 8, 9])
     if which in ("all", "nd"):
         for dims in ([64, 64], [32, 32], [8, 8], [16, 16, 16], [128, 32], [32, 128], [30, 50], [4, 4, 4, 4], [2, 3], [90, 90]):
             ok &= check(0, lengths=dims)
