@@ -52,7 +52,7 @@ struct nd_kernel {
   int pads = 0, padw = 0, occ = 1, regs = 0;
 };
 
-/// Planner of the fused N-D tier: all of the (rank >= 2) transform in LDS.  False when it does not fit (64 KiB)
+/// Planner of the fused N-D tier: all of the (rank >= 2) transform in LDS.  False when it does not fit (128 KiB)
 /// or a dimension has a prime factor above 31.
 bool choose_nd_params(int precision, const std::vector<long long>& dims, size_t max_lds, nd_kernel* out);
 

@@ -456,7 +456,9 @@ def test_fused_multidimensional():
     shapes = [("f32", [64, 64]), ("f32", [16, 16, 16]), ("f32", [2, 3]), ("f32", [30, 50]), ("f32", [4, 2, 8]),
               ("f32", [3, 4, 5, 6]), ("f64", [64, 64]), ("f64", [27, 125]), ("f64", [5, 7]),
               # only a suffix of the dimensions fits LDS: fused suffix + strided passes for the rest
-              ("f32", [16, 16, 16, 16]), ("f32", [30, 50, 70]), ("f64", [5, 6, 7, 8, 9]), ("f32", [12, 64, 64])]
+              ("f32", [16, 16, 16, 16]), ("f32", [30, 50, 70]), ("f64", [5, 6, 7, 8, 9]), ("f32", [12, 64, 64]),
+              # the largest fused shapes (128 KiB of LDS, one work-group per CU)
+              ("f32", [128, 128]), ("f64", [64, 128]), ("f32", [8, 128, 128])]
     for prec, dims in shapes:
         dtype = np.complex64 if prec == "f32" else np.complex128
         n = int(np.prod(dims))
