@@ -547,6 +547,24 @@ def test_streams_and_graph_capture():
     g.replay()  # second replay consumes the first one's output: forward of (N x)
     torch.cuda.synchronize()
     _check(o1.cpu().numpy().reshape(batch, n), y.astype(np.complex128) * n, n, np.complex64, "graph replay 2")
+    # plans whose kernels were compiled at commit time (module launches) capture and replay the same way
+    for dims, kw in (([1200], {}), ([64, 64], {}), ([30000], {}), ([4096], dict(fwd_distance=4160, bwd_distance=4160))):
+        d = G.make_descriptor(dims, "f32", batch=6, **kw)
+        s = torch.cuda.Stream()
+        with torch.cuda.stream(s):
+            plan = d.commit()
+            xin = torch.randn(d.get_input_count(pf.direction.FORWARD), dtype=torch.complex64, device="cuda")
+            out = torch.zeros(d.get_output_count(pf.direction.FORWARD), dtype=torch.complex64, device="cuda")
+            plan.compute_forward(xin, out)
+            s.synchronize()
+            ref = out.clone()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=s):
+                plan.compute_forward(xin, out)
+            out.zero_()
+            g.replay()
+            s.synchronize()
+        assert torch.equal(ref, out), dims
 
 
 def test_full_size_config2_properties():
