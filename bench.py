@@ -235,6 +235,7 @@ def main():
             "config": {"workload": "BASELINE configs[1]: fp32 C2C 1D forward N=4096 batch=65536 per GPU, out-of-place, "
                                    "interleaved, inputs resident in HBM", "n": N, "batch_per_gpu": BATCH_PER_GPU,
                        "global_batch": BATCH_PER_GPU * world, "sharding": "batches, no data-path collective",
+                       "barrier_backend": ("rccl" if pg.backend == "nccl" else pg.backend) if distributed else None,
                        "parity_rel_l2_vs_numpy": worst},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,

@@ -36,11 +36,26 @@ class process_group:
         self.world, self.rank, self.local_rank = env_world()
         self.device = device if device is not None else torch.device("cpu")
         self.active = self.world > 1
+        self.backend = backend
         if self.active and not dist.is_initialized():
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29511")
             if backend == "nccl":
-                dist.init_process_group("nccl", device_id=self.device)
+                try:
+                    dist.init_process_group("nccl", device_id=self.device)
+                    # the first collective creates the RCCL communicator: fail here, not inside the timed region
+                    probe = torch.zeros(1, device=self.device)
+                    dist.all_reduce(probe)
+                    torch.cuda.synchronize()
+                except Exception as e:  # noqa: BLE001 -- RCCL unusable on this node: the scalars can travel over gloo
+                    import sys
+                    print("process_group: RCCL unavailable (%s); falling back to gloo for barrier/max" % e,
+                          file=sys.stderr)
+                    if dist.is_initialized():
+                        dist.destroy_process_group()
+                    dist.init_process_group("gloo")
+                    self.backend = "gloo"
+                    self.device = torch.device("cpu")
             else:
                 dist.init_process_group(backend)
 
