@@ -1,0 +1,87 @@
+"""Random descriptors against NumPy: rank, lengths (31-smooth), batch, layout (packed / batch-interleaved / unpacked rows /
+strided), storage, placement, offsets, scales, precision, direction.  usage: fuzz.py [seed] [iterations]"""
+import os, sys, random
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+import numpy as np
+import helpers as H
+import gpu_utils as G
+import portfft_amd as pf
+
+PRIMES = [2, 2, 2, 2, 3, 3, 5, 5, 7, 11, 13, 17, 19, 23, 29, 31]
+
+def smooth(rng, lo, hi):
+    while True:
+        n = 1
+        while n < lo:
+            n *= rng.choice(PRIMES)
+        if n <= hi:
+            return n
+
+def main():
+    seed = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+    iters = int(sys.argv[2]) if len(sys.argv) > 2 else 200
+    rng = random.Random(seed)
+    fails = 0
+    for it in range(iters):
+        prec = rng.choice(["f32", "f32", "f64"])
+        dtype = np.complex64 if prec == "f32" else np.complex128
+        rank = rng.choice([1, 1, 1, 2, 2, 3])
+        if rank == 1:
+            dims = [smooth(rng, rng.choice([2, 20, 300, 3000]), rng.choice([64, 2000, 20000, 200000]))]
+        else:
+            dims = [smooth(rng, 2, rng.choice([12, 40, 200])) for _ in range(rank)]
+        n = int(np.prod(dims))
+        batch = rng.choice([1, 2, 3, 7, 16, 33, 100])
+        if n * batch > 4_000_000:
+            batch = max(1, 4_000_000 // n)
+        storage = rng.choice([0, 0, 1])
+        kw = {}
+        place = rng.choice([0, 1])
+        layout = "P"
+        if rank == 1:
+            layout = rng.choice(["P", "P", "BI", "ROWS", "STR", "PBI", "BIP"])
+            if layout == "BI":
+                kw = dict(fwd_strides=[batch], fwd_distance=1, bwd_strides=[batch], bwd_distance=1)
+            elif layout == "PBI" and place == 1:
+                kw = dict(bwd_strides=[batch], bwd_distance=1)
+            elif layout == "BIP" and place == 1:
+                kw = dict(fwd_strides=[batch], fwd_distance=1)
+            elif layout == "ROWS":
+                ld = n + rng.choice([1, 3, 16, 64])
+                kw = dict(fwd_distance=ld, bwd_distance=ld)
+            elif layout == "STR":
+                s = rng.choice([2, 3])
+                d = n * s + rng.choice([0, 1, 5])
+                kw = dict(fwd_strides=[s], fwd_distance=d, bwd_strides=[s], bwd_distance=d)
+        fo = rng.choice([0, 0, 3, 17])
+        bo = fo if place == 0 else rng.choice([0, 5])
+        fs, bs = rng.choice([1.0, 0.5]), rng.choice([1.0, 2.0])
+        direction = rng.choice([pf.direction.FORWARD, pf.direction.BACKWARD])
+        desc = "%s dims=%s batch=%d storage=%d place=%d layout=%s off=(%d,%d) dir=%s" % (prec, dims, batch, storage, place, layout, fo, bo, direction.name)
+        try:
+            d = G.make_descriptor(dims, prec, batch=batch, storage=storage, placement=place, fwd_offset=fo, bwd_offset=bo,
+                                  fwd_scale=fs, bwd_scale=bs, **kw)
+            x, y = H.gen_fourier_data(batch, dims, dtype, seed=it)
+            if direction == pf.direction.FORWARD:
+                got, _ = G.transform_packed(d, direction, x)
+                ref = fs * y.astype(np.complex128)
+            else:
+                got, _ = G.transform_packed(d, direction, y)
+                ref = bs * n * x.astype(np.complex128)
+            err = H.rel_l2(np.asarray(got).reshape(batch, -1), ref.reshape(batch, -1))
+            tol = (4e-6 if prec == "f32" else 1e-14)
+            if not (err < tol):
+                fails += 1
+                print("FAIL err=%.2e  %s" % (err, desc), flush=True)
+            if it % 20 == 19:
+                print("... %d done, %d failures" % (it + 1, fails), flush=True)
+        except (pf.unsupported_configuration, pf.invalid_configuration) as e:
+            print("skip (%s): %s" % (type(e).__name__, desc), flush=True)
+        except Exception as e:  # noqa: BLE001
+            fails += 1
+            print("EXC %r  %s" % (e, desc), flush=True)
+    print("fuzz seed %d: %d iterations, %d failures" % (seed, iters, fails))
+    sys.exit(1 if fails else 0)
+
+main()
