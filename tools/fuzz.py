@@ -11,6 +11,7 @@ import portfft_amd as pf
 PRIMES = [2, 2, 2, 2, 3, 3, 5, 5, 7, 11, 13, 17, 19, 23, 29, 31]
 
 def smooth(rng, lo, hi):
+    lo = min(lo, hi)
     while True:
         n = 1
         while n < lo:
@@ -74,7 +75,7 @@ def main():
             if not (err < tol):
                 fails += 1
                 print("FAIL err=%.2e  %s" % (err, desc), flush=True)
-            if it % 20 == 19:
+            if it % 10 == 9:
                 print("... %d done, %d failures" % (it + 1, fails), flush=True)
         except (pf.unsupported_configuration, pf.invalid_configuration) as e:
             print("skip (%s): %s" % (type(e).__name__, desc), flush=True)
