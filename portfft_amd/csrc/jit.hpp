@@ -100,6 +100,11 @@ hipError_t jit_launch_strided(const strided_kernel* k, hipStream_t stream, unsig
                               int backward, int store_modifier);
 hipError_t jit_launch_strided_split(const strided_kernel* k, hipStream_t stream, unsigned grid,
                                     const strided_args& args, int backward);
+/// Make the row-staged form (stockham_strided_row_kernel; fp32, interleaved, no store modifier) of a
+/// runtime-compiled strided entry available: row_out 0 = row-shaped input, 1 = row-shaped output.
+bool jit_strided_ensure_row(const strided_kernel* k, int row_out, size_t max_lds, std::string* why);
+hipError_t jit_launch_strided_row(const strided_kernel* k, hipStream_t stream, unsigned grid, const strided_args& args,
+                                  int backward, int row_out);
 hipError_t jit_launch_strided_mixed(const strided_kernel* k, hipStream_t stream, unsigned grid,
                                     const strided_args& args, int backward, int split_mode);
 

@@ -67,6 +67,8 @@ struct strided_kernel {
   /// mixed storage for the four-step tier on SPLIT_COMPLEX data: [backward] split input -> interleaved scratch with
   /// store modifier (stage A), [2 + backward] interleaved scratch -> split output (stage B)
   hipFunction_t mfn_mixed[4];
+  /// row-staged forms of runtime-compiled entries: mfn_row[row_out * 2 + backward] (lds_bytes_row as above)
+  hipFunction_t mfn_row[4];
 };
 
 const strided_kernel* strided_kernels_f32(int* count);

@@ -356,9 +356,23 @@ struct plan_t {
     // row-shaped side of an interleaved fp32 stage: copy it through LDS with full-line accesses
     const bool user_split =
         desc.complex_storage == PFFT_SPLIT_COMPLEX && in_buf != BUF_SCRATCH && out_buf != BUF_SCRATCH;
-    if (k->launch_row != nullptr && !user_split && k->lds_bytes_row <= max_lds) {  // pre-compiled entries only
-      if (ia.stride == 1 && ia.dist_inner != 1 && oa.dist_inner == 1) s.row_mode = 1;
-      if (oa.stride == 1 && oa.dist_inner != 1 && ia.dist_inner == 1) s.row_mode = 2;
+    // fp32 row-shaped sides are staged through LDS (`_row` forms).  Measured (tools/perf_global_f32.py): a staged
+    // row-shaped INPUT pays up to n = 512 (four-step stage B of N=65536: 2.6 vs 2.0 TB/s; P->BI n=256 5.2 vs 3.2) and
+    // loses beyond (N=2^20: 1.76 vs 2.07 with the group-major intermediate; P->BI n=1024 2.7 vs 3.7); a staged
+    // row-shaped OUTPUT always pays (BI->P n=1024 4.0 vs 2.0).
+    int want_row = 0;
+    if (ia.stride == 1 && ia.dist_inner != 1 && oa.dist_inner == 1 && k->n <= 512) want_row = 1;
+    if (oa.stride == 1 && oa.dist_inner != 1 && ia.dist_inner == 1) want_row = 2;
+    const bool mixed = desc.complex_storage == PFFT_SPLIT_COMPLEX && (in_buf == BUF_SCRATCH) != (out_buf == BUF_SCRATCH);
+    if (k->launch == nullptr && want_row != 0 && !user_split && !mixed) {  // runtime-compiled entry: build the row form
+      std::string why;
+      if (jit_strided_ensure_row(k, want_row - 1, max_lds, &why)) {
+        s.row_mode = want_row;
+        s.lds_bytes = k->lds_bytes_row;
+      }
+    }
+    if (k->launch_row != nullptr && !user_split && k->lds_bytes_row <= max_lds) {  // pre-compiled entries
+      s.row_mode = want_row;
       if (s.row_mode != 0) {
         s.lds_bytes = k->lds_bytes_row;
         for (int i = 0; i < 4; ++i) {
@@ -379,7 +393,9 @@ struct plan_t {
       }
     }
     const long long groups = strided_groups(count, a.inner, k->fpw);
-    if (k->launch == nullptr) {  // runtime-compiled: whichever variant this stage will launch
+    if (k->launch == nullptr && s.row_mode != 0) {
+      s.grid = persistent_grid(nullptr, k->mfn_row[(s.row_mode - 1) * 2 + backward], k->wg, k->lds_bytes_row, groups, 1);
+    } else if (k->launch == nullptr) {  // runtime-compiled: whichever variant this stage will launch
       const bool split_storage = desc.complex_storage == PFFT_SPLIT_COMPLEX;
       hipFunction_t f = user_split ? k->mfn_split[backward] : k->mfn[backward * 2];
       if (split_storage && (in_buf == BUF_SCRATCH) != (out_buf == BUF_SCRATCH)) {
@@ -942,7 +958,10 @@ struct plan_t {
       a.out = const_cast<char*>(base_re(s.out_buf, false)) +
               static_cast<size_t>(s.out_addr.offset + out_shift) * elem_bytes();
       if (s.row_mode != 0 && s.store_modifier == 0) {
-        hip_check(s.strided->launch_row(stream, grid, a, s.backward, s.row_mode - 1), "kernel launch");
+        hip_check(s.strided->launch_row != nullptr
+                      ? s.strided->launch_row(stream, grid, a, s.backward, s.row_mode - 1)
+                      : jit_launch_strided_row(s.strided, stream, grid, a, s.backward, s.row_mode - 1),
+                  "kernel launch");
         return;
       }
       hip_check(s.strided->launch != nullptr

@@ -60,7 +60,7 @@ int main(int argc, char** argv) {
         long long pq = 1;
         for (int r : q.radices) pq *= r;
         EXPECT(pq == n && (q.radices.size() >= 2 || n <= 32), "strided n=%lld", n);
-        EXPECT(q.wg >= 64 && q.wg <= 512 && q.wg % q.fpw == 0, "strided n=%lld wg=%d fpw=%d", n, q.wg, q.fpw);
+        EXPECT(q.wg >= 64 && q.wg <= 1024 && q.wg % q.fpw == 0, "strided n=%lld wg=%d fpw=%d", n, q.wg, q.fpw);
         EXPECT(static_cast<size_t>(n) * q.fpw * es <= 128 * 1024, "strided n=%lld lds", n);
       }
     }
