@@ -6,7 +6,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libportfft_amd.so")
+# PORTFFT_AMD_LIBRARY selects another build of the same library (debug / experiment builds)
+LIB_PATH = os.environ.get("PORTFFT_AMD_LIBRARY") or os.path.join(_HERE, "libportfft_amd.so")
 
 MAX_RANK = 8
 MAX_FACTORS = 16
