@@ -69,6 +69,8 @@ struct strided_kernel {
   hipFunction_t mfn_mixed[4];
   /// row-staged forms of runtime-compiled entries: mfn_row[row_out * 2 + backward] (lds_bytes_row as above)
   hipFunction_t mfn_row[4];
+  /// 1: alternative entry for the same length, preferred when both sides of the stage are column-shaped
+  int wide;
 };
 
 const strided_kernel* strided_kernels_f32(int* count);

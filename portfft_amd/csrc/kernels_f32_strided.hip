@@ -10,8 +10,8 @@ constexpr int NT = 2;
 const strided_kernel g_strided_f32[] = {
     with_rows<strided_cfg<f, radix_list<8, 8>, 256, 32, 2, NT>>(make_strided_entry<strided_cfg<f, radix_list<8, 8>, 256, 32, 2, NT>>()),          // 64
     with_rows<strided_cfg<f, radix_list<16, 8>, 256, 32, 2, NT>>(make_strided_entry<strided_cfg<f, radix_list<16, 8>, 256, 32, 2, NT>>()),         // 128
-    with_rows<strided_cfg<f, radix_list<16, 16>, 256, 16, 2, NT>>(make_strided_entry<strided_cfg<f, radix_list<16, 16>, 256, 16, 2, NT>>()),        // 256
-    with_rows<strided_cfg<f, radix_list<8, 8, 8>, 1024, 16, 4, NT>>(make_strided_entry<strided_cfg<f, radix_list<8, 8, 8>, 1024, 16, 4, NT>>()),      // 512
+    with_rows<strided_cfg<f, radix_list<16, 16>, 512, 32, 2, NT>>(make_strided_entry<strided_cfg<f, radix_list<16, 16>, 512, 32, 2, NT>>()),        // 256
+    with_rows<strided_cfg<f, radix_list<8, 8, 8>, 1024, 32, 2, NT>>(make_strided_entry<strided_cfg<f, radix_list<8, 8, 8>, 1024, 32, 2, NT>>()),      // 512
     with_rows<strided_cfg<f, radix_list<32, 32>, 512, 16, 2, NT>>(make_strided_entry_prefetch<strided_cfg<f, radix_list<32, 32>, 512, 16, 2, NT>>(4)),  // 1024
     with_rows<strided_cfg<f, radix_list<16, 16, 8>, 1024, 8, 4, NT>>(make_strided_entry<strided_cfg<f, radix_list<16, 16, 8>, 1024, 8, 4, NT>>()),     // 2048
     with_rows<strided_cfg<f, radix_list<16, 16, 16>, 1024, 4, 4, NT>>(make_strided_entry<strided_cfg<f, radix_list<16, 16, 16>, 1024, 4, 4, NT>>()),    // 4096

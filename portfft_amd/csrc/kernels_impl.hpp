@@ -162,6 +162,12 @@ hipError_t launch_strided_row(hipStream_t stream, unsigned grid, const strided_a
   return hipGetLastError();
 }
 
+/// mark an entry as the wide-group alternative of its length (strided_kernel::wide)
+inline strided_kernel wide(strided_kernel k) {
+  k.wide = 1;
+  return k;
+}
+
 /// add the row-staged forms to an entry (fp32: a wave covers only 64/FPW * 8 B of a row when addressed f-fastest)
 template <typename Cfg>
 strided_kernel with_rows(strided_kernel k) {

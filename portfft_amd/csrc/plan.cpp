@@ -249,14 +249,18 @@ struct plan_t {
     return nullptr;
   }
 
-  const strided_kernel* find_strided(long long n) const {
+  /// column_both: the stage is column-shaped on both sides -> the wide-group entry of the length, when there is one
+  const strided_kernel* find_strided(long long n, bool column_both = false) const {
     int count = 0;
     const strided_kernel* k =
         desc.precision == PFFT_PRECISION_F64 ? strided_kernels_f64(&count) : strided_kernels_f32(&count);
+    const strided_kernel* found = nullptr;
     for (int i = 0; i < count; ++i) {
-      if (k[i].n == n && k[i].lds_bytes <= max_lds) return &k[i];
+      if (k[i].n != n || k[i].lds_bytes > max_lds) continue;
+      if (k[i].wide == 0 && found == nullptr) found = &k[i];
+      if (k[i].wide != 0 && column_both) return &k[i];
     }
-    return nullptr;
+    return found;
   }
 
   /// FFTs per work-group of the strided kernel get_strided(n, inner_count, ...) would deliver; 0 when there is none.
@@ -270,8 +274,9 @@ struct plan_t {
   }
 
   /// the pre-compiled strided kernel when it suits the stage, otherwise a runtime-specialised one (jit.hpp)
-  const strided_kernel* get_strided(long long n, long long inner_count, bool store_modifier, bool user_split) {
-    const strided_kernel* k = find_strided(n);
+  const strided_kernel* get_strided(long long n, long long inner_count, bool store_modifier, bool user_split,
+                                    bool column_both = false) {
+    const strided_kernel* k = find_strided(n, column_both);
     if (k != nullptr) return k;
     std::string why;
     k = jit_strided_kernel(desc.precision, n, inner_count, store_modifier, user_split ? 1 : 0, max_lds, &why);
@@ -577,8 +582,8 @@ struct plan_t {
     }
     if (n1 == 0) return false;
     const long long n2 = n / n1;
-    const strided_kernel* ka = get_strided(n1, n2 * B, true, false);
-    const strided_kernel* kb = get_strided(n2, B, false, false);
+    const strided_kernel* ka = get_strided(n1, n2 * B, true, false, true);  // both stages are column-shaped on both
+    const strided_kernel* kb = get_strided(n2, B, false, false, true);      // sides: wide-group entries
     addressing a_in{ia.offset, n2 * B, 1, 0};
     addressing a_out{0, n2 * B, 1, 0};
     addressing b_in{0, B, 1, n2 * B};
@@ -684,7 +689,8 @@ struct plan_t {
     // the strided tier pays when at least one side is "column" shaped (consecutive FFTs adjacent in memory)
     const bool column_shaped = ia.dist_inner == 1 || oa.dist_inner == 1;
     const bool user_split = !interleaved && in_buf != BUF_SCRATCH;
-    if (const strided_kernel* k = column_shaped ? get_strided(n, inner_count, false, user_split) : nullptr;
+    const bool column_both = ia.dist_inner == 1 && oa.dist_inner == 1;
+    if (const strided_kernel* k = column_shaped ? get_strided(n, inner_count, false, user_split, column_both) : nullptr;
         strided_fits(k, inner_count, in_buf, ia, out_buf, oa)) {
       out.push_back(make_strided_stage(k, count, inner_count, in_buf, ia, out_buf, oa, scale, backward));
       record(PFFT_TIER_WORKGROUP, std::vector<int>(k->radices, k->radices + k->n_radices), k->wg, k->fpw,
