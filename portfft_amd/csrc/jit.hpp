@@ -35,7 +35,8 @@ bool choose_spec_params(int precision, long long n, size_t max_lds, wg_params* o
 
 /// Same for the strided tier (FPW adjacent FFTs side by side); `inner_count` is the number of adjacent FFTs the
 /// stage offers (narrow stages get narrower groups).
-bool choose_strided_params(int precision, long long n, long long inner_count, size_t max_lds, wg_params* out);
+bool choose_strided_params(int precision, long long n, long long inner_count, size_t max_lds, wg_params* out,
+                           bool column_both = false);
 
 /// LDS bytes of a packed work-group kernel with these parameters (wg_cfg::LDS_BYTES)
 size_t spec_lds_bytes(const wg_params& p);
@@ -76,7 +77,8 @@ const spec_kernel* jit_spec_kernel(int precision, long long n, bool split, size_
 /// (split_mode: 0 interleaved, 1 split on both sides, 2 split input + store modifier (four-step stage A on
 /// SPLIT_COMPLEX data), 3 split output (stage B); see stockham_strided.hpp).
 const strided_kernel* jit_strided_kernel(int precision, long long n, long long inner_count, bool store_modifier,
-                                         int split_mode, size_t max_lds, std::string* why);
+                                         int split_mode, size_t max_lds, std::string* why,
+                                         bool column_both = false);
 
 /// UNPACKED-layout form (stockham_wg_unpacked_kernel) of the packed configuration `like` (a pre-compiled or a
 /// runtime-specialised entry): forward/backward module functions for interleaved or split storage.

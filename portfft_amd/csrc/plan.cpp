@@ -279,7 +279,8 @@ struct plan_t {
     const strided_kernel* k = find_strided(n, column_both);
     if (k != nullptr) return k;
     std::string why;
-    k = jit_strided_kernel(desc.precision, n, inner_count, store_modifier, user_split ? 1 : 0, max_lds, &why);
+    k = jit_strided_kernel(desc.precision, n, inner_count, store_modifier, user_split ? 1 : 0, max_lds, &why,
+                           column_both);
     if (k == nullptr) jit_note("strided", n, why);
     return k;
   }

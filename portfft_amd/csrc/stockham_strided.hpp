@@ -123,8 +123,8 @@ PFA_DEV void strided_pass(const IO& io, const strided_args& a, unsigned f,
             live ? (f * a.out_fdist + (base >> osh) * a.out_stride + (base & ((1u << osh) - 1u))) * ES_OUT
                  : 0xFFFFFFF0u;
         const T scale = static_cast<T>(a.scale);
-        // store modifier W_M^{k*c}, k = base + u*Ns: W^{base*c} and the step W^{Ns*c} come from the hi/lo tables
-        // (4 loads per butterfly instead of 2 per output), the powers of the step by squaring / one multiply
+        // store modifier W_M^{k*c}, k = base + u*Ns: W^{base*c}, the step W^{Ns*c} and every fourth power of the step
+        // come from the hi/lo tables, the other powers are one multiply away from those
         [[maybe_unused]] cx<T> stw[R];
         if constexpr (STW) {
           unsigned long long stw_c = static_cast<unsigned long long>(c0 + f);
@@ -138,12 +138,17 @@ PFA_DEV void strided_pass(const IO& io, const strided_args& a, unsigned f,
           cx<T> pw[R];
           pw[0] = {T(1), T(0)};
           if constexpr (R > 1) pw[1] = cmul(lo[ms & mask], hi[ms >> a.stw_shift]);
+          // powers of the step: every fourth one straight from the tables, the others one multiply away from an
+          // anchor -- a chain of squarings would amplify the rounding of pw[1] by u (radix 32: ~45 ulp in fp32)
           sfor<2, R>([&](auto u_) PFA_LAMBDA {
             constexpr int u = decltype(u_)::value;
-            if constexpr (u % 2 == 0) {
-              pw[u] = cmul(pw[u / 2], pw[u / 2]);
-            } else {
+            if constexpr (u % 4 == 0) {
+              const unsigned long long mu = ms * static_cast<unsigned long long>(u);
+              pw[u] = cmul(lo[mu & mask], hi[mu >> a.stw_shift]);
+            } else if constexpr (u < 4) {
               pw[u] = cmul(pw[u - 1], pw[1]);
+            } else {
+              pw[u] = cmul(pw[u - u % 4], pw[u % 4]);
             }
           });
           stw[0] = w0;
