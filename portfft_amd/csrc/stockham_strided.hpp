@@ -135,24 +135,26 @@ PFA_DEV void strided_pass(const IO& io, const strided_args& a, unsigned f,
           const unsigned long long m0 = static_cast<unsigned long long>(base) * stw_c;
           const unsigned long long ms = static_cast<unsigned long long>(Ns) * stw_c;
           const cx<T> w0 = cmul(lo[m0 & mask], hi[m0 >> a.stw_shift]);
-          cx<T> pw[R];
-          pw[0] = {T(1), T(0)};
+          // stw[u] = W^{(base + u*Ns)*c} = w0 * step^u.  Every fourth one is w0 times a table value (anchor), the
+          // three behind it are one multiply away from their anchor -- a chain of squarings of the step would amplify
+          // its rounding by u (radix 32: ~45 ulp in fp32), and folding w0 into the anchors saves R multiplies.
+          [[maybe_unused]] cx<T> pw[4];
           if constexpr (R > 1) pw[1] = cmul(lo[ms & mask], hi[ms >> a.stw_shift]);
-          // powers of the step: every fourth one straight from the tables, the others one multiply away from an
-          // anchor -- a chain of squarings would amplify the rounding of pw[1] by u (radix 32: ~45 ulp in fp32)
-          sfor<2, R>([&](auto u_) PFA_LAMBDA {
-            constexpr int u = decltype(u_)::value;
-            if constexpr (u % 4 == 0) {
-              const unsigned long long mu = ms * static_cast<unsigned long long>(u);
-              pw[u] = cmul(lo[mu & mask], hi[mu >> a.stw_shift]);
-            } else if constexpr (u < 4) {
-              pw[u] = cmul(pw[u - 1], pw[1]);
-            } else {
-              pw[u] = cmul(pw[u - u % 4], pw[u % 4]);
+          if constexpr (R > 2) pw[2] = cmul(pw[1], pw[1]);
+          if constexpr (R > 3) pw[3] = cmul(pw[2], pw[1]);
+          sfor<0, (R + 3) / 4>([&](auto k_) PFA_LAMBDA {
+            constexpr int k = decltype(k_)::value;
+            cx<T> anchor = w0;
+            if constexpr (k > 0) {
+              const unsigned long long mu = ms * static_cast<unsigned long long>(4 * k);
+              anchor = cmul(w0, cmul(lo[mu & mask], hi[mu >> a.stw_shift]));
             }
+            stw[4 * k] = anchor;
+            sfor<1, 4>([&](auto r_) PFA_LAMBDA {
+              constexpr int r = decltype(r_)::value;
+              if constexpr (4 * k + r < R) stw[4 * k + r] = cmul(anchor, pw[r]);
+            });
           });
-          stw[0] = w0;
-          sfor<1, R>([&](auto u_) PFA_LAMBDA { stw[decltype(u_)::value] = cmul(w0, pw[decltype(u_)::value]); });
         }
         sfor<0, R>([&](auto u_) PFA_LAMBDA {
           constexpr int u = decltype(u_)::value;
