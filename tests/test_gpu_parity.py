@@ -5,6 +5,8 @@ precision result -- far inside the 1e-4 bar of BASELINE.json -- plus the referen
 2*eps*N*log2(N) (fft_test_utils.hpp:461-464).  The size / batch / layout grid follows
 test/unit_test/instantiate_fft_tests.hpp.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -482,6 +484,17 @@ def test_fused_multidimensional():
         finally:
             del os.environ["PFFT_FUSED_ND"]
         assert H.rel_l2(fused, per_dim) < (2e-6 if prec == "f32" else 5e-15), (prec, dims)
+
+
+def test_random_descriptors():
+    """seeded random descriptors (rank, 31-smooth lengths, layouts, storages, placements, offsets, scales, precision,
+    direction) against NumPy -- the generator of tools/fuzz.py, 80 cases"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz.py"), "11", "80"], capture_output=True,
+                       text=True, timeout=900)
+    assert p.returncode == 0 and "0 failures" in p.stdout, p.stdout[-3000:] + p.stderr[-2000:]
 
 
 def test_error_behaviour_and_plan_info():
