@@ -71,6 +71,8 @@ struct strided_kernel {
   hipFunction_t mfn_row[4];
   /// 1: alternative entry for the same length, preferred when both sides of the stage are column-shaped
   int wide;
+  /// 1: alternative entry preferred when one side of the stage is row-shaped (its `_row` forms pay at this length)
+  int rowish;
 };
 
 const strided_kernel* strided_kernels_f32(int* count);

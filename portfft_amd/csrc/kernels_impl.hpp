@@ -168,6 +168,12 @@ inline strided_kernel wide(strided_kernel k) {
   return k;
 }
 
+/// mark an entry as the alternative of its length for stages with a row-shaped side (strided_kernel::rowish)
+inline strided_kernel rowish(strided_kernel k) {
+  k.rowish = 1;
+  return k;
+}
+
 /// add the row-staged forms to an entry (fp32: a wave covers only 64/FPW * 8 B of a row when addressed f-fastest)
 template <typename Cfg>
 strided_kernel with_rows(strided_kernel k) {

@@ -250,15 +250,17 @@ struct plan_t {
   }
 
   /// column_both: the stage is column-shaped on both sides -> the wide-group entry of the length, when there is one
-  const strided_kernel* find_strided(long long n, bool column_both = false) const {
+  /// row_side: one side of the stage is row-shaped -> the row-friendly entry of the length, when there is one
+  const strided_kernel* find_strided(long long n, bool column_both = false, bool row_side = false) const {
     int count = 0;
     const strided_kernel* k =
         desc.precision == PFFT_PRECISION_F64 ? strided_kernels_f64(&count) : strided_kernels_f32(&count);
     const strided_kernel* found = nullptr;
     for (int i = 0; i < count; ++i) {
       if (k[i].n != n || k[i].lds_bytes > max_lds) continue;
-      if (k[i].wide == 0 && found == nullptr) found = &k[i];
+      if (k[i].wide == 0 && k[i].rowish == 0 && found == nullptr) found = &k[i];
       if (k[i].wide != 0 && column_both) return &k[i];
+      if (k[i].rowish != 0 && row_side && k[i].lds_bytes_row <= max_lds) return &k[i];
     }
     return found;
   }
@@ -275,8 +277,8 @@ struct plan_t {
 
   /// the pre-compiled strided kernel when it suits the stage, otherwise a runtime-specialised one (jit.hpp)
   const strided_kernel* get_strided(long long n, long long inner_count, bool store_modifier, bool user_split,
-                                    bool column_both = false) {
-    const strided_kernel* k = find_strided(n, column_both);
+                                    bool column_both = false, bool row_side = false) {
+    const strided_kernel* k = find_strided(n, column_both, row_side && !user_split);
     if (k != nullptr) return k;
     std::string why;
     k = jit_strided_kernel(desc.precision, n, inner_count, store_modifier, user_split ? 1 : 0, max_lds, &why,
@@ -367,7 +369,7 @@ struct plan_t {
     // loses beyond (N=2^20: 1.76 vs 2.07 with the group-major intermediate; P->BI n=1024 2.7 vs 3.7); a staged
     // row-shaped OUTPUT always pays (BI->P n=1024 4.0 vs 2.0).
     int want_row = 0;
-    if (ia.stride == 1 && ia.dist_inner != 1 && oa.dist_inner == 1 && k->n <= 512) want_row = 1;
+    if (ia.stride == 1 && ia.dist_inner != 1 && oa.dist_inner == 1 && (k->n <= 512 || k->rowish != 0)) want_row = 1;
     if (oa.stride == 1 && oa.dist_inner != 1 && ia.dist_inner == 1) want_row = 2;
     const bool mixed = desc.complex_storage == PFFT_SPLIT_COMPLEX && (in_buf == BUF_SCRATCH) != (out_buf == BUF_SCRATCH);
     if (k->launch == nullptr && want_row != 0 && !user_split && !mixed) {  // runtime-compiled entry: build the row form
@@ -691,7 +693,9 @@ struct plan_t {
     const bool column_shaped = ia.dist_inner == 1 || oa.dist_inner == 1;
     const bool user_split = !interleaved && in_buf != BUF_SCRATCH;
     const bool column_both = ia.dist_inner == 1 && oa.dist_inner == 1;
-    if (const strided_kernel* k = column_shaped ? get_strided(n, inner_count, false, user_split, column_both) : nullptr;
+    const bool row_side = (ia.stride == 1 && ia.dist_inner != 1) || (oa.stride == 1 && oa.dist_inner != 1);
+    if (const strided_kernel* k =
+            column_shaped ? get_strided(n, inner_count, false, user_split, column_both, row_side) : nullptr;
         strided_fits(k, inner_count, in_buf, ia, out_buf, oa)) {
       out.push_back(make_strided_stage(k, count, inner_count, in_buf, ia, out_buf, oa, scale, backward));
       record(PFFT_TIER_WORKGROUP, std::vector<int>(k->radices, k->radices + k->n_radices), k->wg, k->fpw,
@@ -755,7 +759,7 @@ struct plan_t {
     const bool user_io = in_buf != BUF_SCRATCH && out_buf != BUF_SCRATCH;
     const strided_kernel* ka = interleaved_user ? get_strided(n1, n2, true, false)
                                                 : (user_io ? get_strided_mixed(n1, n2, 2) : nullptr);
-    const strided_kernel* kb = interleaved_user ? get_strided(n2, n1, false, false)
+    const strided_kernel* kb = interleaved_user ? get_strided(n2, n1, false, false, false, true)  // rows in
                                                 : (user_io ? get_strided_mixed(n2, n1, 3) : nullptr);
     const char* dbg = getenv("PFFT_DEBUG_GLOBAL");  // debugging aid: "ga" / "gb" force the generic kernel for a stage
     const bool force_generic_a = dbg != nullptr && std::strstr(dbg, "ga") != nullptr;
