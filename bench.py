@@ -17,6 +17,7 @@ import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
+os.environ.setdefault("PFFT_JIT_CACHE_DIR", os.path.join(ROOT, "build", "jit_cache"))  # only --config c3/c5 paths compile
 for _p in (ROOT, os.path.join(ROOT, "tests")):
     if _p not in sys.path:
         sys.path.insert(0, _p)

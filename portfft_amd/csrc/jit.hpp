@@ -7,7 +7,9 @@
 // radix sequence the planner below picks, so any length with prime factors <= 31 that fits LDS runs on a
 // compile-time-radix kernel instead of the runtime-radix generic kernel (3-5x slower, profiles/r1_notes.md).
 //
-// The compiled code objects are cached per process and device, and on disk when PFFT_JIT_CACHE_DIR is set.
+// The compiled code objects are cached per process and device, and on disk (PFFT_JIT_CACHE_DIR, default
+// $XDG_CACHE_HOME/portfft_amd or ~/.cache/portfft_amd; empty string: no disk cache), keyed by a hash of the kernel
+// sources, the instantiation, the architecture and the hiprtc version.
 // PFFT_JIT=0 disables the facility (the planner then falls back to the generic tier); PFFT_JIT_VERBOSE=1 logs
 // every compilation to stderr.
 #pragma once

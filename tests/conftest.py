@@ -9,6 +9,10 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
         sys.path.insert(0, p)
 
 
+# commit-time compiled kernels: keep the tests' code-object cache inside the repository
+os.environ.setdefault("PFFT_JIT_CACHE_DIR", os.path.join(ROOT, "build", "jit_cache"))
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     # the library is built in-tree by __graft_entry__.build(); a fresh checkout (the .so is git-ignored) builds it here
