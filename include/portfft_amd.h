@@ -121,8 +121,8 @@ int32_t pfft_desc_layout(const pfft_desc_t* desc, int32_t direction);
 
 /* descriptor::commit(queue) (src/portfft/descriptor.hpp:152-156): validate, plan every dimension, upload
  * twiddles, allocate scratch.  `hip_stream` is a hipStream_t (NULL = default stream) on the current device.
- * Configurations without a pre-compiled kernel are specialised here by hiprtc (0.2-2 s once per process, device and
- * configuration; the reference builds its kernels at commit too: committed_descriptor_impl.hpp:448-573);
+ * Configurations without a pre-compiled kernel are specialised here by hiprtc (0.2-2 s the first time, then cached
+ * in the process and on disk; the reference builds its kernels at commit too: committed_descriptor_impl.hpp:448-573);
  * nothing is compiled or allocated at execute.  Thread-safe; the plan itself is not (one plan per host thread). */
 pfft_status pfft_plan_create(const pfft_desc_t* desc, void* hip_stream, pfft_plan_t** plan);
 /* committed_descriptor_impl::~committed_descriptor_impl (committed_descriptor_impl.hpp:825-828): waits for the
