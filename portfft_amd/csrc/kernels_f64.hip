@@ -20,7 +20,7 @@ const spec_kernel g_spec_f64[] = {
     make_spec_entry<wg_cfg_twl<d, radix_list<16, 16, 8>, 256, 2, 16, 1, 2, NT>>(2),    // 2048
     make_spec_entry<wg_cfg<d, radix_list<16, 16, 16>, 256, 1, 16, 1, TW_REGS, 1, NT>>(1),      // 4096
     make_spec_entry<wg_cfg_twl<d, radix_list<16, 8, 8, 8>, 512, 1, 16, 1, 2, NT>>(1),   // 8192
-    make_spec_entry<wg_cfg_twl<d, radix_list<12, 8>, 256, 32, 0, 0, 2, NT, 1>>(),       // 96
+    make_spec_entry<wg_cfg<d, radix_list<12, 8>, 256, 32, 0, 0, TW_GLOBAL, 2, NT, 1>>(),  // 96 (TWL loses 8 % here)
     make_spec_entry<wg_cfg_twl<d, radix_list<16, 12>, 256, 16, 16, 1, 2, NT>>(),         // 192
     make_spec_entry<wg_cfg_twl<d, radix_list<8, 8, 6>, 256, 4, 16, 1, 2, NT>>(),         // 384
     make_spec_entry<wg_cfg_twl<d, radix_list<16, 8, 6>, 256, 4, 16, 1, 2, NT>>(),        // 768

@@ -114,6 +114,7 @@ int main() {
 #elif TUNE_CASE == 256
   using S = radix_list<16, 16>; using T = f; const int N = 256;
   add<wg_cfg<f, S, 256, 16, 16, 1, TW_GLOBAL, 4, NT>, false>("256 twG fpw16 o4");
+  add<wg_cfg<f, S, 256, 16, 16, 1, TW_GLOBAL, 4, NT, 0, 1>, false>("256 twG fpw16 o4 TWL1");
   add<wg_cfg<f, S, 256, 16, 16, 1, TW_REGS, 4, NT>, false>("256 twR fpw16 o4");
   add<wg_cfg<f, S, 256, 16, 16, 1, TW_GLOBAL, 4, NT, 1>, false>("256 twG fpw16 o4 STAGED");
   add<wg_cfg<f, S, 64, 4, 16, 1, TW_REGS, 4, NT>, false>("256 twR wg64 fpw4 o4");
