@@ -18,9 +18,9 @@ const spec_kernel g_spec_f32[] = {
     make_spec_entry<wg_cfg_twl<f, radix_list<8, 8>, 256, 32, 8, 1, 4, NT, 1>>(),        // 64
     make_spec_entry<wg_cfg_twl<f, radix_list<16, 8>, 256, 32, 16, 1, 4, NT, 1>>(),       // 128
     make_spec_entry<wg_cfg_twl<f, radix_list<16, 16>, 256, 16, 16, 1, 4, NT>>(),         // 256
-    make_spec_entry<wg_cfg<f, radix_list<8, 8, 8>, 256, 4, 16, 1, TW_REGS, 4, NT>>(2),           // 512
+    make_spec_entry<wg_cfg<f, radix_list<8, 8, 8>, 256, 4, 16, 1, TW_GLOBAL, 4, NT, 0, 2>>(2),  // 512 (TWL 2: 6.56 vs 6.40 with TW_REGS)
     make_spec_entry<wg_cfg<f, radix_list<16, 8, 8>, 256, 4, 16, 1, TW_GLOBAL, 4, NT, 0, 2>>(),  // 1024 (TWL 2: tools/tune.hip)
-    make_spec_entry<wg_cfg<f, radix_list<16, 16, 8>, 256, 2, 16, 1, TW_REGS, 4, NT>>(4),        // 2048
+    make_spec_entry<wg_cfg<f, radix_list<16, 16, 8>, 256, 2, 16, 1, TW_GLOBAL, 4, NT, 0, 2>>(2),  // 2048 (TWL 2: 6.03 vs 5.93)
     // the headline shape: register-resident twiddles + software-pipelined loads (3 work-groups per CU)
     make_spec_entry_prefetch<wg_cfg<f, radix_list<16, 16, 16>, 256, 1, 16, 1, TW_REGS, 3, NT>>(4),  // 4096
     make_spec_entry<wg_cfg<f, radix_list<32, 16, 16>, 256, 1, 16, 1, TW_REGS, 2, NT>>(4),       // 8192

@@ -497,6 +497,11 @@ __global__ __launch_bounds__(Cfg::WG, Cfg::OCC) void stockham_wg_prefetch_kernel
     });
   }
 
+  if constexpr (Cfg::TWL > 0) {  // leading twiddle tables behind the images, once per work-group lifetime
+    cx<T>* twl = reinterpret_cast<cx<T>*>(pfa_smem) + Cfg::LDS_ELEMS;
+    for (int i = threadIdx.x; i < Cfg::TWL_ELEMS; i += Cfg::WG) twl[i] = tw[i];
+    __syncthreads();
+  }
   const long long ngroups = (nfft + Cfg::FPW - 1) / Cfg::FPW;
   long long g = blockIdx.x;
   if (g >= ngroups) return;

@@ -56,6 +56,8 @@ int main() {
   using S = radix_list<16, 16, 8>; using T = f; const int N = 2048;
   add<wg_cfg<f, S, 256, 2, 16, 1, TW_GLOBAL, 4, NT>, false>("twG fpw2 o4");
   add<wg_cfg<f, S, 256, 2, 16, 1, TW_REGS, 4, NT>, false>("twR fpw2 o4");
+  add<wg_cfg<f, S, 256, 2, 16, 1, TW_GLOBAL, 4, NT, 0, 1>, false>("twG fpw2 o4 TWL1");
+  add<wg_cfg<f, S, 256, 2, 16, 1, TW_GLOBAL, 4, NT, 0, 2>, false>("twG fpw2 o4 TWL2");
   add<wg_cfg<f, S, 256, 2, 16, 1, TW_REGS, 3, NT>, true>("twR fpw2 o3 PF");
   add<wg_cfg<f, S, 256, 2, 16, 1, TW_GLOBAL, 4, NT>, true>("twG fpw2 o4 PF");
   add<wg_cfg<f, S, 128, 1, 16, 1, TW_REGS, 4, NT>, false>("twR wg128 fpw1 o4");
@@ -72,6 +74,8 @@ int main() {
   using S = radix_list<32, 16, 16>; using T = f; const int N = 8192;
   add<wg_cfg<f, S, 256, 1, 16, 1, TW_GLOBAL, 2, NT>, false>("r32.16.16 twG wg256 o2");
   add<wg_cfg<f, S, 256, 1, 16, 1, TW_REGS, 2, NT>, false>("r32.16.16 twR wg256 o2");
+  add<wg_cfg<f, S, 256, 1, 16, 1, TW_GLOBAL, 2, NT, 0, 1>, false>("r32.16.16 twG TWL1 o2");
+  add<wg_cfg<f, S, 256, 1, 16, 1, TW_GLOBAL, 3, NT, 0, 1>, false>("r32.16.16 twG TWL1 o3");
   add<wg_cfg<f, radix_list<16, 16, 32>, 256, 1, 16, 1, TW_GLOBAL, 2, NT>, false>("r16.16.32 twG wg256 o2");
   add<wg_cfg<f, radix_list<16, 16, 16, 2>, 512, 1, 16, 1, TW_GLOBAL, 4, NT>, false>("r16.16.16.2 twG wg512 o4");
   add<wg_cfg<f, radix_list<8, 8, 8, 16>, 512, 1, 16, 1, TW_GLOBAL, 4, NT>, false>("r8.8.8.16 twG wg512 o4");
@@ -121,7 +125,9 @@ int main() {
 #elif TUNE_CASE == 4096
   using S = radix_list<16, 16, 16>; using T = f; const int N = 4096;
   add<wg_cfg<f, S, 256, 1, 16, 1, TW_REGS, 3, NT>, true>("twR o3 PF (current)");
-  add<wg_cfg<f, S, 256, 1, 16, 1, TW_REGS, 4, NT>, true>("twR o4 PF");
+  add<wg_cfg<f, S, 256, 1, 16, 1, TW_GLOBAL, 4, NT, 0, 1>, false>("twG TWL1 o4");
+  add<wg_cfg<f, S, 256, 1, 16, 1, TW_GLOBAL, 4, NT, 0, 1>, true>("twG TWL1 o4 PF");
+  add<wg_cfg<f, S, 256, 1, 16, 1, TW_GLOBAL, 3, NT, 0, 1>, true>("twG TWL1 o3 PF");
   add<wg_cfg<f, S, 256, 1, 16, 1, TW_REGS, 4, NT>, false>("twR o4");
   add<wg_cfg<f, S, 256, 1, 16, 1, TW_GLOBAL, 4, NT>, true>("twG o4 PF");
   add<wg_cfg<f, S, 256, 1, 16, 1, TW_GLOBAL, 4, NT>, false>("twG o4");
@@ -160,6 +166,7 @@ int main() {
   using S = radix_list<8, 8, 8>; using T = f; const int N = 512;
   add<wg_cfg<f, S, 256, 4, 16, 1, TW_GLOBAL, 4, NT>, false>("twG fpw4 o4");
   add<wg_cfg<f, S, 256, 4, 16, 1, TW_REGS, 4, NT>, false>("twR fpw4 o4");
+  add<wg_cfg<f, S, 256, 4, 16, 1, TW_GLOBAL, 4, NT, 0, 2>, false>("twG fpw4 o4 TWL2");
   add<wg_cfg<f, S, 256, 4, 16, 1, TW_REGS, 4, NT>, true>("twR fpw4 o4 PF");
   add<wg_cfg<f, radix_list<32, 16>, 256, 16, 16, 1, TW_GLOBAL, 2, NT>, false>("r32x16 twG fpw16 o2");
   add<wg_cfg<f, radix_list<16, 32>, 256, 16, 16, 1, TW_GLOBAL, 2, NT>, false>("r16x32 twG fpw16 o2");
