@@ -91,6 +91,8 @@ int main() {
   add<wg_cfg<d, S, 256, 1, 16, 1, TW_GLOBAL, 2, NT>, false>("f64 twG o2");
   add<wg_cfg<d, S, 256, 1, 16, 1, TW_GLOBAL, 1, NT>, true>("f64 twG o1 PF");
   add<wg_cfg<d, S, 256, 1, 16, 1, TW_REGS, 1, NT>, false>("f64 twR o1");
+  add<wg_cfg<d, S, 256, 1, 16, 1, TW_GLOBAL, 2, NT, 0, 1>, false>("f64 twG TWL1 o2");
+  add<wg_cfg<d, S, 256, 1, 16, 1, TW_GLOBAL, 2, NT, 0, 1>, true>("f64 twG TWL1 o2 PF");
   add<wg_cfg<d, radix_list<8, 8, 8, 8>, 512, 1, 16, 1, TW_GLOBAL, 2, NT>, false>("f64 r8x4 wg512 o2");
 #elif TUNE_CASE == 16385
   using S = radix_list<32, 32, 16>; using T = f; const int N = 16384;
@@ -112,6 +114,8 @@ int main() {
 #elif TUNE_CASE == 8192064
   using S = radix_list<16, 16, 16, 2>; using T = d; const int N = 8192;
   add<wg_cfg<d, S, 512, 1, 16, 1, TW_GLOBAL, 2, NT>, false>("f64 8192 r16.16.16.2 twG wg512");
+  add<wg_cfg<d, radix_list<16, 8, 8, 8>, 512, 1, 16, 1, TW_GLOBAL, 2, NT, 0, 2>, false>("f64 8192 r16.8.8.8 TWL2 wg512");
+  add<wg_cfg<d, radix_list<16, 8, 8, 8>, 512, 1, 16, 1, TW_GLOBAL, 2, NT, 0, 1>, false>("f64 8192 r16.8.8.8 TWL1 wg512");
   add<wg_cfg<d, radix_list<32, 16, 16>, 256, 1, 16, 1, TW_GLOBAL, 1, NT>, false>("f64 8192 r32.16.16 twG wg256 o1");
   add<wg_cfg<d, radix_list<32, 16, 16>, 256, 1, 0, 0, TW_GLOBAL, 1, NT>, false>("f64 8192 r32.16.16 twG wg256 nopad");
   add<wg_cfg<d, radix_list<16, 8, 8, 8>, 512, 1, 16, 1, TW_GLOBAL, 2, NT>, false>("f64 8192 r16.8.8.8 twG wg512");
