@@ -433,7 +433,7 @@ struct plan_t {
   /// largest length the generic tier can hold (two LDS images)
   long long generic_max_n() const { return static_cast<long long>(max_lds / (2 * elem_bytes())); }
 
-  /// Grid of a persistent kernel.  Measured on the N=4096 kernel (tools/proto_c2.hip, interleaved rounds): a grid of
+  /// Grid of a persistent kernel.  Measured on the N=4096 kernel (tools/probes/proto_c2.hip, interleaved rounds): a grid of
   /// 1-2x the resident work-groups keeps every work-group in lock-step (all load, then all compute) and loses ~5 %
   /// against a grid where each work-group handles only `groups_per_wg` groups (4-5 is the optimum when the kernel
   /// pre-loads its twiddles into registers, 1 when it re-reads them per FFT): staggered work-group start times smooth

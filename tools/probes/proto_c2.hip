@@ -1,7 +1,7 @@
 // Stand-alone kernel exploration harness (not part of the product, not used by tests or bench.py):
 // times copy kernels (the achievable-HBM yardstick) and work-group FFT kernel variants on the C2 shape
 // (fp32, N=4096, batch 65536) and checks a few batches against a double-precision DFT on the host.
-//   hipcc -O3 --offload-arch=gfx950 -std=c++17 tools/proto_c2.hip -o tools/proto_c2 && tools/proto_c2
+//   hipcc -O3 --offload-arch=gfx950 -std=c++17 tools/probes/proto_c2.hip -o tools/probes/proto_c2 && tools/proto_c2
 #include <hip/hip_runtime.h>
 
 #include <cmath>

@@ -7,7 +7,7 @@ figure used by bench.py's roofline.traffic.
 Units and corrections follow /opt/skills/guides/MI355X_MICROARCH.md (HBM section): both counters are in KiB;
 on gfx950 FETCH_SIZE reports exactly half of the bytes of a coalesced streaming read, WRITE_SIZE is exact.  The
 halving is re-checked here on a calibration kernel with a known byte count and the FFT kernel's own access shape
-(tools/copy_sweep2.hip: 32 KiB rows, 8 B per lane): cal_* directories.
+(tools/probes/copy_sweep2.hip: 32 KiB rows, 8 B per lane): cal_* directories.
 """
 import collections
 import csv

@@ -1,0 +1,108 @@
+// Scratch tuner for the strided kernel on the C3 stage-A shape (fp64, 128 matrices of 1024 x 1024, column FFTs)
+// and the C5 column pass (fp32, 256 matrices 1024 x 1024).
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <functional>
+#include <string>
+#include <vector>
+#include "../portfft_amd/csrc/stockham_strided.hpp"
+using namespace pfa;
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s line %d\n", hipGetErrorString(e_), __LINE__); exit(1);} } while (0)
+template <typename Seq, typename T>
+std::vector<cx<T>> make_twiddles() {
+  std::vector<cx<T>> tw(Seq::tw_total > 0 ? Seq::tw_total : 1);
+  for (int p = 1; p < Seq::count; ++p) {
+    const int R = Seq::r[p], Ns = Seq::ns(p);
+    for (int t = 1; t < R; ++t) for (int q = 0; q < Ns; ++q) {
+      const long double a = -2.0L * 3.14159265358979323846264338327950288L * (long double)(t * q) / (long double)(Ns * R);
+      tw[Seq::tw_off(p) + (t - 1) * Ns + q] = {(T)cosl(a), (T)sinl(a)};
+    }
+  }
+  return tw;
+}
+struct variant { std::string name; int fpw; int wg; size_t lds; const void* fn; std::function<void(unsigned)> launch; };
+static std::vector<variant> g_variants;
+static void *g_in, *g_out;
+static long long g_total, g_inner, g_dist_outer; static unsigned g_stride; static int g_tiled = 0;
+
+template <typename Cfg, int KIND>
+void add(const char* name) {
+  using T = typename Cfg::T;
+  auto tw = make_twiddles<typename Cfg::Seq, T>();
+  cx<T>* d_tw; CK(hipMalloc(&d_tw, tw.size() * sizeof(cx<T>)));
+  CK(hipMemcpy(d_tw, tw.data(), tw.size() * sizeof(cx<T>), hipMemcpyHostToDevice));
+  const void* fn;
+  if constexpr (KIND == 1) fn = (const void*)&stockham_strided_prefetch_kernel<Cfg, false, false>;
+  else fn = (const void*)&stockham_strided_kernel<Cfg, false, false>;
+  constexpr size_t lds = strided_lds_bytes<Cfg>();
+  CK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  g_variants.push_back({name, Cfg::FPW, Cfg::WG, lds, fn, [d_tw](unsigned grid) {
+    strided_args a{};
+    a.in = g_in; a.out = g_out; a.tw = d_tw; a.total = g_total; a.inner = g_inner;
+    a.in_dist_outer = a.out_dist_outer = g_dist_outer; a.in_stride = a.out_stride = g_stride; a.in_fdist = a.out_fdist = 1; a.scale = 1.0;
+    if (g_tiled & 1) { a.in_gdist = (long long)Cfg::N * Cfg::FPW; a.in_stride = Cfg::FPW; }
+    if (g_tiled & 2) { a.out_gdist = (long long)Cfg::N * Cfg::FPW; a.out_stride = Cfg::FPW; }
+    if constexpr (KIND == 1) hipLaunchKernelGGL((stockham_strided_prefetch_kernel<Cfg, false, false>), dim3(grid), dim3(Cfg::WG), lds, 0, a);
+    else hipLaunchKernelGGL((stockham_strided_kernel<Cfg, false, false>), dim3(grid), dim3(Cfg::WG), lds, 0, a);
+  }});
+}
+
+int main() {
+  const size_t bytes = (size_t)2 << 30;
+  CK(hipMalloc(&g_in, bytes)); CK(hipMalloc(&g_out, bytes)); CK(hipMemset(g_in, 0x3c, bytes));
+  hipDeviceProp_t prop; CK(hipGetDeviceProperties(&prop, 0)); const int cus = prop.multiProcessorCount;
+  using f = float; using d = double; constexpr int NT = 2;
+#if TUNE_CASE == 3
+  using T = d; g_stride = 1024; g_inner = 1024; g_dist_outer = 1 << 20; g_total = 128 * 1024;
+  add<wg_cfg<d, radix_list<16, 8, 8>, 512, 8, 0, 0, TW_GLOBAL, 2, NT>, 0>("f64 16.8.8 wg512 fpw8");
+  add<wg_cfg<d, radix_list<16, 8, 8>, 512, 8, 0, 0, TW_GLOBAL, 2, NT, 0, 1>, 0>("f64 16.8.8 wg512 fpw8 TWL1");
+  add<wg_cfg<d, radix_list<16, 8, 8>, 512, 8, 0, 0, TW_GLOBAL, 2, NT, 0, 2>, 0>("f64 16.8.8 wg512 fpw8 TWL2");
+  add<wg_cfg<d, radix_list<16, 8, 8>, 512, 8, 0, 0, TW_GLOBAL, 1, NT>, 1>("f64 16.8.8 wg512 fpw8 PF");
+  add<wg_cfg<d, radix_list<32, 32>, 256, 8, 0, 0, TW_GLOBAL, 1, NT>, 0>("f64 32.32 wg256 fpw8");
+  add<wg_cfg<d, radix_list<32, 32>, 256, 8, 0, 0, TW_GLOBAL, 1, NT>, 1>("f64 32.32 wg256 fpw8 PF");
+  add<wg_cfg<d, radix_list<16, 8, 8>, 256, 4, 0, 0, TW_GLOBAL, 2, NT>, 0>("f64 16.8.8 wg256 fpw4");
+  add<wg_cfg<d, radix_list<16, 8, 8>, 256, 4, 0, 0, TW_GLOBAL, 2, NT>, 1>("f64 16.8.8 wg256 fpw4 PF");
+  add<wg_cfg<d, radix_list<16, 8, 8>, 1024, 8, 0, 0, TW_GLOBAL, 4, NT>, 0>("f64 16.8.8 wg1024(8pt) fpw8");
+#else
+  using T = f; g_stride = 1024; g_inner = 1024; g_dist_outer = 1 << 20; g_total = 256 * 1024;
+  add<wg_cfg<f, radix_list<16, 8, 8>, 1024, 16, 0, 0, TW_GLOBAL, 4, NT>, 0>("f32 16.8.8 wg1024 fpw16");
+  add<wg_cfg<f, radix_list<16, 8, 8>, 1024, 16, 0, 0, TW_GLOBAL, 2, NT>, 1>("f32 16.8.8 wg1024 fpw16 PF");
+  add<wg_cfg<f, radix_list<32, 32>, 512, 16, 0, 0, TW_GLOBAL, 2, NT>, 0>("f32 32.32 wg512 fpw16");
+  add<wg_cfg<f, radix_list<32, 32>, 512, 16, 0, 0, TW_GLOBAL, 2, NT>, 1>("f32 32.32 wg512 fpw16 PF");
+  add<wg_cfg<f, radix_list<32, 32>, 512, 16, 0, 0, TW_GLOBAL, 2, NT, 0, 1>, 1>("f32 32.32 wg512 fpw16 PF TWL1");
+  add<wg_cfg<f, radix_list<16, 8, 8>, 1024, 16, 0, 0, TW_GLOBAL, 4, NT, 0, 2>, 0>("f32 16.8.8 wg1024 fpw16 TWL2");
+  add<wg_cfg<f, radix_list<16, 8, 8>, 512, 8, 0, 0, TW_GLOBAL, 4, NT>, 0>("f32 16.8.8 wg512 fpw8");
+  add<wg_cfg<f, radix_list<16, 8, 8>, 512, 8, 0, 0, TW_GLOBAL, 2, NT>, 1>("f32 16.8.8 wg512 fpw8 PF");
+#endif
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  struct gridopt { const char* name; int mode; int k; };
+  const gridopt gopts[] = {{"1xres", 0, 1}, {"2xres", 0, 2}, {"4xres", 0, 4}, {"grp/4", 1, 4}, {"grp/2", 1, 2}, {"grp/1", 1, 1}};
+  const int NGO = 6;
+  std::vector<std::vector<std::vector<float>>> times(g_variants.size(), std::vector<std::vector<float>>(NGO));
+  for (g_tiled = 0; g_tiled < 1; ++g_tiled) {
+  for (auto& t : times) for (auto& u : t) u.clear();
+  printf("---- tiled input %d, tiled output %d\n", g_tiled & 1, (g_tiled >> 1) & 1);
+  for (int round = 0; round < 5; ++round)
+    for (size_t v = 0; v < g_variants.size(); ++v) {
+      int occ = 0; CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, g_variants[v].fn, g_variants[v].wg, g_variants[v].lds));
+      const long long groups = g_total / g_variants[v].fpw;
+      for (int go = 0; go < NGO; ++go) {
+        long long grid = gopts[go].mode == 0 ? (long long)gopts[go].k * std::max(occ, 1) * cus : (groups + gopts[go].k - 1) / gopts[go].k;
+        grid = std::max<long long>(1, std::min(grid, groups));
+        CK(hipEventRecord(e0)); g_variants[v].launch((unsigned)grid); CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        if (round) times[v][go].push_back(ms);
+      }
+    }
+  CK(hipGetLastError());
+  for (size_t v = 0; v < g_variants.size(); ++v) {
+    int occ = 0; CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, g_variants[v].fn, g_variants[v].wg, g_variants[v].lds));
+    printf("%-30s occ=%d lds=%-6zu", g_variants[v].name.c_str(), occ, g_variants[v].lds);
+    for (int go = 0; go < NGO; ++go) { auto t = times[v][go]; std::sort(t.begin(), t.end()); printf("  %s %.2f", gopts[go].name, 2.0 * bytes / t[t.size() / 2] * 1e-9); }
+    printf("  TB/s\n");
+  }
+  }
+  return 0;
+}
