@@ -5,8 +5,9 @@
 //   portfft::committed_descriptor<Scalar, Domain> (/root/reference/src/portfft/committed_descriptor.hpp:46-315)
 //   enums                                          (/root/reference/src/portfft/enums.hpp:25-38)
 //   exceptions                                     (/root/reference/src/portfft/common/exceptions.hpp:32-77)
-// with these substitutions: sycl::queue -> portfft::queue (a HIP stream), sycl::event -> portfft::event (stream-
-// ordered completion; wait() blocks), USM pointers -> HIP device pointers.  sycl::buffer overloads do not exist
+// with these substitutions: sycl::queue -> portfft::queue (a HIP stream), sycl::event -> portfft::event (a hipEvent_t
+// recorded behind the submission: per-call completion, usable as a dependency of later calls), USM pointers -> HIP
+// device pointers.  sycl::buffer overloads do not exist
 // (HIP has no buffer/accessor model).  Link with -lportfft_amd.
 #ifndef PORTFFT_PORTFFT_HPP
 #define PORTFFT_PORTFFT_HPP
@@ -82,29 +83,70 @@ inline std::vector<std::size_t> get_default_strides(const std::vector<std::size_
 }
 }  // namespace detail
 
-/// Stands where the reference takes a sycl::queue: an in-order HIP stream (nullptr = the default stream).
+template <typename Scalar, domain Domain>
+class committed_descriptor;
+class queue;
+
+/// Stands where the reference returns a sycl::event: the completion of ONE submission.  Owns a hipEvent_t recorded
+/// on the plan's stream behind the last kernel of the compute_* call that returned it; copies share it.  wait()
+/// blocks the host until that submission has finished (hipEventSynchronize); passing the event in another call's
+/// `dependencies` orders that call behind it on the device (hipStreamWaitEvent), also across streams.  A
+/// default-constructed event is already complete.  native() is the hipEvent_t for direct HIP interop.
+class event {
+ public:
+  event() = default;
+  void wait() const {
+    if (ev_) detail::check(pfft_event_wait(ev_.get()));
+  }
+  /// sycl::event::wait_and_throw(): errors surface as exceptions from wait() already
+  void wait_and_throw() const { wait(); }
+  /// true once the submission has finished (info::event_command_status::complete in the reference's world)
+  bool is_complete() const {
+    int32_t done = 1;
+    if (ev_) detail::check(pfft_event_query(ev_.get(), &done));
+    return done != 0;
+  }
+  void* native() const { return ev_.get(); }
+  /// sycl::event::wait(const std::vector<event>&)
+  static void wait(const std::vector<event>& events) {
+    for (const event& e : events) e.wait();
+  }
+
+ private:
+  template <typename S, domain D>
+  friend class committed_descriptor;
+  friend class queue;
+  explicit event(void* hip_event) : ev_(hip_event, [](void* e) { (void)pfft_event_destroy(e); }) {}
+  std::shared_ptr<void> ev_;
+};
+
+/// Stands where the reference takes a sycl::queue: an in-order HIP stream (nullptr = the default stream).  copy()
+/// and wait() are the two queue members the reference's own callers use around compute_* (test/unit_test/
+/// fft_test_utils.hpp:286-333, test/bench/portfft/launch_bench.hpp:96-135).
 class queue {
  public:
   queue() = default;
   explicit queue(void* hip_stream) : stream_(hip_stream) {}
   void* native() const { return stream_; }
 
+  /// sycl::queue::copy(src, dest, count, dependencies): asynchronous on this stream, any combination of host and
+  /// device pointers; the returned event completes with the copy
+  template <typename T>
+  event copy(const T* src, T* dest, std::size_t count, const std::vector<event>& dependencies = {}) {
+    std::vector<void*> deps;
+    deps.reserve(dependencies.size());
+    for (const event& e : dependencies) deps.push_back(e.native());
+    void* ev = nullptr;
+    detail::check(pfft_queue_copy(stream_, src, dest, count * sizeof(T), static_cast<int32_t>(deps.size()), deps.data(),
+                                  &ev));
+    return event(ev);
+  }
+  /// sycl::queue::wait() / wait_and_throw()
+  void wait() const { detail::check(pfft_queue_wait(stream_)); }
+  void wait_and_throw() const { wait(); }
+
  private:
   void* stream_ = nullptr;
-};
-
-/// Stands where the reference returns a sycl::event.  Work is ordered on the plan's stream; wait() blocks until
-/// everything enqueued so far on that stream has finished.
-class event {
- public:
-  event() = default;
-  explicit event(std::shared_ptr<pfft_plan_t> plan) : plan_(std::move(plan)) {}
-  void wait() const {
-    if (plan_) detail::check(pfft_plan_wait(plan_.get()));
-  }
-
- private:
-  std::shared_ptr<pfft_plan_t> plan_;
 };
 
 template <typename Scalar, domain Domain>
@@ -116,57 +158,108 @@ class committed_descriptor {
   friend struct descriptor<Scalar, Domain>;
   std::shared_ptr<pfft_plan_t> plan_;
 
+  static std::shared_ptr<pfft_plan_t> own(pfft_plan_t* p) {
+    return std::shared_ptr<pfft_plan_t>(p, [](pfft_plan_t* x) { (void)pfft_plan_destroy(x); });
+  }
+
   committed_descriptor(const pfft_desc_t& d, queue& q) {
     pfft_plan_t* p = nullptr;
     detail::check(pfft_plan_create(&d, q.native(), &p));
-    plan_ = std::shared_ptr<pfft_plan_t>(p, [](pfft_plan_t* x) { (void)pfft_plan_destroy(x); });
+    plan_ = own(p);
   }
 
-  event run(direction dir, const void* in, void* out) {
-    detail::check(pfft_execute(plan_.get(), static_cast<int32_t>(dir), in, out));
-    return event(plan_);
+  static std::vector<void*> natives(const std::vector<event>& dependencies) {
+    std::vector<void*> deps;
+    deps.reserve(dependencies.size());
+    for (const event& e : dependencies) deps.push_back(e.native());
+    return deps;
   }
-  event run_split(direction dir, const void* ir, const void* ii, void* outr, void* outi) {
-    detail::check(pfft_execute_split(plan_.get(), static_cast<int32_t>(dir), ir, ii, outr, outi));
-    return event(plan_);
+
+  event run(direction dir, const void* in, void* out, const std::vector<event>& dependencies) {
+    const std::vector<void*> deps = natives(dependencies);
+    void* ev = nullptr;
+    detail::check(pfft_execute_ex(plan_.get(), static_cast<int32_t>(dir), in, out, static_cast<int32_t>(deps.size()),
+                                  deps.data(), &ev));
+    return event(ev);
+  }
+  event run_split(direction dir, const void* ir, const void* ii, void* outr, void* outi,
+                  const std::vector<event>& dependencies) {
+    const std::vector<void*> deps = natives(dependencies);
+    void* ev = nullptr;
+    detail::check(pfft_execute_split_ex(plan_.get(), static_cast<int32_t>(dir), ir, ii, outr, outi,
+                                        static_cast<int32_t>(deps.size()), deps.data(), &ev));
+    return event(ev);
   }
 
  public:
   using complex_type = std::complex<Scalar>;
   using scalar_type = Scalar;
 
-  // dependencies are expressed by stream order; the vector overloads of the reference take explicit events
-  // (committed_descriptor.hpp:171-310), here callers enqueue on the same stream or wait() first.
+  /// Copies share the kernels and twiddle tables and get scratch memory of their own, like the reference's
+  /// (committed_descriptor_impl.hpp:774-817): two copies can execute concurrently on two host threads / streams.
+  committed_descriptor(const committed_descriptor& other) {
+    pfft_plan_t* p = nullptr;
+    detail::check(pfft_plan_clone(other.plan_.get(), &p));
+    plan_ = own(p);
+  }
+  committed_descriptor& operator=(const committed_descriptor& other) {
+    if (this != &other) {
+      pfft_plan_t* p = nullptr;
+      detail::check(pfft_plan_clone(other.plan_.get(), &p));
+      plan_ = own(p);
+    }
+    return *this;
+  }
+  committed_descriptor(committed_descriptor&&) noexcept = default;
+  committed_descriptor& operator=(committed_descriptor&&) noexcept = default;
+
+  // Signatures of the USM overloads follow committed_descriptor.hpp:171-310 argument for argument:
+  // `dependencies` are events that must complete before the computation starts; the returned event completes with
+  // this computation.
 
   /// in-place, interleaved (committed_descriptor.hpp:171-176 / 215-218)
-  event compute_forward(complex_type* inout) { return run(direction::FORWARD, inout, inout); }
-  event compute_backward(complex_type* inout) { return run(direction::BACKWARD, inout, inout); }
-  /// in-place, split (committed_descriptor.hpp:186-192 / 228-232)
-  event compute_forward(scalar_type* inout_real, scalar_type* inout_imag) {
-    return run_split(direction::FORWARD, inout_real, inout_imag, inout_real, inout_imag);
+  event compute_forward(complex_type* inout, const std::vector<event>& dependencies = {}) {
+    return run(direction::FORWARD, inout, inout, dependencies);
   }
-  event compute_backward(scalar_type* inout_real, scalar_type* inout_imag) {
-    return run_split(direction::BACKWARD, inout_real, inout_imag, inout_real, inout_imag);
+  event compute_backward(complex_type* inout, const std::vector<event>& dependencies = {}) {
+    return run(direction::BACKWARD, inout, inout, dependencies);
+  }
+  /// in-place, split (committed_descriptor.hpp:186-192 / 228-232)
+  event compute_forward(scalar_type* inout_real, scalar_type* inout_imag,
+                        const std::vector<event>& dependencies = {}) {
+    return run_split(direction::FORWARD, inout_real, inout_imag, inout_real, inout_imag, dependencies);
+  }
+  event compute_backward(scalar_type* inout_real, scalar_type* inout_imag,
+                         const std::vector<event>& dependencies = {}) {
+    return run_split(direction::BACKWARD, inout_real, inout_imag, inout_real, inout_imag, dependencies);
   }
   /// out-of-place, interleaved (committed_descriptor.hpp:242-246 / 288-293)
-  event compute_forward(const complex_type* in, complex_type* out) { return run(direction::FORWARD, in, out); }
-  event compute_backward(const complex_type* in, complex_type* out) { return run(direction::BACKWARD, in, out); }
+  event compute_forward(const complex_type* in, complex_type* out, const std::vector<event>& dependencies = {}) {
+    return run(direction::FORWARD, in, out, dependencies);
+  }
+  event compute_backward(const complex_type* in, complex_type* out, const std::vector<event>& dependencies = {}) {
+    return run(direction::BACKWARD, in, out, dependencies);
+  }
   /// out-of-place, split (committed_descriptor.hpp:258-263 / 305-310)
   event compute_forward(const scalar_type* in_real, const scalar_type* in_imag, scalar_type* out_real,
-                        scalar_type* out_imag) {
-    return run_split(direction::FORWARD, in_real, in_imag, out_real, out_imag);
+                        scalar_type* out_imag, const std::vector<event>& dependencies = {}) {
+    return run_split(direction::FORWARD, in_real, in_imag, out_real, out_imag, dependencies);
   }
   event compute_backward(const scalar_type* in_real, const scalar_type* in_imag, scalar_type* out_real,
-                         scalar_type* out_imag) {
-    return run_split(direction::BACKWARD, in_real, in_imag, out_real, out_imag);
+                         scalar_type* out_imag, const std::vector<event>& dependencies = {}) {
+    return run_split(direction::BACKWARD, in_real, in_imag, out_real, out_imag, dependencies);
   }
   /// real-to-complex entry points exist in the reference only to throw (committed_descriptor.hpp:134-137,273-278)
-  event compute_forward(const scalar_type*, complex_type*) {
+  event compute_forward(const scalar_type*, complex_type*, const std::vector<event>& = {}) {
     throw unsupported_configuration("Real to complex FFTs not yet implemented.");
   }
-  event compute_backward(const complex_type*, scalar_type*) {
+  event compute_backward(const complex_type*, scalar_type*, const std::vector<event>& = {}) {
     throw unsupported_configuration("Complex to real FFTs not yet implemented.");
   }
+
+  /// queue.wait() of the reference's callers: everything submitted on the plan's stream has finished
+  void wait() const { detail::check(pfft_plan_wait(plan_.get())); }
+
 
   pfft_plan_info_t info() const {
     pfft_plan_info_t i{};

@@ -139,7 +139,31 @@ pfft_status pfft_execute(pfft_plan_t* plan, int32_t direction, const void* in, v
 /* Split-complex USM overloads (src/portfft/committed_descriptor.hpp:186-192, 228-232, 258-263, 305-310). */
 pfft_status pfft_execute_split(pfft_plan_t* plan, int32_t direction, const void* in_real, const void* in_imag,
                                void* out_real, void* out_imag);
-/* sycl::event::wait() on the returned event: blocks until everything queued on the plan's stream is done. */
+/* The same overloads with the reference's `const std::vector<sycl::event>& dependencies` argument and its returned
+ * sycl::event (src/portfft/committed_descriptor.hpp:171, 215, 242-246, 288-293; split twins 186-192, 228-232,
+ * 258-263, 305-310).  `deps` is an array of `n_deps` hipEvent_t handles (as void*; NULL entries are skipped): the
+ * plan's stream waits for each of them (hipStreamWaitEvent) before the first kernel.  When `event_out` is not NULL
+ * it receives a fresh hipEvent_t recorded behind the last kernel of THIS submission; the caller owns it
+ * (pfft_event_wait / pfft_event_query / pfft_event_destroy, or any HIP call that takes a hipEvent_t). */
+pfft_status pfft_execute_ex(pfft_plan_t* plan, int32_t direction, const void* in, void* out, int32_t n_deps,
+                            void* const* deps, void** event_out);
+pfft_status pfft_execute_split_ex(pfft_plan_t* plan, int32_t direction, const void* in_real, const void* in_imag,
+                                  void* out_real, void* out_imag, int32_t n_deps, void* const* deps,
+                                  void** event_out);
+/* sycl::event::wait() / get_info<command_execution_status>() / destruction of an event returned by the _ex calls. */
+pfft_status pfft_event_wait(void* event);
+pfft_status pfft_event_query(void* event, int32_t* done);
+pfft_status pfft_event_destroy(void* event);
+/* committed_descriptor's copy constructor / copy assignment (committed_descriptor_impl.hpp:774-817): the copy shares
+ * the kernels and twiddle tables and gets scratch buffers of its own. */
+pfft_status pfft_plan_clone(const pfft_plan_t* plan, pfft_plan_t** copy);
+/* sycl::queue::copy(src, dest, count, dependencies) and sycl::queue::wait() as the reference's callers use them around
+ * compute_* (test/unit_test/fft_test_utils.hpp:286-333, test/bench/portfft/launch_bench.hpp:96-135): an asynchronous
+ * copy of `bytes` bytes on `hip_stream` (host or device pointers) behind `deps`, with its own completion event. */
+pfft_status pfft_queue_copy(void* hip_stream, const void* src, void* dst, size_t bytes, int32_t n_deps,
+                            void* const* deps, void** event_out);
+pfft_status pfft_queue_wait(void* hip_stream);
+/* Blocks until everything queued on the plan's stream is done (queue.wait() of the reference's destructor path). */
 pfft_status pfft_plan_wait(pfft_plan_t* plan);
 
 /* ---- misc ----------------------------------------------------------------------------------------------------- */

@@ -12,6 +12,7 @@ src/portfft/committed_descriptor.hpp) on top of the C ABI of include/portfft_amd
 from .api import (  # noqa: F401
     base_error,
     committed_descriptor,
+    event,
     complex_storage,
     descriptor,
     direction,
@@ -28,7 +29,7 @@ from .api import (  # noqa: F401
 )
 
 __all__ = [
-    "descriptor", "committed_descriptor", "domain", "complex_storage", "placement", "direction", "layout", "inv",
+    "descriptor", "committed_descriptor", "event", "domain", "complex_storage", "placement", "direction", "layout", "inv",
     "base_error", "internal_error", "invalid_configuration", "unsupported_configuration",
     "out_of_local_memory_error", "hip_error", "version",
 ]

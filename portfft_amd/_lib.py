@@ -71,6 +71,17 @@ SYMBOLS = {
     "pfft_plan_get_info": (C.c_int, [C.c_void_p, C.POINTER(pfft_plan_info_t)]),
     "pfft_execute": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
     "pfft_execute_split": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "pfft_execute_ex": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_void_p),
+                                  C.POINTER(C.c_void_p)]),
+    "pfft_execute_split_ex": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                        C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
+    "pfft_event_wait": (C.c_int, [C.c_void_p]),
+    "pfft_event_query": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32)]),
+    "pfft_event_destroy": (C.c_int, [C.c_void_p]),
+    "pfft_queue_copy": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int32, C.POINTER(C.c_void_p),
+                                  C.POINTER(C.c_void_p)]),
+    "pfft_queue_wait": (C.c_int, [C.c_void_p]),
+    "pfft_plan_clone": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
     "pfft_plan_wait": (C.c_int, [C.c_void_p]),
     "pfft_last_error": (C.c_char_p, []),
     "pfft_status_string": (C.c_char_p, [C.c_int]),

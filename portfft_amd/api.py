@@ -205,49 +205,152 @@ def _is_complex(x):
     return bool(f()) if callable(f) else False
 
 
+class event:
+    """sycl::event of the reference: the completion of ONE compute_* submission (a hipEvent_t recorded behind its last
+    kernel).  wait() blocks the host; pass it in another call's `dependencies` to order that call behind it."""
+
+    def __init__(self, handle=None, plan=None):
+        self._h = handle
+        self._plan = plan  # keeps the plan alive; wait() on an event-less submission falls back to the stream
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            lib.pfft_event_destroy(h)
+
+    @property
+    def native(self):
+        return self._h
+
+    def wait(self):
+        if self._h:
+            _check(lib.pfft_event_wait(self._h))
+        elif self._plan is not None:
+            self._plan.wait()
+        return self
+
+    def is_complete(self):
+        if not self._h:
+            return True
+        done = C.c_int32(1)
+        _check(lib.pfft_event_query(self._h, C.byref(done)))
+        return bool(done.value)
+
+
+def _dep_handle(d):
+    """hipEvent_t of a dependency: an `event`, a torch.cuda.Event or a raw handle"""
+    if isinstance(d, event):
+        return d.native
+    if hasattr(d, "cuda_event"):
+        return int(d.cuda_event)
+    return int(d) if d else None
+
+
 class committed_descriptor:
     """portfft::committed_descriptor<Scalar, Domain> (committed_descriptor.hpp:46-315)."""
 
-    def __init__(self, desc, queue=None):
+    def __init__(self, desc, queue=None, _clone_of=None):
         self._plan = C.c_void_p()
         self.params = desc
-        c = desc._c()
-        _check(lib.pfft_plan_create(C.byref(c), C.c_void_p(_stream_handle(queue)), C.byref(self._plan)))
+        if _clone_of is not None:
+            _check(lib.pfft_plan_clone(_clone_of._plan, C.byref(self._plan)))
+        else:
+            c = desc._c()
+            _check(lib.pfft_plan_create(C.byref(c), C.c_void_p(_stream_handle(queue)), C.byref(self._plan)))
+        self._device = None
+        try:
+            import torch
+            if torch.cuda.is_available():
+                self._device = torch.cuda.current_device()
+        except ImportError:
+            pass
 
     def __del__(self):
         plan, self._plan = getattr(self, "_plan", None), None
         if plan:
             lib.pfft_plan_destroy(plan)
 
+    def copy(self):
+        """the reference's copy constructor (committed_descriptor_impl.hpp:774-817): shares kernels and twiddles,
+        owns its scratch"""
+        return committed_descriptor(self.params, _clone_of=self)
+
+    __copy__ = copy
+
     def info(self):
         out = _lib.pfft_plan_info_t()
         _check(lib.pfft_plan_get_info(self._plan, C.byref(out)))
         return out
 
-    def _compute(self, dir, args):
+    def _check_buffer(self, x, count, split_plane, what):
+        """a torch tensor handed to compute_* must live on the plan's device, have the descriptor's element type, be
+        contiguous and cover the descriptor's element count (raw pointers cannot be checked)"""
+        if not hasattr(x, "data_ptr") or not hasattr(x, "is_cuda"):
+            return
+        import torch
+        if not x.is_cuda:
+            raise invalid_configuration("%s: the buffer is not in device memory" % what)
+        if self._device is not None and x.device.index != self._device:
+            raise invalid_configuration("%s: the buffer lives on device %s, the plan was committed on device %d"
+                                        % (what, x.device.index, self._device))
+        f64 = self.params.scalar == "f64"
+        if split_plane:
+            want, unit = (torch.float64 if f64 else torch.float32), 1
+            ok = x.dtype == want
+        else:
+            want = torch.complex128 if f64 else torch.complex64
+            real = torch.float64 if f64 else torch.float32
+            ok = x.dtype in (want, real)  # a real view of interleaved data counts two scalars per element
+            unit = 2 if x.dtype == real else 1
+        if not ok:
+            raise invalid_configuration("%s: dtype %s does not match the descriptor (%s %s storage)"
+                                        % (what, x.dtype, self.params.scalar,
+                                           "split" if split_plane else "interleaved"))
+        if not x.is_contiguous():
+            raise invalid_configuration("%s: the buffer must be contiguous" % what)
+        if x.numel() < count * unit:
+            raise invalid_configuration("%s: %d elements, the descriptor addresses %d" % (what, x.numel() // unit, count))
+
+    def _compute(self, dir, args, dependencies=None, want_event=True):
         n = len(args)
+        split = self.params.complex_storage == complex_storage.SPLIT_COMPLEX
+        n_in, n_out = self.params.get_input_count(dir), self.params.get_output_count(dir)
+        deps = [h for h in (_dep_handle(d) for d in (dependencies or [])) if h]
+        dep_arr = (C.c_void_p * max(len(deps), 1))(*deps)
+        ev = C.c_void_p()
+        ev_ref = C.byref(ev) if want_event else None
         if n == 1:  # in-place interleaved (committed_descriptor.hpp:171-176, 215-218)
-            _check(lib.pfft_execute(self._plan, int(dir), _ptr(args[0]), _ptr(args[0])))
-        elif n == 2 and self.params.complex_storage == complex_storage.SPLIT_COMPLEX and not _is_complex(args[0]):
+            self._check_buffer(args[0], max(n_in, n_out), False, "inout")
+            _check(lib.pfft_execute_ex(self._plan, int(dir), _ptr(args[0]), _ptr(args[0]), len(deps), dep_arr, ev_ref))
+        elif n == 2 and split and not _is_complex(args[0]):
             # in-place split (committed_descriptor.hpp:186-192, 228-232)
-            _check(lib.pfft_execute_split(self._plan, int(dir), _ptr(args[0]), _ptr(args[1]), _ptr(args[0]),
-                                          _ptr(args[1])))
+            for a, w in zip(args, ("inout_real", "inout_imag")):
+                self._check_buffer(a, max(n_in, n_out), True, w)
+            _check(lib.pfft_execute_split_ex(self._plan, int(dir), _ptr(args[0]), _ptr(args[1]), _ptr(args[0]),
+                                             _ptr(args[1]), len(deps), dep_arr, ev_ref))
         elif n == 2:  # out-of-place interleaved (committed_descriptor.hpp:242-246, 288-293)
-            _check(lib.pfft_execute(self._plan, int(dir), _ptr(args[0]), _ptr(args[1])))
+            self._check_buffer(args[0], n_in, False, "in")
+            self._check_buffer(args[1], n_out, False, "out")
+            _check(lib.pfft_execute_ex(self._plan, int(dir), _ptr(args[0]), _ptr(args[1]), len(deps), dep_arr, ev_ref))
         elif n == 4:  # out-of-place split (committed_descriptor.hpp:258-263, 305-310)
-            _check(lib.pfft_execute_split(self._plan, int(dir), _ptr(args[0]), _ptr(args[1]), _ptr(args[2]),
-                                          _ptr(args[3])))
+            for a, w, c in zip(args, ("in_real", "in_imag", "out_real", "out_imag"), (n_in, n_in, n_out, n_out)):
+                self._check_buffer(a, c, True, w)
+            _check(lib.pfft_execute_split_ex(self._plan, int(dir), _ptr(args[0]), _ptr(args[1]), _ptr(args[2]),
+                                             _ptr(args[3]), len(deps), dep_arr, ev_ref))
         else:
             raise invalid_configuration("compute_* takes (inout), (in, out), (inout_re, inout_im) or "
                                         "(in_re, in_im, out_re, out_im)")
-        return self
+        return event(ev.value if want_event else None, self)
 
-    def compute_forward(self, *args):
-        return self._compute(direction.FORWARD, args)
+    def compute_forward(self, *args, dependencies=None, want_event=True):
+        """the USM overloads of committed_descriptor.hpp:171-310; `dependencies`: events (this module's, torch.cuda.Event
+        or raw hipEvent_t) that must complete first; returns the event of this submission (want_event=False skips
+        recording one: the returned object's wait() then waits for the plan's whole stream)."""
+        return self._compute(direction.FORWARD, args, dependencies, want_event)
 
-    def compute_backward(self, *args):
-        return self._compute(direction.BACKWARD, args)
+    def compute_backward(self, *args, dependencies=None, want_event=True):
+        return self._compute(direction.BACKWARD, args, dependencies, want_event)
 
     def wait(self):
-        """sycl::event::wait() of the event the reference returns."""
+        """queue.wait(): everything submitted on the plan's stream has finished."""
         _check(lib.pfft_plan_wait(self._plan))

@@ -75,6 +75,22 @@ struct strided_kernel {
   int rowish;
 };
 
+/// First pass of the two-pass 2-D plan (stockham_rows2d.hpp): whole row FFTs of length n + the first radix-rc
+/// butterfly of the column FFT, rows {M*a + b} -> rows {rc*b + u}.
+struct rows2d_kernel {
+  int precision;
+  int n;   // row length
+  int rc;  // column radix taken in this pass (rows per work-group)
+  int wg;
+  size_t lds_bytes;
+  int n_radices;
+  int radices[8];
+  int groups_per_wg;
+  const void* fn[2];  // [backward]
+  hipError_t (*launch)(hipStream_t stream, unsigned grid, const rows2d_args& args, int backward);
+};
+const rows2d_kernel* rows2d_kernels(int* count);
+
 const strided_kernel* strided_kernels_f32(int* count);
 const strided_kernel* strided_kernels_f64(int* count);
 

@@ -3,6 +3,7 @@
 #include "../../include/portfft_amd.h"
 #include "generic_kernel.hpp"
 #include "kernels.hpp"
+#include "stockham_rows2d.hpp"
 #include "stockham_strided.hpp"
 #include "stockham_wg.hpp"
 
@@ -160,6 +161,34 @@ hipError_t launch_strided_row(hipStream_t stream, unsigned grid, const strided_a
     }
   }
   return hipGetLastError();
+}
+
+template <typename Cfg>
+hipError_t launch_rows2d(hipStream_t stream, unsigned grid, const rows2d_args& args, int backward) {
+  if (backward) {
+    hipLaunchKernelGGL((stockham_rows2d_kernel<Cfg, true>), dim3(grid), dim3(Cfg::WG), Cfg::LDS_BYTES, stream, args);
+  } else {
+    hipLaunchKernelGGL((stockham_rows2d_kernel<Cfg, false>), dim3(grid), dim3(Cfg::WG), Cfg::LDS_BYTES, stream, args);
+  }
+  return hipGetLastError();
+}
+
+/// Cfg: the row FFT's wg_cfg with FPW = rows per work-group (= the column radix)
+template <typename Cfg>
+rows2d_kernel make_rows2d_entry(int groups_per_wg) {
+  rows2d_kernel k{};
+  k.precision = sizeof(typename Cfg::T) == 8 ? PFFT_PRECISION_F64 : PFFT_PRECISION_F32;
+  k.n = Cfg::N;
+  k.rc = Cfg::FPW;
+  k.wg = Cfg::WG;
+  k.lds_bytes = Cfg::LDS_BYTES;
+  k.n_radices = Cfg::NP;
+  for (int i = 0; i < Cfg::NP; ++i) k.radices[i] = Cfg::Seq::r[i];
+  k.groups_per_wg = groups_per_wg;
+  k.fn[0] = reinterpret_cast<const void*>(&stockham_rows2d_kernel<Cfg, false>);
+  k.fn[1] = reinterpret_cast<const void*>(&stockham_rows2d_kernel<Cfg, true>);
+  k.launch = &launch_rows2d<Cfg>;
+  return k;
 }
 
 /// mark an entry as the wide-group alternative of its length (strided_kernel::wide)

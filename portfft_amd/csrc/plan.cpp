@@ -47,6 +47,12 @@ struct stage {
   const unpacked_kernel* unpacked = nullptr;  // spec + UNPACKED layout: in_addr / out_addr hold strides and distances
   const strided_kernel* strided = nullptr;
   strided_args sa{};
+  const rows2d_kernel* rows2d = nullptr;  // first pass of the two-pass 2-D plan (stockham_rows2d.hpp)
+  rows2d_args ra{};
+  // two-pass 2-D plan: pass 1 permutes rows between distinct buffers (IN -> OUT), pass 2 works in place on OUT.
+  // When the caller's buffers alias (in-place transform) the intermediate goes through scratch instead:
+  // 1: this stage writes it (out_buf -> scratch), 2: this stage reads it (in_buf -> scratch)
+  int alias_scratch = 0;
   int store_modifier = 0;
   int row_mode = 0;  // 0: both sides addressed by the passes, 1: row-shaped input staged, 2: row-shaped output staged
   int in_buf = BUF_IN, out_buf = BUF_OUT;
@@ -156,6 +162,33 @@ std::vector<int> choose_radices(long long n) {
 
 }  // namespace
 
+/// Device allocations that copies of a plan share (twiddle tables): freed when the last copy goes away.
+/// (reference: the kernels and twiddles of committed_descriptor_impl are shared_ptr members, copied by
+/// create_copy, committed_descriptor_impl.hpp:774-803)
+struct shared_allocs {
+  std::vector<void*> ptrs;
+  ~shared_allocs() {
+    for (void* p : ptrs) (void)hipFree(p);
+  }
+};
+
+/// makes the plan's device current for the duration of a call when it is not (plan_t::device was unused)
+struct device_guard {
+  int prev = -1;
+  explicit device_guard(int device) {
+    int cur = -1;
+    if (hipGetDevice(&cur) == hipSuccess && cur != device) {
+      if (hipSetDevice(device) != hipSuccess) fail(PFFT_HIP_ERROR, "hipSetDevice(", device, ") failed");
+      prev = cur;
+    }
+  }
+  ~device_guard() {
+    if (prev >= 0) (void)hipSetDevice(prev);
+  }
+  device_guard(const device_guard&) = delete;
+  device_guard& operator=(const device_guard&) = delete;
+};
+
 struct plan_t {
   pfft_desc_t desc{};
   hipStream_t stream = nullptr;
@@ -163,10 +196,12 @@ struct plan_t {
   int n_cus = 0;
   size_t max_lds = 0;
   std::vector<stage> stages[2];
-  std::vector<void*> device_allocs;
-  void* scratch = nullptr;
+  std::shared_ptr<shared_allocs> tables = std::make_shared<shared_allocs>();  // twiddles: shared by copies
+  void* scratch = nullptr;                                                     // scratch: one per copy
   size_t scratch_bytes = 0;
   size_t twiddle_bytes = 0;
+  void* alias_scratch = nullptr;  // intermediate of the two-pass 2-D plan for aliasing (in-place) executes
+  size_t alias_scratch_bytes = 0;
   long long chunk_batches = 0;  // user transforms per chunk of the GLOBAL tier
   int n_chunk_groups = 0;
   pfft_plan_info_t info{};
@@ -175,14 +210,15 @@ struct plan_t {
   size_t elem_bytes() const { return 2 * static_cast<size_t>(scalar_bytes()); }
 
   ~plan_t() {
-    if (stream != nullptr || !device_allocs.empty()) (void)hipStreamSynchronize(stream);
-    for (void* p : device_allocs) (void)hipFree(p);
+    (void)hipStreamSynchronize(stream);
+    if (scratch != nullptr) (void)hipFree(scratch);
+    if (alias_scratch != nullptr) (void)hipFree(alias_scratch);
   }
 
   void* upload(const void* host, size_t bytes) {
     void* d = nullptr;
     hip_check(hipMalloc(&d, bytes), "hipMalloc(twiddles)");
-    device_allocs.push_back(d);
+    tables->ptrs.push_back(d);
     hip_check(hipMemcpy(d, host, bytes, hipMemcpyHostToDevice), "hipMemcpy(twiddles)");
     twiddle_bytes += bytes;
     return d;
@@ -251,7 +287,8 @@ struct plan_t {
 
   /// column_both: the stage is column-shaped on both sides -> the wide-group entry of the length, when there is one
   /// row_side: one side of the stage is row-shaped -> the row-friendly entry of the length, when there is one
-  const strided_kernel* find_strided(long long n, bool column_both = false, bool row_side = false) const {
+  const strided_kernel* find_strided(long long n, bool column_both = false, bool row_side = false,
+                                     long long inner_count = -1) const {
     int count = 0;
     const strided_kernel* k =
         desc.precision == PFFT_PRECISION_F64 ? strided_kernels_f64(&count) : strided_kernels_f32(&count);
@@ -259,7 +296,8 @@ struct plan_t {
     for (int i = 0; i < count; ++i) {
       if (k[i].n != n || k[i].lds_bytes > max_lds) continue;
       if (k[i].wide == 0 && k[i].rowish == 0 && found == nullptr) found = &k[i];
-      if (k[i].wide != 0 && column_both) return &k[i];
+      // wide groups only pay when the stage has that many adjacent columns (surplus lanes would be masked)
+      if (k[i].wide != 0 && column_both && (inner_count < 0 || inner_count >= k[i].fpw)) return &k[i];
       if (k[i].rowish != 0 && row_side && k[i].lds_bytes_row <= max_lds) return &k[i];
     }
     return found;
@@ -278,7 +316,7 @@ struct plan_t {
   /// the pre-compiled strided kernel when it suits the stage, otherwise a runtime-specialised one (jit.hpp)
   const strided_kernel* get_strided(long long n, long long inner_count, bool store_modifier, bool user_split,
                                     bool column_both = false, bool row_side = false) {
-    const strided_kernel* k = find_strided(n, column_both, row_side && !user_split);
+    const strided_kernel* k = find_strided(n, column_both, row_side && !user_split, inner_count);
     if (k != nullptr) return k;
     std::string why;
     k = jit_strided_kernel(desc.precision, n, inner_count, store_modifier, user_split ? 1 : 0, max_lds, &why,
@@ -332,6 +370,64 @@ struct plan_t {
       return a.stride < (1ll << 31) && a.dist_inner < (1ll << 31) && elems * elem_bytes() < 0xFFFFFFF0ull;
     };
     return range_ok(ia) && range_ok(oa);
+  }
+
+  const rows2d_kernel* find_rows2d(long long n1, long long n0) const {
+    const char* e = getenv("PFFT_2D_TWO_PASS");
+    if (e != nullptr && e[0] == '0') return nullptr;  // experiments / parity A-B: rows, then full-length columns
+    int count = 0;
+    const rows2d_kernel* k = rows2d_kernels(&count);
+    for (int i = 0; i < count; ++i) {
+      if (k[i].precision == desc.precision && k[i].n == n1 && k[i].lds_bytes <= max_lds && n0 % k[i].rc == 0 &&
+          n0 / k[i].rc >= 2) {
+        return &k[i];
+      }
+    }
+    return nullptr;
+  }
+
+  /// W_n^m for m in [0, n): the inter-pass column twiddles of the two-pass 2-D plan
+  const void* upload_unit_roots(long long n) {
+    auto fill = [&](auto tag) {
+      using T = decltype(tag);
+      std::vector<T> v(static_cast<size_t>(2 * n));
+      for (long long i = 0; i < n; ++i) {
+        const long double a = -2.0L * static_cast<long double>(PI_L) * static_cast<long double>(i) /
+                              static_cast<long double>(n);
+        v[static_cast<size_t>(2 * i)] = static_cast<T>(cosl(a));
+        v[static_cast<size_t>(2 * i + 1)] = static_cast<T>(sinl(a));
+      }
+      return upload(v.data(), v.size() * sizeof(T));
+    };
+    return desc.precision == PFFT_PRECISION_F64 ? fill(double{}) : fill(float{});
+  }
+
+  stage make_rows2d_stage(const rows2d_kernel* k, long long nmat, long long n0, long long in_off, long long out_off,
+                          int backward) {
+    stage s;
+    s.rows2d = k;
+    s.n = k->n;
+    s.in_buf = BUF_IN;
+    s.out_buf = BUF_OUT;
+    s.in_offset = in_off;
+    s.out_offset = out_off;
+    s.count = nmat * n0;
+    s.backward = backward;
+    s.lds_bytes = k->lds_bytes;
+    s.alias_scratch = 1;
+    s.ra.tw = upload_twiddles(std::vector<int>(k->radices, k->radices + k->n_radices));
+    s.ra.twc = upload_unit_roots(n0);
+    s.ra.nmat = nmat;
+    s.ra.n0 = static_cast<int>(n0);
+    for (int d = 0; d < 2; ++d) {
+      if (k->lds_bytes > 48 * 1024) {
+        hip_check(hipFuncSetAttribute(k->fn[d], hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      static_cast<int>(k->lds_bytes)),
+                  "hipFuncSetAttribute");
+      }
+    }
+    s.grid = persistent_grid(k->fn[backward], nullptr, k->wg, k->lds_bytes, nmat * (n0 / k->rc), k->groups_per_wg);
+    return s;
   }
 
   stage make_strided_stage(const strided_kernel* k, long long count, long long inner_count, int in_buf,
@@ -874,6 +970,52 @@ struct plan_t {
     }
     if (fused_from == 0) return;
     long long inner = 1;
+    // Two-pass plan for the last two dimensions (stockham_rows2d.hpp): pass 1 = whole rows + the first radix-RC
+    // butterfly of the columns (contiguous rows on both sides), pass 2 = the remaining (n0 / RC)-point column FFTs
+    // as a batch-interleaved transform over RC * n1 adjacent columns.  C5 (fp32 1024 x 1024 x 256): 1.57 -> 1.40 ms.
+    if (fused_from == rank && desc.complex_storage == PFFT_INTERLEAVED_COMPLEX) {
+      const long long n0 = static_cast<long long>(desc.lengths[rank - 2]);
+      const long long n1 = static_cast<long long>(desc.lengths[rank - 1]);
+      const long long nmat = B * (total / (n0 * n1));
+      const rows2d_kernel* rk = find_rows2d(n1, n0);
+      const bool range_ok = static_cast<unsigned long long>(n0) * static_cast<unsigned long long>(n1) * elem_bytes() <
+                            0xFFFFFFF0ull;
+      const size_t all_bytes = static_cast<size_t>(B) * static_cast<size_t>(total) * elem_bytes();
+      const bool alias_ok = desc.placement != PFFT_IN_PLACE || all_bytes <= global_chunk_bytes();
+      if (rk != nullptr && range_ok && alias_ok) {
+        const long long m = n0 / rk->rc;
+        const long long cols = static_cast<long long>(rk->rc) * n1;
+        addressing a{static_cast<long long>(vout.offset), cols, 1, n0 * n1};
+        std::vector<stage> tail;
+        pfft_dim_info_t di{};
+        const int tier = plan_1d(tail, m, nmat * cols, cols, BUF_OUT, a, BUF_OUT, a, false, scale, backward, &di);
+        if (tier == PFFT_TIER_WORKGROUP && tail.size() == 1 && tail[0].strided != nullptr) {
+          st.push_back(make_rows2d_stage(rk, nmat, n0, static_cast<long long>(vin.offset),
+                                         static_cast<long long>(vout.offset), backward));
+          tail[0].alias_scratch = 2;
+          st.push_back(tail[0]);
+          if (desc.placement == PFFT_IN_PLACE) alias_scratch_bytes = std::max(alias_scratch_bytes, all_bytes);
+          if (record) {
+            pfft_dim_info_t& d1 = info.dims[rank - 1];
+            d1.length = static_cast<uint64_t>(n1);
+            d1.tier = PFFT_TIER_WORKGROUP;
+            d1.n_factors = rk->n_radices;
+            for (int i = 0; i < rk->n_radices; ++i) d1.factors[i] = rk->radices[i];
+            d1.workgroup_size = rk->wg;
+            d1.ffts_per_workgroup = rk->rc;
+            d1.lds_bytes = rk->lds_bytes;
+            pfft_dim_info_t& d0 = info.dims[rank - 2];
+            d0 = di;  // the column dimension: radix RC (fused into pass 1), then the factors of n0 / RC
+            d0.length = static_cast<uint64_t>(n0);
+            const int nf = std::min<int>(di.n_factors, PFFT_MAX_FACTORS - 1);
+            d0.factors[0] = rk->rc;
+            for (int i = 0; i < nf; ++i) d0.factors[i + 1] = di.factors[i];
+            d0.n_factors = nf + 1;
+          }
+          fused_from = rank - 2;  // `inner` is accumulated over lengths[fused_from..rank) below
+        }
+      }
+    }
     if (fused_from == rank) {
       const long long last = static_cast<long long>(desc.lengths[rank - 1]);
       addressing ia{static_cast<long long>(vin.offset), 1, last, 0};
@@ -909,10 +1051,35 @@ struct plan_t {
     build_direction(PFFT_BACKWARD);
     if (scratch_bytes > 0) {
       hip_check(hipMalloc(&scratch, scratch_bytes), "hipMalloc(scratch)");
-      device_allocs.push_back(scratch);
     }
+    if (alias_scratch_bytes > 0) ensure_alias_scratch();
     info.twiddle_bytes = twiddle_bytes;
-    info.scratch_bytes = scratch_bytes;
+    info.scratch_bytes = scratch_bytes + alias_scratch_bytes;
+  }
+
+  /// Copy of a committed plan (committed_descriptor_impl.hpp:774-817): the kernels and the twiddle tables are shared,
+  /// the scratch buffers are allocated again, so two copies can execute concurrently on two streams.
+  plan_t(const plan_t& o)
+      : desc(o.desc), stream(o.stream), device(o.device), n_cus(o.n_cus), max_lds(o.max_lds), tables(o.tables),
+        scratch_bytes(o.scratch_bytes), twiddle_bytes(o.twiddle_bytes), alias_scratch_bytes(o.alias_scratch_bytes),
+        chunk_batches(o.chunk_batches), n_chunk_groups(o.n_chunk_groups), info(o.info) {
+    stages[0] = o.stages[0];
+    stages[1] = o.stages[1];
+    device_guard dg(device);
+    if (scratch_bytes > 0) hip_check(hipMalloc(&scratch, scratch_bytes), "hipMalloc(scratch)");
+    if (o.alias_scratch != nullptr) ensure_alias_scratch();
+  }
+  plan_t& operator=(const plan_t&) = delete;
+
+  /// intermediate of the two-pass 2-D plan when the caller's buffers alias: allocated at commit for IN_PLACE
+  /// descriptors, on first use when an OUT_OF_PLACE plan is executed with in == out
+  void ensure_alias_scratch() {
+    if (alias_scratch != nullptr) return;
+    if (alias_scratch_bytes == 0) {
+      alias_scratch_bytes = static_cast<size_t>(desc.number_of_transforms) * static_cast<size_t>(flattened_length(desc)) *
+                            elem_bytes();
+    }
+    hip_check(hipMalloc(&alias_scratch, alias_scratch_bytes), "hipMalloc(2-D intermediate)");
   }
 
   /// run stage `s` for the user transforms [b0, b0 + nb) (chunked stages) or entirely (nb < 0)
@@ -936,6 +1103,16 @@ struct plan_t {
       return split ? static_cast<const char*>(out_im) : static_cast<const char*>(out_re) + sb;
     };
     auto step_of = [&](int buf) { return (buf == BUF_SCRATCH || !split) ? 2 : 1; };
+    const bool aliased = s.alias_scratch != 0 && in_re == out_re;
+    if (aliased) ensure_alias_scratch();
+    if (s.rows2d != nullptr) {
+      rows2d_args a = s.ra;
+      a.in = static_cast<const char*>(in_re) + static_cast<size_t>(s.in_offset) * elem_bytes();
+      a.out = aliased ? static_cast<char*>(alias_scratch)
+                      : static_cast<char*>(out_re) + static_cast<size_t>(s.out_offset) * elem_bytes();
+      hip_check(s.rows2d->launch(stream, s.grid, a, s.backward), "kernel launch");
+      return;
+    }
     if (s.strided != nullptr) {
       strided_args a = s.sa;
       a.total = count;
@@ -966,6 +1143,7 @@ struct plan_t {
         return;
       }
       a.in = base_re(s.in_buf, true) + static_cast<size_t>(s.in_addr.offset + in_shift) * elem_bytes();
+      if (aliased && s.alias_scratch == 2) a.in = alias_scratch;  // two-pass 2-D plan, in-place execute
       a.out = const_cast<char*>(base_re(s.out_buf, false)) +
               static_cast<size_t>(s.out_addr.offset + out_shift) * elem_bytes();
       if (s.row_mode != 0 && s.store_modifier == 0) {
@@ -1038,6 +1216,7 @@ struct plan_t {
       fail(PFFT_INVALID_CONFIGURATION, "Invalid direction ", direction);
     }
     if (in_re == nullptr || out_re == nullptr) fail(PFFT_INVALID_CONFIGURATION, "null data pointer");
+    device_guard dg(device);  // launches go to the device the plan was committed on, whatever is current
     const std::vector<stage>& st = stages[direction];
     for (size_t i = 0; i < st.size();) {
       if (st[i].chunk_group < 0) {
@@ -1062,6 +1241,34 @@ struct plan_t {
 struct pfft_plan_t {
   std::unique_ptr<pfa::plan_t> impl;
 };
+
+namespace {
+/// dependencies in, completion event out (shared by the two _ex entry points)
+template <typename Run>
+void execute_with_events(pfft_plan_t* plan, int32_t n_deps, void* const* deps, void** event_out, Run&& run) {
+  pfa::plan_t& p = *plan->impl;
+  pfa::device_guard dg(p.device);
+  if (n_deps < 0 || (n_deps > 0 && deps == nullptr)) pfa::fail(PFFT_INVALID_CONFIGURATION, "invalid dependency list");
+  for (int32_t i = 0; i < n_deps; ++i) {
+    if (deps[i] == nullptr) continue;  // a default-constructed event: nothing to wait for
+    const hipError_t e = hipStreamWaitEvent(p.stream, static_cast<hipEvent_t>(deps[i]), 0);
+    if (e != hipSuccess) pfa::fail(PFFT_HIP_ERROR, "hipStreamWaitEvent: ", hipGetErrorString(e));
+  }
+  run();
+  if (event_out != nullptr) {
+    *event_out = nullptr;
+    hipEvent_t ev = nullptr;
+    hipError_t e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+    if (e != hipSuccess) pfa::fail(PFFT_HIP_ERROR, "hipEventCreate: ", hipGetErrorString(e));
+    e = hipEventRecord(ev, p.stream);
+    if (e != hipSuccess) {
+      (void)hipEventDestroy(ev);
+      pfa::fail(PFFT_HIP_ERROR, "hipEventRecord: ", hipGetErrorString(e));
+    }
+    *event_out = ev;
+  }
+}
+}  // namespace
 
 extern "C" {
 
@@ -1108,6 +1315,110 @@ pfft_status pfft_execute_split(pfft_plan_t* plan, int32_t direction, const void*
     }
     if (in_imag == nullptr || out_imag == nullptr) pfa::fail(PFFT_INVALID_CONFIGURATION, "null imaginary pointer");
     plan->impl->execute(direction, in_real, in_imag, out_real, out_imag);
+  });
+}
+
+pfft_status pfft_execute_ex(pfft_plan_t* plan, int32_t direction, const void* in, void* out, int32_t n_deps,
+                            void* const* deps, void** event_out) {
+  return pfa::guarded([&] {
+    if (plan == nullptr) pfa::fail(PFFT_INVALID_CONFIGURATION, "null plan");
+    if (plan->impl->desc.complex_storage != PFFT_INTERLEAVED_COMPLEX) {
+      pfa::fail(PFFT_INVALID_CONFIGURATION,
+                "To use interleaved data layout, the descriptor.complex_storage must be INTERLEAVED_COMPLEX");
+    }
+    execute_with_events(plan, n_deps, deps, event_out,
+                        [&] { plan->impl->execute(direction, in, nullptr, out, nullptr); });
+  });
+}
+
+pfft_status pfft_execute_split_ex(pfft_plan_t* plan, int32_t direction, const void* in_real, const void* in_imag,
+                                  void* out_real, void* out_imag, int32_t n_deps, void* const* deps,
+                                  void** event_out) {
+  return pfa::guarded([&] {
+    if (plan == nullptr) pfa::fail(PFFT_INVALID_CONFIGURATION, "null plan");
+    if (plan->impl->desc.complex_storage != PFFT_SPLIT_COMPLEX) {
+      pfa::fail(PFFT_INVALID_CONFIGURATION,
+                "To use split data layout, the descriptor.complex_storage must be SPLIT_COMPLEX");
+    }
+    if (in_imag == nullptr || out_imag == nullptr) pfa::fail(PFFT_INVALID_CONFIGURATION, "null imaginary pointer");
+    execute_with_events(plan, n_deps, deps, event_out,
+                        [&] { plan->impl->execute(direction, in_real, in_imag, out_real, out_imag); });
+  });
+}
+
+pfft_status pfft_event_wait(void* event) {
+  return pfa::guarded([&] {
+    if (event == nullptr) return;
+    const hipError_t e = hipEventSynchronize(static_cast<hipEvent_t>(event));
+    if (e != hipSuccess) pfa::fail(PFFT_HIP_ERROR, "hipEventSynchronize: ", hipGetErrorString(e));
+  });
+}
+
+pfft_status pfft_event_query(void* event, int32_t* done) {
+  return pfa::guarded([&] {
+    if (done == nullptr) pfa::fail(PFFT_INVALID_CONFIGURATION, "null argument");
+    *done = 1;
+    if (event == nullptr) return;
+    const hipError_t e = hipEventQuery(static_cast<hipEvent_t>(event));
+    if (e == hipErrorNotReady) {
+      *done = 0;
+    } else if (e != hipSuccess) {
+      pfa::fail(PFFT_HIP_ERROR, "hipEventQuery: ", hipGetErrorString(e));
+    }
+  });
+}
+
+pfft_status pfft_event_destroy(void* event) {
+  return pfa::guarded([&] {
+    if (event == nullptr) return;
+    const hipError_t e = hipEventDestroy(static_cast<hipEvent_t>(event));
+    if (e != hipSuccess) pfa::fail(PFFT_HIP_ERROR, "hipEventDestroy: ", hipGetErrorString(e));
+  });
+}
+
+pfft_status pfft_queue_copy(void* hip_stream, const void* src, void* dst, size_t bytes, int32_t n_deps,
+                            void* const* deps, void** event_out) {
+  return pfa::guarded([&] {
+    hipStream_t st = static_cast<hipStream_t>(hip_stream);
+    if (n_deps < 0 || (n_deps > 0 && deps == nullptr)) pfa::fail(PFFT_INVALID_CONFIGURATION, "invalid dependency list");
+    for (int32_t i = 0; i < n_deps; ++i) {
+      if (deps[i] == nullptr) continue;
+      const hipError_t e = hipStreamWaitEvent(st, static_cast<hipEvent_t>(deps[i]), 0);
+      if (e != hipSuccess) pfa::fail(PFFT_HIP_ERROR, "hipStreamWaitEvent: ", hipGetErrorString(e));
+    }
+    if (bytes > 0) {
+      const hipError_t e = hipMemcpyAsync(dst, src, bytes, hipMemcpyDefault, st);
+      if (e != hipSuccess) pfa::fail(PFFT_HIP_ERROR, "hipMemcpyAsync: ", hipGetErrorString(e));
+    }
+    if (event_out != nullptr) {
+      *event_out = nullptr;
+      hipEvent_t ev = nullptr;
+      hipError_t e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+      if (e != hipSuccess) pfa::fail(PFFT_HIP_ERROR, "hipEventCreate: ", hipGetErrorString(e));
+      e = hipEventRecord(ev, st);
+      if (e != hipSuccess) {
+        (void)hipEventDestroy(ev);
+        pfa::fail(PFFT_HIP_ERROR, "hipEventRecord: ", hipGetErrorString(e));
+      }
+      *event_out = ev;
+    }
+  });
+}
+
+pfft_status pfft_queue_wait(void* hip_stream) {
+  return pfa::guarded([&] {
+    const hipError_t e = hipStreamSynchronize(static_cast<hipStream_t>(hip_stream));
+    if (e != hipSuccess) pfa::fail(PFFT_HIP_ERROR, "hipStreamSynchronize: ", hipGetErrorString(e));
+  });
+}
+
+pfft_status pfft_plan_clone(const pfft_plan_t* plan, pfft_plan_t** copy) {
+  return pfa::guarded([&] {
+    if (plan == nullptr || copy == nullptr) pfa::fail(PFFT_INVALID_CONFIGURATION, "null argument");
+    *copy = nullptr;
+    auto p = std::make_unique<pfft_plan_t>();
+    p->impl = std::make_unique<pfa::plan_t>(*plan->impl);
+    *copy = p.release();
   });
 }
 

@@ -55,6 +55,61 @@ constexpr int strided_pitch() {
   return ROW ? Cfg::FPW + 1 : Cfg::FPW;
 }
 
+/// The HBM side of a last pass: butterfly outputs v[u] = element (base + u * Ns) of FFT f go to memory, conjugated
+/// for the backward transform, scaled, and -- STW -- multiplied by the store modifier W_M^{k*c}.
+template <typename Cfg, bool BWD, bool STW, int R, int Ns, typename IO>
+PFA_DEV void strided_store_butterfly(const IO& io, const strided_args& a, unsigned f, unsigned base, bool live,
+                                     long long c0, cx<typename Cfg::T> (&v)[R]) {
+  using T = typename Cfg::T;
+  constexpr unsigned ES_OUT = IO::ES_OUT;
+  const unsigned osh = static_cast<unsigned>(a.out_tile_shift);
+  const unsigned voff =
+      live ? (f * a.out_fdist + (base >> osh) * a.out_stride + (base & ((1u << osh) - 1u))) * ES_OUT : 0xFFFFFFF0u;
+  const T scale = static_cast<T>(a.scale);
+  // store modifier W_M^{k*c}, k = base + u*Ns: W^{base*c}, the step W^{Ns*c} and every fourth power of the step
+  // come from the hi/lo tables, the other powers are one multiply away from those
+  [[maybe_unused]] cx<T> stw[R];
+  if constexpr (STW) {
+    unsigned long long stw_c = static_cast<unsigned long long>(c0 + f);
+    if (a.stw_cdiv > 1) stw_c /= static_cast<unsigned long long>(a.stw_cdiv);
+    const cx<T>* lo = static_cast<const cx<T>*>(a.stw_lo);
+    const cx<T>* hi = static_cast<const cx<T>*>(a.stw_hi);
+    const unsigned long long mask = (1ull << a.stw_shift) - 1;
+    const unsigned long long m0 = static_cast<unsigned long long>(base) * stw_c;
+    const unsigned long long ms = static_cast<unsigned long long>(Ns) * stw_c;
+    const cx<T> w0 = cmul(lo[m0 & mask], hi[m0 >> a.stw_shift]);
+    // stw[u] = W^{(base + u*Ns)*c} = w0 * step^u.  Every fourth one is w0 times a table value (anchor), the
+    // three behind it are one multiply away from their anchor -- a chain of squarings of the step would amplify
+    // its rounding by u (radix 32: ~45 ulp in fp32), and folding w0 into the anchors saves R multiplies.
+    [[maybe_unused]] cx<T> pw[4];
+    if constexpr (R > 1) pw[1] = cmul(lo[ms & mask], hi[ms >> a.stw_shift]);
+    if constexpr (R > 2) pw[2] = cmul(pw[1], pw[1]);
+    if constexpr (R > 3) pw[3] = cmul(pw[2], pw[1]);
+    sfor<0, (R + 3) / 4>([&](auto k_) PFA_LAMBDA {
+      constexpr int k = decltype(k_)::value;
+      cx<T> anchor = w0;
+      if constexpr (k > 0) {
+        const unsigned long long mu = ms * static_cast<unsigned long long>(4 * k);
+        anchor = cmul(w0, cmul(lo[mu & mask], hi[mu >> a.stw_shift]));
+      }
+      stw[4 * k] = anchor;
+      sfor<1, 4>([&](auto r_) PFA_LAMBDA {
+        constexpr int r = decltype(r_)::value;
+        if constexpr (4 * k + r < R) stw[4 * k + r] = cmul(anchor, pw[r]);
+      });
+    });
+  }
+  sfor<0, R>([&](auto u_) PFA_LAMBDA {
+    constexpr int u = decltype(u_)::value;
+    cx<T> y = v[u];
+    if constexpr (STW) y = cmul(y, stw[u]);
+    if constexpr (BWD) y.im = -y.im;
+    y.re *= scale;
+    y.im *= scale;
+    io.store(y, voff, (static_cast<unsigned>(u * Ns) >> osh) * a.out_stride * ES_OUT);
+  });
+}
+
 template <typename Cfg, bool BWD, bool STW, int P, typename IO, bool ROW_IN = false, bool ROW_OUT = false>
 PFA_DEV void strided_pass(const IO& io, const strided_args& a, unsigned f,
                           unsigned tid, bool live, long long c0, cx<typename Cfg::T>* lds,
@@ -70,7 +125,7 @@ PFA_DEV void strided_pass(const IO& io, const strided_args& a, unsigned f,
   constexpr bool first = P == 0 && !ROW_IN;   // reads HBM directly
   constexpr bool last = P == Cfg::NP - 1 && !ROW_OUT;  // writes HBM directly
   constexpr int FPW = strided_pitch<Cfg, ROW_IN || ROW_OUT>();
-  constexpr unsigned ES_IN = IO::ES_IN, ES_OUT = IO::ES_OUT;
+  [[maybe_unused]] constexpr unsigned ES_IN = IO::ES_IN;
 
   cx<T> v[BPT][R];
   sfor<0, BPT>([&](auto i_) PFA_LAMBDA {
@@ -118,53 +173,7 @@ PFA_DEV void strided_pass(const IO& io, const strided_args& a, unsigned f,
       dft<R>(v[i]);
       const unsigned base = (j / Ns) * (Ns * R) + q;
       if constexpr (last) {
-        const unsigned osh = static_cast<unsigned>(a.out_tile_shift);
-        const unsigned voff =
-            live ? (f * a.out_fdist + (base >> osh) * a.out_stride + (base & ((1u << osh) - 1u))) * ES_OUT
-                 : 0xFFFFFFF0u;
-        const T scale = static_cast<T>(a.scale);
-        // store modifier W_M^{k*c}, k = base + u*Ns: W^{base*c}, the step W^{Ns*c} and every fourth power of the step
-        // come from the hi/lo tables, the other powers are one multiply away from those
-        [[maybe_unused]] cx<T> stw[R];
-        if constexpr (STW) {
-          unsigned long long stw_c = static_cast<unsigned long long>(c0 + f);
-          if (a.stw_cdiv > 1) stw_c /= static_cast<unsigned long long>(a.stw_cdiv);
-          const cx<T>* lo = static_cast<const cx<T>*>(a.stw_lo);
-          const cx<T>* hi = static_cast<const cx<T>*>(a.stw_hi);
-          const unsigned long long mask = (1ull << a.stw_shift) - 1;
-          const unsigned long long m0 = static_cast<unsigned long long>(base) * stw_c;
-          const unsigned long long ms = static_cast<unsigned long long>(Ns) * stw_c;
-          const cx<T> w0 = cmul(lo[m0 & mask], hi[m0 >> a.stw_shift]);
-          // stw[u] = W^{(base + u*Ns)*c} = w0 * step^u.  Every fourth one is w0 times a table value (anchor), the
-          // three behind it are one multiply away from their anchor -- a chain of squarings of the step would amplify
-          // its rounding by u (radix 32: ~45 ulp in fp32), and folding w0 into the anchors saves R multiplies.
-          [[maybe_unused]] cx<T> pw[4];
-          if constexpr (R > 1) pw[1] = cmul(lo[ms & mask], hi[ms >> a.stw_shift]);
-          if constexpr (R > 2) pw[2] = cmul(pw[1], pw[1]);
-          if constexpr (R > 3) pw[3] = cmul(pw[2], pw[1]);
-          sfor<0, (R + 3) / 4>([&](auto k_) PFA_LAMBDA {
-            constexpr int k = decltype(k_)::value;
-            cx<T> anchor = w0;
-            if constexpr (k > 0) {
-              const unsigned long long mu = ms * static_cast<unsigned long long>(4 * k);
-              anchor = cmul(w0, cmul(lo[mu & mask], hi[mu >> a.stw_shift]));
-            }
-            stw[4 * k] = anchor;
-            sfor<1, 4>([&](auto r_) PFA_LAMBDA {
-              constexpr int r = decltype(r_)::value;
-              if constexpr (4 * k + r < R) stw[4 * k + r] = cmul(anchor, pw[r]);
-            });
-          });
-        }
-        sfor<0, R>([&](auto u_) PFA_LAMBDA {
-          constexpr int u = decltype(u_)::value;
-          cx<T> y = v[i][u];
-          if constexpr (STW) y = cmul(y, stw[u]);
-          if constexpr (BWD) y.im = -y.im;
-          y.re *= scale;
-          y.im *= scale;
-          io.store(y, voff, (static_cast<unsigned>(u * Ns) >> osh) * a.out_stride * ES_OUT);
-        });
+        strided_store_butterfly<Cfg, BWD, STW, R, Ns>(io, a, f, base, live, c0, v[i]);
       } else {
         cx<T>* p = lds + base * FPW + f;
         sfor<0, R>([&](auto u_) PFA_LAMBDA {

@@ -30,4 +30,15 @@ struct strided_args {
   int in_tile_shift, out_tile_shift;
 };
 
+/// Launch-time arguments of the first pass of the two-pass 2-D plan (stockham_rows2d.hpp): `nmat` matrices of
+/// n0 rows x N columns (N is the kernel's row length), packed, interleaved.
+struct rows2d_args {
+  const void* in;
+  void* out;
+  const void* tw;   // row twiddles (layout: radix_list::tw_off)
+  const void* twc;  // W_n0^m, m in [0, n0)
+  long long nmat;   // matrices (batch x leading dimensions)
+  int n0;           // rows per matrix; n0 % RC == 0
+};
+
 }  // namespace pfa

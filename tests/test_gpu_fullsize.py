@@ -1,0 +1,158 @@
+"""Full-size BASELINE configs 3 and 5, the two-pass 2-D plan, and buffers beyond 4 GiB -- through the C ABI on an MI355X.
+
+Full sizes cannot be compared element by element on the host in reasonable time, so they are checked through
+size-independent properties (Parseval on every batch, forward->backward round trip) plus sampled transforms against
+NumPy in double precision.  Tolerances: rel-L2 per transform <= helpers.REL_L2_TOL (2e-6 fp32 / 5e-15 fp64), the same
+bar as tests/test_gpu_parity.py, far inside BASELINE.json's 1e-4.
+"""
+import os
+
+import numpy as np
+import pytest
+
+import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+
+def _mods():
+    import gpu_utils as G
+    import portfft_amd as pf
+    return G, pf, G.torch_mod()
+
+
+def _full_size_properties(lengths, batch, prec, samples):
+    G, pf, torch = _mods()
+    cdt = torch.complex64 if prec == "f32" else torch.complex128
+    tol = H.REL_L2_TOL[np.dtype(np.complex64 if prec == "f32" else np.complex128)]
+    n = int(np.prod(lengths))
+    g = torch.Generator(device="cuda").manual_seed(3)
+    x = torch.empty(batch * n, dtype=cdt, device="cuda")
+    torch.view_as_real(x).uniform_(-1, 1, generator=g)
+    y = torch.empty_like(x)
+    plan = G.make_descriptor(lengths, prec, batch=batch).commit()
+    plan.compute_forward(x, y).wait()
+    xs, ys = x.view(batch, n), y.view(batch, n)
+    for b in samples:
+        ref = np.fft.fftn(xs[b].cpu().numpy().astype(np.complex128).reshape(lengths)).ravel()
+        assert H.rel_l2(ys[b].cpu().numpy(), ref) <= tol, (lengths, prec, "batch", b)
+    # Parseval on every batch: sum |X|^2 == n * sum |x|^2
+    ex = (xs.abs().double() ** 2).sum(dim=1)
+    ey = (ys.abs().double() ** 2).sum(dim=1)
+    assert float(((ey / (n * ex)) - 1).abs().max()) < (1e-5 if prec == "f32" else 1e-12)
+    # round trip on every batch: backward(forward(x)) == n * x  (x is overwritten by its reconstruction)
+    z = torch.empty_like(x)
+    plan.compute_backward(y, z).wait()
+    err = (z.view(batch, n) / n - xs).abs().double().pow(2).sum(dim=1).sqrt() / ex.sqrt()
+    assert float(err.max()) <= tol, float(err.max())
+    return plan
+
+
+def test_full_size_config3_properties():
+    """BASELINE configs[2]: fp64 C2C 1-D N=2^20 batch=128 (GLOBAL tier, two launches through scratch)."""
+    plan = _full_size_properties([1 << 20], 128, "f64", [0, 1, 63, 127])
+    assert plan.info().dims[0].tier == 3
+
+
+def test_full_size_config5_properties():
+    """BASELINE configs[4]: fp32 C2C 2-D 1024 x 1024 batch=256 (two-pass 2-D plan)."""
+    _full_size_properties([1024, 1024], 256, "f32", [0, 1, 128, 255])
+
+
+@pytest.mark.parametrize("prec", ["f32", "f64"])
+def test_two_pass_2d_plan(prec):
+    """The two-pass 2-D plan (rows + first column radix, then short batch-interleaved columns) against NumPy and
+    against the per-dimension plan it replaces (PFFT_2D_TWO_PASS=0): both placements, offsets, scales, both
+    directions, leading dimensions, an OUT_OF_PLACE plan executed with aliasing buffers."""
+    G, pf, torch = _mods()
+    dtype = np.complex64 if prec == "f32" else np.complex128
+    shapes = ([256, 256], [64, 1024], [1024, 1024], [512, 512], [16, 2048], [1000, 1024], [3, 128, 512], [2, 2, 64, 256])
+    for dims in shapes:
+        n = int(np.prod(dims))
+        batch = 3 if n <= (1 << 18) else 2
+        x, y = H.gen_fourier_data(batch, dims, dtype, seed=n % 1000)
+        for place in (0, 1):
+            d = G.make_descriptor(dims, prec, batch=batch, placement=place, fwd_scale=0.25, bwd_scale=2.0,
+                                  fwd_offset=7, bwd_offset=7 if place == 0 else 13)
+            got, _ = G.transform_packed(d, pf.direction.FORWARD, x)
+            for b in range(batch):
+                assert H.rel_l2(got[b], 0.25 * y[b]) <= H.REL_L2_TOL[np.dtype(dtype)], ("fwd", dims, place, b)
+            back, _ = G.transform_packed(d, pf.direction.BACKWARD, y)
+            for b in range(batch):
+                assert H.rel_l2(back[b], 2.0 * n * x[b].astype(np.complex128)) <= H.REL_L2_TOL[np.dtype(dtype)], \
+                    ("bwd", dims, place, b)
+        # the plan it replaces gives the same answer up to rounding
+        d = G.make_descriptor(dims, prec, batch=batch)
+        got, _ = G.transform_packed(d, pf.direction.FORWARD, x)
+        os.environ["PFFT_2D_TWO_PASS"] = "0"
+        try:
+            old, _ = G.transform_packed(G.make_descriptor(dims, prec, batch=batch), pf.direction.FORWARD, x)
+        finally:
+            del os.environ["PFFT_2D_TWO_PASS"]
+        assert H.rel_l2(got, old) <= 2 * H.REL_L2_TOL[np.dtype(dtype)], ("vs per-dimension plan", dims)
+        # OUT_OF_PLACE descriptor, aliasing buffers (the reference's in-place overload forwards to the out-of-place
+        # one: committed_descriptor.hpp:171-176)
+        plan = G.make_descriptor(dims, prec, batch=batch).commit()
+        buf = torch.from_numpy(x.ravel().copy()).cuda()
+        plan.compute_forward(buf).wait()
+        assert H.rel_l2(buf.cpu().numpy().reshape(batch, -1), y.reshape(batch, -1)) <= H.REL_L2_TOL[np.dtype(dtype)], \
+            ("aliased", dims)
+    info = G.make_descriptor([1024, 1024], prec, batch=2).commit().info()
+    assert info.dims[1].tier == 1 and info.dims[0].tier == 1
+    assert int(np.prod(list(info.dims[0].factors)[:info.dims[0].n_factors])) == 1024
+
+
+def _big_case(n, batch, prec="f32", layout_in="P", layout_out="P", split=False):
+    """device-generated data, transforms around the 2^31-element and 2^32-byte marks checked against NumPy"""
+    G, pf, torch = _mods()
+    cdt = torch.complex64 if prec == "f32" else torch.complex128
+    rdt = torch.float32 if prec == "f32" else torch.float64
+    total = n * batch
+    g = torch.Generator(device="cuda").manual_seed(1)
+    x = torch.view_as_complex(torch.rand(total, 2, dtype=rdt, device="cuda", generator=g) * 2 - 1)
+    d = pf.descriptor([n], prec)
+    d.number_of_transforms = batch
+    if layout_in == "BI":
+        d.forward_strides, d.forward_distance = [batch], 1
+    if layout_out == "BI":
+        d.backward_strides, d.backward_distance = [batch], 1
+    if split:
+        d.complex_storage = pf.complex_storage.SPLIT_COMPLEX
+    plan = d.commit()
+    if split:
+        a, b = x.real.contiguous(), x.imag.contiguous()
+        yr = torch.empty(total, dtype=rdt, device="cuda")
+        yi = torch.empty(total, dtype=rdt, device="cuda")
+        plan.compute_forward(a, b, yr, yi).wait()
+    else:
+        y = torch.empty(total, dtype=cdt, device="cuda")
+        plan.compute_forward(x, y).wait()
+    esz = 8 if prec == "f32" else 16
+    marks = {0, 1, batch // 2, batch - 2, batch - 1}
+    for m in ((1 << 32) // (esz * n) + 3, (1 << 31) // n + 1):
+        if m < batch:
+            marks.add(m)
+    tol = 2e-6 if prec == "f32" else 1e-14
+    for b_ in sorted(marks):
+        xi_ = x[b_::batch][:n] if layout_in == "BI" else x[b_ * n:(b_ + 1) * n]
+        if split:
+            yo = (torch.complex(yr[b_::batch][:n], yi[b_::batch][:n]) if layout_out == "BI"
+                  else torch.complex(yr[b_ * n:(b_ + 1) * n], yi[b_ * n:(b_ + 1) * n]))
+        else:
+            yo = y[b_::batch][:n] if layout_out == "BI" else y[b_ * n:(b_ + 1) * n]
+        ref = np.fft.fft(xi_.cpu().numpy().astype(np.complex128))
+        assert H.rel_l2(yo.cpu().numpy(), ref) <= tol, (n, batch, prec, layout_in, layout_out, split, b_)
+    del x
+    torch.cuda.empty_cache()
+
+
+def test_buffers_beyond_4gib():
+    """Every tier addresses buffers beyond 4 GiB / 2^31 elements with 64-bit offsets (2.2-9.6 GiB per buffer)."""
+    _big_case(4096, 300000)                                       # work-group tier, 9.2 GiB
+    _big_case(16, 80000000)                                       # register tier, 9.5 GiB
+    _big_case(4096, 300000, split=True)                           # split storage
+    _big_case(4096, 300000, layout_in="BI", layout_out="BI")      # two column-shaped stages through scratch
+    _big_case(512, 2400000, layout_in="BI")                       # strided tier, row-shaped output
+    _big_case(1200, 1000000)                                      # runtime-specialised length
+    _big_case(1 << 20, 1200)                                      # GLOBAL tier fp32, chunked scratch
+    _big_case(65536, 10000, prec="f64")                           # GLOBAL tier fp64

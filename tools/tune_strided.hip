@@ -7,7 +7,7 @@
 #include <functional>
 #include <string>
 #include <vector>
-#include "../portfft_amd/csrc/stockham_strided.hpp"
+#include "../portfft_amd/csrc/stockham_strided_hx.hpp"
 using namespace pfa;
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s line %d\n", hipGetErrorString(e_), __LINE__); exit(1);} } while (0)
 template <typename Seq, typename T>
@@ -27,25 +27,29 @@ static std::vector<variant> g_variants;
 static void *g_in, *g_out;
 static long long g_total, g_inner, g_dist_outer; static unsigned g_stride; static int g_tiled = 0;
 
-template <typename Cfg, int KIND>
+static void *g_stw_lo, *g_stw_hi; static int g_stw_shift = 10;
+template <typename Cfg, int KIND, bool STW = false>
 void add(const char* name) {
   using T = typename Cfg::T;
   auto tw = make_twiddles<typename Cfg::Seq, T>();
   cx<T>* d_tw; CK(hipMalloc(&d_tw, tw.size() * sizeof(cx<T>)));
   CK(hipMemcpy(d_tw, tw.data(), tw.size() * sizeof(cx<T>), hipMemcpyHostToDevice));
   const void* fn;
-  if constexpr (KIND == 1) fn = (const void*)&stockham_strided_prefetch_kernel<Cfg, false, false>;
-  else fn = (const void*)&stockham_strided_kernel<Cfg, false, false>;
-  constexpr size_t lds = strided_lds_bytes<Cfg>();
+  if constexpr (KIND == 1) fn = (const void*)&stockham_strided_prefetch_kernel<Cfg, false, STW>;
+  else if constexpr (KIND == 2) fn = (const void*)&stockham_strided_hx_kernel<Cfg, false, STW>;
+  else fn = (const void*)&stockham_strided_kernel<Cfg, false, STW>;
+  constexpr size_t lds = KIND == 2 ? strided_hx_lds_bytes<Cfg>() : strided_lds_bytes<Cfg>();
   CK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  g_variants.push_back({name, Cfg::FPW, Cfg::WG, lds, fn, [d_tw](unsigned grid) {
+  g_variants.push_back({std::string(name) + (STW ? " +stw" : ""), Cfg::FPW, Cfg::WG, lds, fn, [d_tw](unsigned grid) {
     strided_args a{};
     a.in = g_in; a.out = g_out; a.tw = d_tw; a.total = g_total; a.inner = g_inner;
     a.in_dist_outer = a.out_dist_outer = g_dist_outer; a.in_stride = a.out_stride = g_stride; a.in_fdist = a.out_fdist = 1; a.scale = 1.0;
+    a.stw_lo = g_stw_lo; a.stw_hi = g_stw_hi; a.stw_shift = g_stw_shift; a.stw_cdiv = 1;
     if (g_tiled & 1) { a.in_gdist = (long long)Cfg::N * Cfg::FPW; a.in_stride = Cfg::FPW; }
     if (g_tiled & 2) { a.out_gdist = (long long)Cfg::N * Cfg::FPW; a.out_stride = Cfg::FPW; }
-    if constexpr (KIND == 1) hipLaunchKernelGGL((stockham_strided_prefetch_kernel<Cfg, false, false>), dim3(grid), dim3(Cfg::WG), lds, 0, a);
-    else hipLaunchKernelGGL((stockham_strided_kernel<Cfg, false, false>), dim3(grid), dim3(Cfg::WG), lds, 0, a);
+    if constexpr (KIND == 1) hipLaunchKernelGGL((stockham_strided_prefetch_kernel<Cfg, false, STW>), dim3(grid), dim3(Cfg::WG), lds, 0, a);
+    else if constexpr (KIND == 2) hipLaunchKernelGGL((stockham_strided_hx_kernel<Cfg, false, STW>), dim3(grid), dim3(Cfg::WG), lds, 0, a);
+    else hipLaunchKernelGGL((stockham_strided_kernel<Cfg, false, STW>), dim3(grid), dim3(Cfg::WG), lds, 0, a);
   }});
 }
 
@@ -54,17 +58,33 @@ int main() {
   CK(hipMalloc(&g_in, bytes)); CK(hipMalloc(&g_out, bytes)); CK(hipMemset(g_in, 0x3c, bytes));
   hipDeviceProp_t prop; CK(hipGetDeviceProperties(&prop, 0)); const int cus = prop.multiProcessorCount;
   using f = float; using d = double; constexpr int NT = 2;
+  {  // store-modifier tables of M = 2^20 (hi/lo split, shift 10), in the precision of the case
+#if TUNE_CASE == 3
+    using TT = double;
+#else
+    using TT = float;
+#endif
+    std::vector<cx<TT>> lo(1 << 10), hi((1 << 10) + 1);
+    for (int i = 0; i < (1 << 10); ++i) { const long double a = -2.0L * 3.14159265358979323846264338327950288L * i / 1048576.0L; lo[i] = {(TT)cosl(a), (TT)sinl(a)}; }
+    for (int i = 0; i <= (1 << 10); ++i) { const long double a = -2.0L * 3.14159265358979323846264338327950288L * ((i * 1024) % 1048576) / 1048576.0L; hi[i] = {(TT)cosl(a), (TT)sinl(a)}; }
+    CK(hipMalloc(&g_stw_lo, lo.size() * sizeof(lo[0]))); CK(hipMemcpy(g_stw_lo, lo.data(), lo.size() * sizeof(lo[0]), hipMemcpyHostToDevice));
+    CK(hipMalloc(&g_stw_hi, hi.size() * sizeof(hi[0]))); CK(hipMemcpy(g_stw_hi, hi.data(), hi.size() * sizeof(hi[0]), hipMemcpyHostToDevice));
+  }
 #if TUNE_CASE == 3
   using T = d; g_stride = 1024; g_inner = 1024; g_dist_outer = 1 << 20; g_total = 128 * 1024;
-  add<wg_cfg<d, radix_list<16, 8, 8>, 512, 8, 0, 0, TW_GLOBAL, 2, NT>, 0>("f64 16.8.8 wg512 fpw8");
-  add<wg_cfg<d, radix_list<16, 8, 8>, 512, 8, 0, 0, TW_GLOBAL, 2, NT, 0, 1>, 0>("f64 16.8.8 wg512 fpw8 TWL1");
-  add<wg_cfg<d, radix_list<16, 8, 8>, 512, 8, 0, 0, TW_GLOBAL, 2, NT, 0, 2>, 0>("f64 16.8.8 wg512 fpw8 TWL2");
-  add<wg_cfg<d, radix_list<16, 8, 8>, 512, 8, 0, 0, TW_GLOBAL, 1, NT>, 1>("f64 16.8.8 wg512 fpw8 PF");
-  add<wg_cfg<d, radix_list<32, 32>, 256, 8, 0, 0, TW_GLOBAL, 1, NT>, 0>("f64 32.32 wg256 fpw8");
-  add<wg_cfg<d, radix_list<32, 32>, 256, 8, 0, 0, TW_GLOBAL, 1, NT>, 1>("f64 32.32 wg256 fpw8 PF");
-  add<wg_cfg<d, radix_list<16, 8, 8>, 256, 4, 0, 0, TW_GLOBAL, 2, NT>, 0>("f64 16.8.8 wg256 fpw4");
-  add<wg_cfg<d, radix_list<16, 8, 8>, 256, 4, 0, 0, TW_GLOBAL, 2, NT>, 1>("f64 16.8.8 wg256 fpw4 PF");
-  add<wg_cfg<d, radix_list<16, 8, 8>, 1024, 8, 0, 0, TW_GLOBAL, 4, NT>, 0>("f64 16.8.8 wg1024(8pt) fpw8");
+  add<wg_cfg<d, radix_list<16, 8, 8>, 512, 8, 0, 0, TW_GLOBAL, 2, NT, 0, 1>, 0>("f64 16.8.8 wg512 fpw8 TWL1 (production)");
+  add<wg_cfg<d, radix_list<16, 8, 8>, 512, 8, 0, 0, TW_GLOBAL, 2, NT, 0, 1>, 0, true>("f64 16.8.8 wg512 fpw8 TWL1 (production)");
+  add<wg_cfg<d, radix_list<16, 8, 8>, 512, 8, 0, 0, TW_GLOBAL, 2, NT, 0, 1>, 2>("HX f64 16.8.8 wg512 fpw8 TWL1");
+  add<wg_cfg<d, radix_list<16, 8, 8>, 512, 8, 0, 0, TW_GLOBAL, 2, NT, 0, 1>, 2, true>("HX f64 16.8.8 wg512 fpw8 TWL1");
+  add<wg_cfg<d, radix_list<16, 8, 8>, 512, 8, 0, 0, TW_GLOBAL, 2, NT, 0, 2>, 2>("HX f64 16.8.8 wg512 fpw8 TWL2");
+  add<wg_cfg<d, radix_list<16, 8, 8>, 512, 8, 0, 0, TW_GLOBAL, 2, NT, 0, 2>, 2, true>("HX f64 16.8.8 wg512 fpw8 TWL2");
+  add<wg_cfg<d, radix_list<16, 8, 8>, 256, 8, 0, 0, TW_GLOBAL, 1, NT, 0, 1>, 2>("HX f64 16.8.8 wg256(32pt) fpw8 TWL1");
+  add<wg_cfg<d, radix_list<16, 8, 8>, 1024, 16, 0, 0, TW_GLOBAL, 4, NT, 0, 1>, 2>("HX f64 16.8.8 wg1024 fpw16 TWL1");
+  add<wg_cfg<d, radix_list<16, 8, 8>, 1024, 16, 0, 0, TW_GLOBAL, 4, NT, 0, 1>, 2, true>("HX f64 16.8.8 wg1024 fpw16 TWL1");
+  add<wg_cfg<d, radix_list<16, 8, 8>, 512, 16, 0, 0, TW_GLOBAL, 2, NT, 0, 1>, 2>("HX f64 16.8.8 wg512(32pt) fpw16 TWL1");
+  add<wg_cfg<d, radix_list<16, 8, 8>, 512, 16, 0, 0, TW_GLOBAL, 2, NT, 0, 1>, 2, true>("HX f64 16.8.8 wg512(32pt) fpw16 TWL1");
+  add<wg_cfg<d, radix_list<32, 32>, 512, 16, 0, 0, TW_GLOBAL, 2, NT, 0, 1>, 2>("HX f64 32.32 wg512 fpw16 TWL1");
+  add<wg_cfg<d, radix_list<32, 32>, 256, 8, 0, 0, TW_GLOBAL, 2, NT, 0, 1>, 2>("HX f64 32.32 wg256 fpw8 TWL1");
 #else
   using T = f; g_stride = 1024; g_inner = 1024; g_dist_outer = 1 << 20; g_total = 256 * 1024;
   add<wg_cfg<f, radix_list<16, 8, 8>, 1024, 16, 0, 0, TW_GLOBAL, 4, NT>, 0>("f32 16.8.8 wg1024 fpw16");
@@ -81,10 +101,10 @@ int main() {
   const gridopt gopts[] = {{"1xres", 0, 1}, {"2xres", 0, 2}, {"4xres", 0, 4}, {"grp/4", 1, 4}, {"grp/2", 1, 2}, {"grp/1", 1, 1}};
   const int NGO = 6;
   std::vector<std::vector<std::vector<float>>> times(g_variants.size(), std::vector<std::vector<float>>(NGO));
-  for (g_tiled = 0; g_tiled < 1; ++g_tiled) {
+  for (g_tiled = 0; g_tiled < 3; ++g_tiled) {
   for (auto& t : times) for (auto& u : t) u.clear();
   printf("---- tiled input %d, tiled output %d\n", g_tiled & 1, (g_tiled >> 1) & 1);
-  for (int round = 0; round < 5; ++round)
+  for (int round = 0; round < 4; ++round)
     for (size_t v = 0; v < g_variants.size(); ++v) {
       int occ = 0; CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, g_variants[v].fn, g_variants[v].wg, g_variants[v].lds));
       const long long groups = g_total / g_variants[v].fpw;
