@@ -5,57 +5,99 @@ out-of-place, inputs resident in HBM.
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
+`python bench.py --gpus N` with N > 1 and no torch.distributed.run environment starts its own N ranks (a CHILD
+torch.distributed.run process, before this process touches the GPU) and relays rank 0's line.
+
 A step is one pass of the hot path (one compute_forward over the whole batch).  Batches shard over GPUs with no
 data-path collective (weak scaling: every rank owns 65536 transforms); RCCL is used only for the barrier and the
-max-over-ranks of the elapsed time.  Rank 0 prints ONE JSON line.
+max / gather of the per-rank elapsed times.  Rank 0 prints ONE JSON line.
+
+Timing: the K timed steps run back to back between barrier + synchronize on both sides (wall clock -> `value`,
+`ms_per_step`, nothing else in the loop); a SECOND loop of K steps brackets every launch with HIP events on the
+plan's stream (-> `roofline.kernel_ms`, `roofline.achieved`), so the event records never sit in the timed region.
+
+--config selects the other single-GPU workloads with the same JSON fields: c3 / c5 (BASELINE configs[2] / [4]) and
+the reference's own bench set ref16 / ref256 / ref4096 / ref65536 (test/bench/portfft/bench_float.cpp:49-52).
 """
 import argparse
+import glob
 import json
 import math
 import os
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
-os.environ.setdefault("PFFT_JIT_CACHE_DIR", os.path.join(ROOT, "build", "jit_cache"))  # only --config c3/c5 paths compile
+os.environ.setdefault("PFFT_JIT_CACHE_DIR", os.path.join(ROOT, "build", "jit_cache"))  # only non-headline configs compile
 for _p in (ROOT, os.path.join(ROOT, "tests")):
     if _p not in sys.path:
         sys.path.insert(0, _p)
 
-N = 4096
-BATCH_PER_GPU = 65536
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+METRIC = "GFLOP/s (5Nlog2N) + achieved-HBM% for fp32 C2C 1D, 1/2/4/8 GPUs"
+
+# name -> (lengths, transforms per GPU, precision, description, launches per execute)
+WORKLOADS = {
+    "c2": ([4096], 65536, "f32", "BASELINE configs[1]: fp32 C2C 1D forward N=4096 batch=65536 per GPU", 1),
+    "c3": ([1 << 20], 128, "f64", "BASELINE configs[2]: fp64 C2C 1D N=1048576 batch=128", 2),
+    "c5": ([1024, 1024], 256, "f32", "BASELINE configs[4]: fp32 C2C 2D 1024x1024 batch=256", 2),
+    "ref16": ([16], 8 * 1024 * 1024, "f32", "reference bench set small_1d: fp32 N=16 batch=8Mi", 1),
+    "ref256": ([256], 512 * 1024, "f32", "reference bench set medium_small_1d: fp32 N=256 batch=512Ki", 1),
+    "ref4096": ([4096], 32 * 1024, "f32", "reference bench set medium_large_1d: fp32 N=4096 batch=32Ki", 1),
+    "ref65536": ([65536], 2048, "f32", "reference bench set large_1d: fp32 N=65536 batch=2Ki", 2),
+}
 
 
-def pmc_traffic():
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE x2 on gfx950 +
-    WRITE_SIZE, see tools/summarize_pmc.py and profiles/r*_pmc_traffic.json); None when no summary is committed.
-    PMC counters cannot be collected from inside this process, so the figure comes from the same command run under
-    rocprofv3 --pmc and is reported with its provenance."""
-    import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
-    if not files:
-        return None, None
-    try:
-        with open(files[-1]) as f:
-            d = json.load(f)
-        return float(d["traffic_bytes_per_launch"]), os.path.relpath(files[-1], ROOT)
-    except (OSError, ValueError, KeyError):
-        return None, None
+def pmc_traffic(config):
+    """HBM bytes per execute from the committed rocprofv3 PMC passes of the same command (FETCH_SIZE x2 on gfx950 +
+    WRITE_SIZE, separate passes: tools/summarize_pmc.py -> profiles/r*_pmc_traffic*.json); None when no summary is
+    committed for this config.  PMC counters cannot be collected from inside this process, so the figure is reported
+    with its provenance."""
+    names = ["r*_pmc_traffic.json"] if config == "c2" else []
+    names.append("r*_pmc_traffic_%s.json" % config)
+    files = sorted(f for n in names for f in glob.glob(os.path.join(ROOT, "profiles", n)))
+    for path in reversed(files):
+        try:
+            with open(path) as f:
+                return float(json.load(f)["traffic_bytes_per_launch"]), os.path.relpath(path, ROOT)
+        except (OSError, ValueError, KeyError):
+            continue
+    return None, None
 
 
-def cpu_baseline(sample_seconds=12.0):
-    """The oracle (CPU restatement of the reference algorithm, kind 'port') timed on this host's cores on a bounded
-    sample of the same workload: fp32 N=4096 forward, batch sized to take about `sample_seconds`."""
+def _numpy_slice_worker(args):
+    import numpy as np
+    seed, rows, n, seconds = args
+    rng = np.random.Generator(np.random.SFC64(seed))
+    x = (rng.uniform(-1, 1, (rows, n)) + 1j * rng.uniform(-1, 1, (rows, n))).astype(np.complex64)
+    np.fft.fft(x)
+    t0, reps = time.perf_counter(), 0
+    while time.perf_counter() - t0 < seconds:
+        np.fft.fft(x)
+        reps += 1
+    return rows * reps, time.perf_counter() - t0
+
+
+def cpu_baseline(n, sample_seconds=10.0):
+    """CPU baselines on this host's cores, bounded samples of the headline workload (fp32 C2C forward, length n):
+      value                  the oracle (oracle/: the reference's algorithm restated in C, kind 'port'), OpenMP over
+                             transforms on every core.  It EMULATES the reference's sub-group lanes one by one (that is
+                             what makes it a faithful restatement), which costs ~100x per core against a tuned CPU FFT:
+                             it is the parity checker timed, not a statement about CPU FFT speed.
+      numpy_allcore_gflops   NumPy's pocketfft on every core (a process pool over batch slices): what this host's
+                             CPUs do on the same transforms with a production CPU library."""
+    import multiprocessing as mp
     import numpy as np
     import oracle_binding as ob
 
     cores = max(1, min(os.cpu_count() or 1, ob.lib().pfo_max_threads()))
     rng = np.random.Generator(np.random.SFC64(0))
+    flop = 5.0 * n * math.log2(n)
 
     def run(batch):
-        x = (rng.uniform(-1, 1, (batch, N)) + 1j * rng.uniform(-1, 1, (batch, N))).astype(np.complex64).ravel()
-        d = ob.make_desc([N], "f32", batch=batch)
+        x = (rng.uniform(-1, 1, (batch, n)) + 1j * rng.uniform(-1, 1, (batch, n))).astype(np.complex64).ravel()
+        d = ob.make_desc([n], "f32", batch=batch)
         t0 = time.perf_counter()
         ob.compute(d, ob.FORWARD, x, threads=cores)
         return time.perf_counter() - t0
@@ -69,71 +111,59 @@ def cpu_baseline(sample_seconds=12.0):
     while total < sample_seconds and reps < 64:  # many-core hosts finish the whole batch in ~2 s: repeat it
         total += run(batch)
         reps += 1
-    gflops = 5.0 * N * math.log2(N) * batch * reps / total / 1e9
-    # sanity row: NumPy's pocketfft on one core, same transform, ~1 s
-    xs = (rng.uniform(-1, 1, (256, N)) + 1j * rng.uniform(-1, 1, (256, N))).astype(np.complex64)
-    np.fft.fft(xs)
-    t0, nrep = time.perf_counter(), 0
-    while time.perf_counter() - t0 < 1.0:
-        np.fft.fft(xs)
-        nrep += 1
-    numpy_gflops = 5.0 * N * math.log2(N) * 256 * nrep / (time.perf_counter() - t0) / 1e9
+    gflops = flop * batch * reps / total / 1e9
+    # NumPy (pocketfft): one core, then every core through a process pool (each worker owns a slice of the batch)
+    one = _numpy_slice_worker((1, 256, n, 1.0))
+    numpy_1 = flop * one[0] / one[1] / 1e9
+    workers = max(1, os.cpu_count() or 1)
+    try:
+        with mp.get_context("fork").Pool(workers) as pool:
+            parts = pool.map(_numpy_slice_worker, [(10 + i, 256, n, 3.0) for i in range(workers)])
+        numpy_all = sum(flop * rows / secs for rows, secs in parts) / 1e9
+    except (OSError, ValueError):
+        numpy_all, workers = None, 0
     return {"value": round(gflops, 3), "unit": "GFLOP/s", "cores": cores, "kind": "port",
-            "numpy_1core_gflops": round(numpy_gflops, 3),
+            "numpy_1core_gflops": round(numpy_1, 3),
+            "numpy_allcore_gflops": None if numpy_all is None else round(numpy_all, 3), "numpy_cores": workers,
+            "note": "oracle emulates the reference's sub-group lanes one by one (parity checker, ~100x slower per "
+                    "core than pocketfft); numpy_allcore_gflops is the credible CPU figure for this host",
             "sample": "oracle/ (reference algorithm restated in C, OpenMP over transforms), fp32 C2C forward N=%d, "
-                      "batch=%d of the 65536 x %d passes, %.1f s" % (N, batch, reps, total)}
+                      "batch=%d of the 65536 x %d passes, %.1f s; numpy: 256 transforms per worker, 3 s"
+                      % (n, batch, reps, total)}
 
 
-def other_config(args):
-    """BASELINE configs[2] / configs[4] on one GPU: same protocol, same JSON fields (no cpu_baseline)."""
-    import torch
-    import portfft_amd as pf
-    import numpy as np
+def kernel_label(plan, lengths):
+    """name the launches of one execute from the planner's own record (pfft_plan_get_info)"""
+    info = plan.info()
+    tiers = {0: "register", 1: "workgroup", 2: "generic", 3: "global(four-step)"}
+    parts = []
+    for i in range(info.rank):
+        d = info.dims[i]
+        parts.append("dim%d n=%d %s radices/factors %s wg%d x%d ffts lds %d B" % (
+            i, d.length, tiers.get(d.tier, "?"), "x".join(str(d.factors[k]) for k in range(d.n_factors)),
+            d.workgroup_size, d.ffts_per_workgroup, d.lds_bytes))
+    return "; ".join(parts)
 
-    torch.cuda.set_device(0)
-    if args.config == "c3":
-        lengths, batch, prec, dt, name = [1 << 20], 128, "f64", torch.complex128, "BASELINE configs[2]: fp64 C2C 1D N=1048576 batch=128"
-    else:
-        lengths, batch, prec, dt, name = [1024, 1024], 256, "f32", torch.complex64, "BASELINE configs[4]: fp32 C2C 2D 1024x1024 batch=256"
-    n = int(np.prod(lengths))
-    d = pf.descriptor(lengths, prec)
-    d.number_of_transforms = batch
-    plan = d.commit()
-    xs = []
-    for _ in range(2):
-        x = torch.empty(batch * n, dtype=dt, device="cuda")
-        torch.view_as_real(x).uniform_(-1, 1)
-        xs.append(x)
-    y = torch.empty_like(xs[0])
-    for w in range(args.warmup):
-        plan.compute_forward(xs[w % 2], y)
-    torch.cuda.synchronize()
-    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    s.record()
-    for k in range(args.steps):
-        plan.compute_forward(xs[k % 2], y)
-    e.record()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    dev_ms = s.elapsed_time(e) / args.steps
-    last = xs[(args.steps - 1) % 2].view([batch] + lengths)[batch - 1].cpu().numpy()
-    ref = np.fft.fftn(last.astype(np.complex128))
-    got = y.view([batch] + lengths)[batch - 1].cpu().numpy()
-    err = float(np.linalg.norm(got - ref) / np.linalg.norm(ref))
-    assert err < 1e-4, err
-    esz = 16 if prec == "f64" else 8
-    alg = 2.0 * n * batch * esz
-    print(json.dumps({
-        "metric": "GFLOP/s (5Nlog2N) + achieved-HBM%% (%s)" % args.config, "value": round(5.0 * n * math.log2(n) * batch / (elapsed / args.steps) / 1e9, 1),
-        "unit": "GFLOP/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(elapsed / args.steps * 1e3, 5), "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": prec, "data": "synthetic",
-        "config": {"workload": name + ", out-of-place, inputs resident in HBM", "parity_rel_l2_vs_numpy": err},
-        "roofline": {"bound": "hbm", "achieved": round(alg / (dev_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": round(alg / (dev_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
-                     "kernel": "two launches per execute (see DESIGN.md 3.3)", "kernel_ms": round(dev_ms, 5),
-                     "algorithmic_bytes_per_launch": alg}}))
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a torch.distributed.run environment: start the N ranks as a CHILD process
+    (never exec: this process may not have touched the GPU yet, and must not be replaced either way) and relay."""
+    port = os.environ.get("PFFT_BENCH_PORT", str(29500 + (os.getpid() % 400)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", port, os.path.abspath(__file__), "--gpus", str(args.gpus),
+           "--steps", str(args.steps), "--warmup", str(args.warmup), "--config", args.config]
+    if args.no_cpu_baseline:
+        cmd.append("--no-cpu-baseline")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    for ln in p.stdout.splitlines():
+        if not ln.startswith("{"):
+            print(ln, file=sys.stderr)
+    if lines:
+        print(lines[-1])
+    return p.returncode if p.returncode != 0 or lines else 1
 
 
 def main():
@@ -142,110 +172,128 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--config", default="c2", choices=["c2", "c3", "c5"],
-                    help="c2 (default, the headline line): fp32 N=4096 batch=65536; c3: fp64 N=2^20 batch=128; "
-                         "c5: fp32 2-D 1024x1024 batch=256 -- the other single-GPU configs of BASELINE.json, "
-                         "reported with the same fields")
+    ap.add_argument("--config", default="c2", choices=sorted(WORKLOADS),
+                    help="c2 (default, the headline line); c3 / c5: the other single-GPU configs of BASELINE.json; "
+                         "ref16 / ref256 / ref4096 / ref65536: the reference's own bench set")
     args = ap.parse_args()
-    if args.config != "c2":
-        return other_config(args)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args))
+
+    import numpy as np
+
+    lengths, batch_per_gpu, prec, name, launches = WORKLOADS[args.config]
+    n = int(np.prod(lengths))
+    # the CPU baseline runs first, before this process initialises the GPU (its NumPy leg forks a worker pool)
+    cpu = None
+    if int(os.environ.get("WORLD_SIZE", "1")) == 1 and args.config == "c2" and not args.no_cpu_baseline:
+        cpu = cpu_baseline(n)
 
     import torch
     import portfft_amd as pf
-
     from portfft_amd.sharding import env_world, process_group, shard_range
+
+    cdt = torch.complex64 if prec == "f32" else torch.complex128
+    esz = 8 if prec == "f32" else 16
 
     world, rank, local_rank = env_world()
     distributed = world > 1
-    # one process per GPU; PFFT_BENCH_BACKEND=gloo + PFFT_BENCH_ONE_DEVICE=1 exist only to smoke-test the multi-rank
-    # plumbing on a single-GPU box (every rank on device 0, scalar collectives over gloo)
+    if args.gpus != world and rank == 0:
+        print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
+    # one process per GPU; PFFT_BENCH_ONE_DEVICE=1 / PFFT_BENCH_BACKEND=gloo exist only to exercise the multi-rank
+    # plumbing on a single-GPU box (every rank on device 0)
     one_device = os.environ.get("PFFT_BENCH_ONE_DEVICE") == "1"
     backend = os.environ.get("PFFT_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local_rank if (distributed and not one_device) else 0)
-    cuda_dev = torch.device("cuda", torch.cuda.current_device())
-    pg = process_group(backend, cuda_dev if backend == "nccl" else torch.device("cpu"))
-    if args.gpus != world and rank == 0:
-        print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
-    # weak scaling: the global batch is BATCH_PER_GPU * world transforms, sharded contiguously
-    lo, hi = shard_range(BATCH_PER_GPU * world, world, rank)
-    assert hi - lo == BATCH_PER_GPU
-
     dev = torch.device("cuda", torch.cuda.current_device())
+    pg = process_group(backend, dev)  # RCCL communicator created and probed here, before any timing
+    # weak scaling: the global batch is batch_per_gpu * world transforms, sharded contiguously, no data-path collective
+    lo, hi = shard_range(batch_per_gpu * world, world, rank)
+    assert hi - lo == batch_per_gpu
+
     # synthetic inputs resident in HBM: uniform(-1, 1) real and imaginary parts, two buffers rotated per step
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
     inputs = []
     for _ in range(2):
-        x = torch.empty(BATCH_PER_GPU * N, dtype=torch.complex64, device=dev)
+        x = torch.empty(batch_per_gpu * n, dtype=cdt, device=dev)
         torch.view_as_real(x).uniform_(-1, 1, generator=gen)
         inputs.append(x)
-    out = torch.empty(BATCH_PER_GPU * N, dtype=torch.complex64, device=dev)
+    out = torch.empty(batch_per_gpu * n, dtype=cdt, device=dev)
 
-    desc = pf.descriptor([N], "f32")
-    desc.number_of_transforms = BATCH_PER_GPU
-    plan = desc.commit()  # torch's current stream: the torch.cuda.Event timers below see the kernels
-
-    barrier = pg.barrier
+    desc = pf.descriptor(lengths, prec)
+    desc.number_of_transforms = batch_per_gpu
+    plan = desc.commit()  # torch's current stream
 
     for w in range(args.warmup):
-        plan.compute_forward(inputs[w % 2], out)
-    barrier()
-    starts = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
-    stops = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+        plan.compute_forward(inputs[w % 2], out, want_event=False)
+    # ---- the timed region: exactly `steps` steps, wall clock, nothing but the launches inside ----
+    pg.barrier()
     t0 = time.perf_counter()
     for k in range(args.steps):
+        plan.compute_forward(inputs[k % 2], out, want_event=False)
+    torch.cuda.synchronize()
+    my_elapsed = time.perf_counter() - t0
+    pg.barrier()
+    elapsed = pg.max(my_elapsed)
+    per_rank = pg.gather([my_elapsed])
+
+    # ---- second loop: per-launch device time (HIP events on the plan's stream = torch's current stream) ----
+    starts = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    stops = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    for k in range(args.steps):
         starts[k].record()
-        plan.compute_forward(inputs[k % 2], out)
+        plan.compute_forward(inputs[k % 2], out, want_event=False)
         stops[k].record()
     torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    barrier()
-    elapsed = pg.max(elapsed)
     kernel_ms = [s.elapsed_time(e) for s, e in zip(starts, stops)]
     avg_kernel_ms = sum(kernel_ms) / len(kernel_ms)
 
-    # parity spot check of the timed output (last step's input) against NumPy on 4 transforms
-    import numpy as np
-    last_in = inputs[(args.steps - 1) % 2].view(BATCH_PER_GPU, N)
+    # parity spot check of the timed output (last step's input) against NumPy
+    last_in = inputs[(args.steps - 1) % 2].view([batch_per_gpu] + lengths)
+    got_all = out.view([batch_per_gpu] + lengths)
     worst = 0.0
-    for b in (0, 777, 40000, BATCH_PER_GPU - 1):
-        ref = np.fft.fft(last_in[b].cpu().numpy().astype(np.complex128))
-        got = out.view(BATCH_PER_GPU, N)[b].cpu().numpy()
+    for b in sorted({0, 777 % batch_per_gpu, (batch_per_gpu * 5) // 8, batch_per_gpu - 1}):
+        ref = np.fft.fftn(last_in[b].cpu().numpy().astype(np.complex128))
+        got = got_all[b].cpu().numpy()
         worst = max(worst, float(np.linalg.norm(got - ref) / np.linalg.norm(ref)))
     assert worst < 1e-4, "parity check failed: rel-L2 %g" % worst
 
     if rank == 0:
-        flops_per_step = 5.0 * N * math.log2(N) * BATCH_PER_GPU * world
-        ms_per_step = elapsed / args.steps * 1e3
+        flops_per_step = 5.0 * n * math.log2(n) * batch_per_gpu * world
         gflops = flops_per_step / (elapsed / args.steps) / 1e9
-        alg_bytes = 2.0 * N * BATCH_PER_GPU * 8  # per launch: every element read once + written once
+        alg_bytes = 2.0 * n * batch_per_gpu * esz  # per execute: every element read once + written once
         achieved = alg_bytes / (avg_kernel_ms * 1e-3) / 1e9
-        traffic, traffic_src = pmc_traffic()
+        traffic, traffic_src = pmc_traffic(args.config)
         result = {
-            "metric": "GFLOP/s (5Nlog2N) + achieved-HBM% for fp32 C2C 1D, 1/2/4/8 GPUs",
+            "metric": METRIC if args.config == "c2" else "GFLOP/s (5Nlog2N) + achieved-HBM%% (%s)" % args.config,
             "value": round(gflops, 1),
             "unit": "GFLOP/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 5),
+            "ms_per_step": round(elapsed / args.steps * 1e3, 5),
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": prec,
             "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: fp32 C2C 1D forward N=4096 batch=65536 per GPU, out-of-place, "
-                                   "interleaved, inputs resident in HBM", "n": N, "batch_per_gpu": BATCH_PER_GPU,
-                       "global_batch": BATCH_PER_GPU * world, "sharding": "batches, no data-path collective",
+            "config": {"workload": name + ", out-of-place, interleaved, inputs resident in HBM", "lengths": lengths,
+                       "batch_per_gpu": batch_per_gpu, "global_batch": batch_per_gpu * world,
+                       "sharding": "batches, no data-path collective",
                        "barrier_backend": ("rccl" if pg.backend == "nccl" else pg.backend) if distributed else None,
+                       "per_rank_elapsed_ms": [round(r[0] * 1e3, 3) for r in per_rank],
                        "parity_rel_l2_vs_numpy": worst},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "traffic_source": traffic_src,
-                         "kernel": "stockham_wg_prefetch_kernel<f32, 16x16x16, wg256, twiddles in VGPRs>", "kernel_ms": round(avg_kernel_ms, 5),
-                         "algorithmic_bytes_per_launch": alg_bytes},
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
+                         "kernel": kernel_label(plan, lengths), "launches_per_execute": launches,
+                         "kernel_ms": round(avg_kernel_ms, 5),
+                         "algorithmic_bytes_per_launch": alg_bytes,
+                         "note": "achieved = algorithmic bytes of one execute / event-timed duration of its launches"
+                                 + ("" if launches == 1 else " (two HBM passes: 0.5 is the ceiling)")},
         }
-        if world == 1 and not args.no_cpu_baseline:
-            result["cpu_baseline"] = cpu_baseline()
+        if pg.fallback_reason:
+            result["config"]["rccl_fallback_reason"] = pg.fallback_reason
+        if cpu is not None:
+            result["cpu_baseline"] = cpu
         print(json.dumps(result))
     pg.close()
 

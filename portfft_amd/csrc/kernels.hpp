@@ -69,6 +69,10 @@ struct strided_kernel {
   hipFunction_t mfn_mixed[4];
   /// row-staged forms of runtime-compiled entries: mfn_row[row_out * 2 + backward] (lds_bytes_row as above)
   hipFunction_t mfn_row[4];
+  /// tiled-input form (strided_pass TIN): the four-step stage B behind a group-major stage A of the same group
+  /// width; fn_tin[backward]; null when not instantiated
+  const void* fn_tin[2];
+  hipError_t (*launch_tin)(hipStream_t stream, unsigned grid, const strided_args& args, int backward);
   /// 1: alternative entry for the same length, preferred when both sides of the stage are column-shaped
   int wide;
   /// 1: alternative entry preferred when one side of the stage is row-shaped (its `_row` forms pay at this length)

@@ -216,6 +216,27 @@ strided_kernel with_rows(strided_kernel k) {
 }
 
 template <typename Cfg>
+hipError_t launch_strided_tin(hipStream_t stream, unsigned grid, const strided_args& args, int backward) {
+  constexpr size_t lds = strided_lds_bytes<Cfg>();
+  if (backward) {
+    hipLaunchKernelGGL((stockham_strided_kernel<Cfg, true, false, 0, true>), dim3(grid), dim3(Cfg::WG), lds, stream, args);
+  } else {
+    hipLaunchKernelGGL((stockham_strided_kernel<Cfg, false, false, 0, true>), dim3(grid), dim3(Cfg::WG), lds, stream, args);
+  }
+  return hipGetLastError();
+}
+
+/// add the tiled-input form (four-step stage B reading a group-major intermediate) to an entry
+template <typename Cfg>
+strided_kernel with_tin(strided_kernel k) {
+  static_assert(tin_supported<Cfg>(), "see tin_supported()");
+  k.fn_tin[0] = reinterpret_cast<const void*>(&stockham_strided_kernel<Cfg, false, false, 0, true>);
+  k.fn_tin[1] = reinterpret_cast<const void*>(&stockham_strided_kernel<Cfg, true, false, 0, true>);
+  k.launch_tin = &launch_strided_tin<Cfg>;
+  return k;
+}
+
+template <typename Cfg>
 hipError_t launch_strided_split(hipStream_t stream, unsigned grid, const strided_args& args, int backward) {
   constexpr size_t lds = strided_lds_bytes<Cfg>();
   if (backward) {

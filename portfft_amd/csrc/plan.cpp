@@ -55,6 +55,7 @@ struct stage {
   int alias_scratch = 0;
   int store_modifier = 0;
   int row_mode = 0;  // 0: both sides addressed by the passes, 1: row-shaped input staged, 2: row-shaped output staged
+  int tiled_in = 0;  // 1: the kernel's tiled-input form (strided_kernel::launch_tin)
   int in_buf = BUF_IN, out_buf = BUF_OUT;
   long long count = 0;  // number of FFTs
   unsigned grid = 1;
@@ -494,6 +495,11 @@ struct plan_t {
         hip_check(hipFuncSetAttribute(k->fn_split[i / 2], hipFuncAttributeMaxDynamicSharedMemorySize,
                                       static_cast<int>(k->lds_bytes)),
                   "hipFuncSetAttribute");
+        if (k->fn_tin[i / 2] != nullptr) {
+          hip_check(hipFuncSetAttribute(k->fn_tin[i / 2], hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        static_cast<int>(k->lds_bytes)),
+                    "hipFuncSetAttribute");
+        }
       }
     }
     const long long groups = strided_groups(count, a.inner, k->fpw);
@@ -910,6 +916,10 @@ struct plan_t {
         sb.sa.in_tile_shift = sh;
         sb.sa.in_stride = static_cast<unsigned>(n1 * t);
         sb.sa.in_fdist = static_cast<unsigned>(t);
+        // square tiles: stage B takes its lanes element-fastest inside a tile (strided_pass TIN)
+        if (sb.strided->launch_tin != nullptr && sb.strided->fpw == t && getenv("PFFT_NO_TILED_LANES") == nullptr) {
+          sb.tiled_in = 1;
+        }
       }
     }
     out.push_back(sb);
@@ -1151,6 +1161,10 @@ struct plan_t {
                       ? s.strided->launch_row(stream, grid, a, s.backward, s.row_mode - 1)
                       : jit_launch_strided_row(s.strided, stream, grid, a, s.backward, s.row_mode - 1),
                   "kernel launch");
+        return;
+      }
+      if (s.tiled_in != 0) {
+        hip_check(s.strided->launch_tin(stream, grid, a, s.backward), "kernel launch");
         return;
       }
       hip_check(s.strided->launch != nullptr

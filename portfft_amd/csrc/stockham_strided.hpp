@@ -110,10 +110,25 @@ PFA_DEV void strided_store_butterfly(const IO& io, const strided_args& a, unsign
   });
 }
 
-template <typename Cfg, bool BWD, bool STW, int P, typename IO, bool ROW_IN = false, bool ROW_OUT = false>
+/// TIN (tiled input, the four-step stage B behind a group-major stage A): the input of the group is a sequence of
+/// tiles [f][i % FPW] of FPW x FPW elements (strided_args::in_tile_shift == log2 FPW).  Addressed f-fastest a wave
+/// would read one whole tile per instruction but with its lanes transposed inside it (16-byte pieces 128 B apart:
+/// 5.1 instead of 5.8 TB/s on the C3 stage B, profiles/r2_notes.md).  With TIN pass 0 takes its lanes
+/// element-fastest inside a tile -- lane = (i % FPW) + FPW * f + FPW^2 * (i / FPW) -- so every wave-instruction reads
+/// consecutive addresses, and the exchange behind pass 0 stores f ^ (i % FPW) in place of f so that the scatter
+/// (lane stride R0 elements = a multiple of all banks) stays conflict-free; pass 1 reads through the same
+/// permutation, the later passes are unchanged.  Needs FPW^2 | WG and (N / R0) % FPW == 0.
+template <typename Cfg>
+constexpr bool tin_supported() {
+  return Cfg::NP >= 2 && (Cfg::FPW & (Cfg::FPW - 1)) == 0 && Cfg::WG % (Cfg::FPW * Cfg::FPW) == 0 &&
+         (Cfg::N / Cfg::Seq::r[0]) % Cfg::FPW == 0 && (Cfg::N / Cfg::Seq::r[0]) % Cfg::TPF == 0;
+}
+
+template <typename Cfg, bool BWD, bool STW, int P, typename IO, bool ROW_IN = false, bool ROW_OUT = false,
+          bool TIN = false>
 PFA_DEV void strided_pass(const IO& io, const strided_args& a, unsigned f,
                           unsigned tid, bool live, long long c0, cx<typename Cfg::T>* lds,
-                          const cx<typename Cfg::T>* __restrict__ tw) {
+                          const cx<typename Cfg::T>* __restrict__ tw, long long nlive = 0) {
   using T = typename Cfg::T;
   using Seq = typename Cfg::Seq;
   constexpr int R = Seq::r[P];
@@ -127,6 +142,17 @@ PFA_DEV void strided_pass(const IO& io, const strided_args& a, unsigned f,
   constexpr int FPW = strided_pitch<Cfg, ROW_IN || ROW_OUT>();
   [[maybe_unused]] constexpr unsigned ES_IN = IO::ES_IN;
 
+  constexpr bool tin0 = TIN && P == 0;  // lanes element-fastest inside the input tiles
+  constexpr bool tin1 = TIN && P == 1;  // reads through the permutation pass 0 stored with
+  [[maybe_unused]] unsigned tin_jl = 0;
+  if constexpr (tin0) {
+    static_assert(first && tin_supported<Cfg>(), "TIN: see tin_supported()");
+    const unsigned lane = threadIdx.x;
+    tin_jl = lane % Cfg::FPW;
+    f = (lane / Cfg::FPW) % Cfg::FPW;
+    tid = (lane / (Cfg::FPW * Cfg::FPW)) * Cfg::FPW + tin_jl;
+    live = static_cast<long long>(f) < nlive;
+  }
   cx<T> v[BPT][R];
   sfor<0, BPT>([&](auto i_) PFA_LAMBDA {
     constexpr int i = decltype(i_)::value;
@@ -143,6 +169,21 @@ PFA_DEV void strided_pass(const IO& io, const strided_args& a, unsigned f,
           if constexpr (BWD) x.im = -x.im;
           v[i][t] = x;
         });
+      } else if constexpr (tin1) {
+        constexpr int R0 = Seq::r[0];
+        if constexpr (NB % (R0 * Cfg::FPW) == 0) {  // the permutation does not depend on the butterfly leg
+          const cx<T>* p = lds + j * FPW + (f ^ ((j / R0) % Cfg::FPW));
+          sfor<0, R>([&](auto t_) PFA_LAMBDA {
+            constexpr int t = decltype(t_)::value;
+            v[i][t] = p[t * NB * FPW];
+          });
+        } else {
+          sfor<0, R>([&](auto t_) PFA_LAMBDA {
+            constexpr int t = decltype(t_)::value;
+            const unsigned e = j + t * NB;
+            v[i][t] = lds[e * FPW + (f ^ ((e / R0) % Cfg::FPW))];
+          });
+        }
       } else {
         const cx<T>* p = lds + j * FPW + f;
         sfor<0, R>([&](auto t_) PFA_LAMBDA {
@@ -175,7 +216,8 @@ PFA_DEV void strided_pass(const IO& io, const strided_args& a, unsigned f,
       if constexpr (last) {
         strided_store_butterfly<Cfg, BWD, STW, R, Ns>(io, a, f, base, live, c0, v[i]);
       } else {
-        cx<T>* p = lds + base * FPW + f;
+        // TIN pass 0: element e = j * R0 + u of FFT f goes to slot f ^ ((e / R0) % FPW) = f ^ (j % FPW)
+        cx<T>* p = lds + base * FPW + (tin0 ? (f ^ (j % Cfg::FPW)) : f);
         sfor<0, R>([&](auto u_) PFA_LAMBDA {
           constexpr int u = decltype(u_)::value;
           p[u * Ns * FPW] = v[i][u];
@@ -186,12 +228,14 @@ PFA_DEV void strided_pass(const IO& io, const strided_args& a, unsigned f,
   if constexpr (!last) __syncthreads();
 }
 
-template <typename Cfg, bool BWD, bool STW, int P, typename IO, bool ROW_IN = false, bool ROW_OUT = false>
+template <typename Cfg, bool BWD, bool STW, int P, typename IO, bool ROW_IN = false, bool ROW_OUT = false,
+          bool TIN = false>
 PFA_DEV void strided_passes(const IO& io, const strided_args& a, unsigned f, unsigned tid, bool live, long long c0,
-                            cx<typename Cfg::T>* lds, const cx<typename Cfg::T>* __restrict__ tw) {
+                            cx<typename Cfg::T>* lds, const cx<typename Cfg::T>* __restrict__ tw,
+                            long long nlive = 0) {
   if constexpr (P < Cfg::NP) {
-    strided_pass<Cfg, BWD, STW, P, IO, ROW_IN, ROW_OUT>(io, a, f, tid, live, c0, lds, tw);
-    strided_passes<Cfg, BWD, STW, P + 1, IO, ROW_IN, ROW_OUT>(io, a, f, tid, live, c0, lds, tw);
+    strided_pass<Cfg, BWD, STW, P, IO, ROW_IN, ROW_OUT, TIN>(io, a, f, tid, live, c0, lds, tw, nlive);
+    strided_passes<Cfg, BWD, STW, P + 1, IO, ROW_IN, ROW_OUT, TIN>(io, a, f, tid, live, c0, lds, tw, nlive);
   }
 }
 
@@ -433,7 +477,7 @@ PFA_DEV void strided_copy_twiddles(cx<typename Cfg::T>* lds, const cx<typename C
   }
 }
 
-template <typename Cfg, bool BWD, bool STW, int SPLIT = 0>
+template <typename Cfg, bool BWD, bool STW, int SPLIT = 0, bool TIN = false>
 __global__ __launch_bounds__(Cfg::WG, Cfg::OCC) void stockham_strided_kernel(const strided_args a) {
   using T = typename Cfg::T;
   // (a single-pass plan -- one lane per FFT, the reference's WORKITEM tier on strided data -- uses no LDS at all)
@@ -447,9 +491,10 @@ __global__ __launch_bounds__(Cfg::WG, Cfg::OCC) void stockham_strided_kernel(con
   for (long long g = blockIdx.x; g < ngroups; g += gridDim.x) {
     bool live;
     long long c0;
-    const auto io = strided_group<Cfg, SPLIT>(a, g, f, &live, &c0);
+    long long nlive;
+    const auto io = strided_group<Cfg, SPLIT>(a, g, f, &live, &c0, &nlive);
     // no barrier needed here: the last pass ends its LDS reads with a barrier before the next group's first write
-    strided_passes<Cfg, BWD, STW, 0>(io, a, f, tid, live, c0, lds, tw);
+    strided_passes<Cfg, BWD, STW, 0, decltype(io), false, false, TIN>(io, a, f, tid, live, c0, lds, tw, nlive);
   }
 }
 

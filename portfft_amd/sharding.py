@@ -27,9 +27,16 @@ def env_world():
 
 
 class process_group:
-    """Thin wrapper: barrier, max-over-ranks and gather of scalars.  backend 'nccl' (= RCCL on ROCm) or 'gloo'."""
+    """Thin wrapper: barrier, max-over-ranks and gather of scalars.
 
-    def __init__(self, backend, device=None):
+    The default group is always gloo (the control plane).  With backend 'nccl' (= RCCL on ROCm) an RCCL sub-group is
+    created on top of it and probed with one all-reduce before any timing; whether it is used is decided
+    COLLECTIVELY -- the ranks all-reduce (MIN) their success flags over gloo -- so either every rank runs its barrier
+    and scalar collectives over RCCL or every rank runs them over gloo; a rank never changes backend on its own.
+    `backend` after construction says which one carries the barrier ('nccl' or 'gloo')."""
+
+    def __init__(self, backend, device=None, timeout_s=120):
+        import datetime
         import torch
         import torch.distributed as dist
         self.torch, self.dist = torch, dist
@@ -37,33 +44,53 @@ class process_group:
         self.device = device if device is not None else torch.device("cpu")
         self.active = self.world > 1
         self.backend = backend
-        if self.active and not dist.is_initialized():
+        self.group = None  # the group the barrier / scalars travel on (None = the default gloo group)
+        self.fallback_reason = None
+        if not self.active:
+            return
+        if not dist.is_initialized():
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29511")
-            if backend == "nccl":
-                try:
-                    dist.init_process_group("nccl", device_id=self.device)
-                    # the first collective creates the RCCL communicator: fail here, not inside the timed region
-                    probe = torch.zeros(1, device=self.device)
-                    dist.all_reduce(probe)
-                    torch.cuda.synchronize()
-                except Exception as e:  # noqa: BLE001 -- RCCL unusable on this node: the scalars can travel over gloo
-                    import sys
-                    print("process_group: RCCL unavailable (%s); falling back to gloo for barrier/max" % e,
-                          file=sys.stderr)
-                    if dist.is_initialized():
-                        dist.destroy_process_group()
-                    dist.init_process_group("gloo")
-                    self.backend = "gloo"
-                    self.device = torch.device("cpu")
-            else:
-                dist.init_process_group(backend)
+            dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=timeout_s))
+        if backend != "nccl":
+            self.backend = "gloo"
+            self.device = torch.device("cpu")
+            return
+        ok, reason, group = 1, "", None
+        try:
+            # collective: every rank calls new_group; the first all-reduce creates the RCCL communicator -- here, not
+            # inside the timed region
+            group = dist.new_group(backend="nccl", timeout=datetime.timedelta(seconds=timeout_s))
+            probe = torch.ones(1, device=self.device)
+            dist.all_reduce(probe, group=group)
+            torch.cuda.synchronize()
+            if int(probe.item()) != self.world:
+                ok, reason = 0, "probe all-reduce returned %r" % probe.item()
+        except Exception as e:  # noqa: BLE001 -- reported below, decided collectively
+            ok, reason = 0, "%s: %s" % (type(e).__name__, str(e).splitlines()[0] if str(e) else "")
+        flag = torch.tensor([ok], dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)  # over gloo: every rank sees the same verdict
+        if int(flag.item()) == 1:
+            self.group = group
+        else:
+            self.backend = "gloo"
+            self.device = torch.device("cpu")
+            self.fallback_reason = reason or "RCCL failed on another rank"
+            if self.rank == 0:
+                import sys
+                print("process_group: RCCL unusable on at least one rank (%s); every rank uses gloo for barrier/max"
+                      % self.fallback_reason, file=sys.stderr)
 
     def barrier(self):
         if self.torch.cuda.is_available():
             self.torch.cuda.synchronize()
         if self.active:
-            self.dist.barrier()
+            if self.group is not None:
+                # an all-reduce on the RCCL group is the barrier (dist.barrier on NCCL groups needs device_ids)
+                t = self.torch.zeros(1, device=self.device)
+                self.dist.all_reduce(t, group=self.group)
+            else:
+                self.dist.barrier()
         if self.torch.cuda.is_available():
             self.torch.cuda.synchronize()
 
@@ -71,7 +98,7 @@ class process_group:
         if not self.active:
             return float(value)
         t = self.torch.tensor([float(value)], dtype=self.torch.float64, device=self.device)
-        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX, group=self.group)
         return float(t.item())
 
     def gather(self, values):
@@ -80,7 +107,7 @@ class process_group:
         if not self.active:
             return [t.tolist()]
         out = [self.torch.empty_like(t) for _ in range(self.world)]
-        self.dist.all_gather(out, t)
+        self.dist.all_gather(out, t, group=self.group)
         return [o.tolist() for o in out]
 
     def close(self):

@@ -1,60 +1,102 @@
 #!/usr/bin/env python3
-"""Turn rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs (separate passes, csv output) into the per-launch HBM traffic
+"""Turn rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs (separate passes, csv output) into the per-execute HBM traffic
 figure used by bench.py's roofline.traffic.
 
-    tools/summarize_pmc.py gpurun_out/pmc profiles/r1_pmc_traffic.json
+    tools/summarize_pmc.py <src> <dst.json> --config c3 --kernels stockham_strided --alg-bytes 4294967296 \
+        [--cal-dir <dir> --cal-kernel 'copy_cols<128' --cal-kib 2097152]
 
-Units and corrections follow /opt/skills/guides/MI355X_MICROARCH.md (HBM section): both counters are in KiB;
-on gfx950 FETCH_SIZE reports exactly half of the bytes of a coalesced streaming read, WRITE_SIZE is exact.  The
-halving is re-checked here on a calibration kernel with a known byte count and the FFT kernel's own access shape
-(tools/probes/copy_sweep2.hip: 32 KiB rows, 8 B per lane): cal_* directories.
+<src>/FETCH_SIZE/runc/*_counter_collection.csv and <src>/WRITE_SIZE/runc/*_counter_collection.csv come from
+    rocprofv3 --pmc <counter> --kernel-trace --output-format csv -d <src>/<counter>/runc -- python3 bench.py ...
+(tools/run_pmc.sh).  Units and corrections follow /opt/skills/guides/MI355X_MICROARCH.md (HBM section): both counters
+are in KiB; on gfx950 FETCH_SIZE reports half of the bytes of a coalesced streaming read, WRITE_SIZE is exact.  The
+guide calibrates that for 16 B per lane only, so the factor is re-measured on a copy kernel with a known byte count and
+the access shape of the kernel in question (--cal-*: tools/probes/copy_sweep2.hip for 8 B per lane rows,
+tools/probes/copy_strided.hip for 128-byte column segments at 16 B per lane) and the measured factor is what is applied.
+An execute may consist of several launches (two-pass plans): the per-launch means of every matching kernel are summed.
 """
+import argparse
 import collections
 import csv
 import glob
 import json
-import sys
 
 
 def per_kernel(directory, counter):
-    files = glob.glob("%s/runc/*_counter_collection.csv" % directory)
     agg = collections.defaultdict(list)
-    for f in files:
-        for r in csv.DictReader(open(f)):
-            if r["Counter_Name"] == counter:
-                agg[r["Kernel_Name"]].append(float(r["Counter_Value"]))
+    for f in glob.glob("%s/**/*_counter_collection.csv" % directory, recursive=True):
+        with open(f) as fh:
+            for r in csv.DictReader(fh):
+                if r["Counter_Name"] == counter:
+                    agg[r["Kernel_Name"]].append(float(r["Counter_Value"]))
     return agg
 
 
-def main(src, dst):
-    out = {"source": "rocprofv3 --pmc <counter> --kernel-trace --output-format csv -- python3 bench.py --steps 5 "
-                     "--warmup 2 --no-cpu-baseline (one pass per counter)", "unit_of_counters": "KiB"}
-    cal_f = per_kernel(src + "/cal_FETCH_SIZE", "FETCH_SIZE")
-    cal_w = per_kernel(src + "/cal_WRITE_SIZE", "WRITE_SIZE")
-    known_kib = 2 * 1024 * 1024  # the calibration copy reads 2 GiB and writes 2 GiB per launch
-    kf = [v for k, vs in cal_f.items() if "rows_copy" in k for v in vs]
-    kw = [v for k, vs in cal_w.items() if "rows_copy" in k for v in vs]
-    fetch_corr = known_kib / (sum(kf) / len(kf))
-    write_corr = known_kib / (sum(kw) / len(kw))
-    out["calibration"] = {"known_KiB_per_launch": known_kib, "FETCH_SIZE_mean": sum(kf) / len(kf),
-                          "WRITE_SIZE_mean": sum(kw) / len(kw), "fetch_correction": round(fetch_corr, 4),
-                          "write_correction": round(write_corr, 4)}
-    f = [v for k, vs in per_kernel(src + "/FETCH_SIZE", "FETCH_SIZE").items() if "stockham_wg" in k for v in vs]
-    w = [v for k, vs in per_kernel(src + "/WRITE_SIZE", "WRITE_SIZE").items() if "stockham_wg" in k for v in vs]
-    fetch_b = sum(f) / len(f) * 1024 * 2.0  # guide's gfx950 correction (confirmed by the calibration above)
-    write_b = sum(w) / len(w) * 1024
-    out["kernel"] = "stockham_wg_prefetch_kernel<f32, 16x16x16, wg256> (bench.py workload: N=4096 batch=65536)"
-    out["launches_sampled"] = {"FETCH_SIZE": len(f), "WRITE_SIZE": len(w)}
-    out["FETCH_SIZE_mean_KiB"] = sum(f) / len(f)
-    out["WRITE_SIZE_mean_KiB"] = sum(w) / len(w)
-    out["hbm_read_bytes_per_launch"] = fetch_b
+def short(name):
+    return name if len(name) <= 160 else name[:157] + "..."
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("src")
+    ap.add_argument("dst")
+    ap.add_argument("--config", default="c2")
+    ap.add_argument("--kernels", default="stockham_", help="comma-separated substrings of the kernels of one execute")
+    ap.add_argument("--alg-bytes", type=float, required=True)
+    ap.add_argument("--label", default="")
+    ap.add_argument("--cal-dir", default=None, help="directory with cal FETCH_SIZE / WRITE_SIZE passes of a copy kernel")
+    ap.add_argument("--cal-kernel", default="rows_copy")
+    ap.add_argument("--cal-kib", type=float, default=2 * 1024 * 1024, help="KiB the calibration kernel reads (= writes)")
+    a = ap.parse_args()
+    subs = [s for s in a.kernels.split(",") if s]
+    out = {"config": a.config, "label": a.label,
+           "source": "rocprofv3 --pmc <counter> --kernel-trace --output-format csv -- python3 bench.py --config %s "
+                     "--steps 5 --warmup 2 --no-cpu-baseline (one pass per counter, tools/run_pmc.sh)" % a.config,
+           "unit_of_counters": "KiB"}
+    fetch_corr, write_corr = 2.0, 1.0
+    if a.cal_dir:
+        kf = [v for k, vs in per_kernel(a.cal_dir + "/FETCH_SIZE", "FETCH_SIZE").items() if a.cal_kernel in k for v in vs]
+        kw = [v for k, vs in per_kernel(a.cal_dir + "/WRITE_SIZE", "WRITE_SIZE").items() if a.cal_kernel in k for v in vs]
+        if kf and kw:
+            fetch_corr = a.cal_kib / (sum(kf) / len(kf))
+            write_corr = a.cal_kib / (sum(kw) / len(kw))
+            out["calibration"] = {"kernel": a.cal_kernel, "known_KiB_per_launch": a.cal_kib,
+                                  "FETCH_SIZE_mean": sum(kf) / len(kf), "WRITE_SIZE_mean": sum(kw) / len(kw),
+                                  "fetch_correction": round(fetch_corr, 4), "write_correction": round(write_corr, 4),
+                                  "launches": [len(kf), len(kw)]}
+    if "calibration" not in out:
+        out["calibration"] = {"note": "guide's gfx950 factors (FETCH_SIZE x2, WRITE_SIZE x1); "
+                                      "confirmed for 8 B per lane rows in profiles/r1_pmc_traffic.json"}
+    fetch = per_kernel(a.src + "/FETCH_SIZE", "FETCH_SIZE")
+    write = per_kernel(a.src + "/WRITE_SIZE", "WRITE_SIZE")
+    kernels = []
+    read_b = write_b = 0.0
+    for name in sorted(set(fetch) | set(write)):
+        if not any(s in name for s in subs):
+            continue
+        f, w = fetch.get(name, []), write.get(name, [])
+        if not f or not w:
+            continue
+        rb = sum(f) / len(f) * 1024 * fetch_corr
+        wb = sum(w) / len(w) * 1024 * write_corr
+        kernels.append({"kernel": short(name), "launches_sampled": [len(f), len(w)],
+                        "FETCH_SIZE_mean_KiB": sum(f) / len(f), "WRITE_SIZE_mean_KiB": sum(w) / len(w),
+                        "hbm_read_bytes_per_launch": rb, "hbm_write_bytes_per_launch": wb})
+        read_b += rb
+        write_b += wb
+    out["kernels"] = kernels
+    out["hbm_read_bytes_per_launch"] = read_b
     out["hbm_write_bytes_per_launch"] = write_b
-    out["traffic_bytes_per_launch"] = fetch_b + write_b
-    out["algorithmic_bytes_per_launch"] = 2.0 * 4096 * 65536 * 8
-    out["traffic_over_algorithmic"] = round((fetch_b + write_b) / out["algorithmic_bytes_per_launch"], 4)
-    json.dump(out, open(dst, "w"), indent=1)
-    print(json.dumps(out, indent=1))
+    out["traffic_bytes_per_launch"] = read_b + write_b
+    out["algorithmic_bytes_per_launch"] = a.alg_bytes
+    out["hbm_passes"] = len(kernels)
+    out["traffic_over_algorithmic"] = round((read_b + write_b) / a.alg_bytes, 4) if a.alg_bytes else None
+    with open(a.dst, "w") as fh:
+        json.dump(out, fh, indent=1)
+    print(json.dumps({k: v for k, v in out.items() if k != "kernels"}, indent=1))
+    for k in kernels:
+        print("  %-100s read %.4g B write %.4g B" % (k["kernel"][:100], k["hbm_read_bytes_per_launch"],
+                                                    k["hbm_write_bytes_per_launch"]))
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2])
+    main()
