@@ -40,6 +40,9 @@ struct spec_kernel {
   /// the remaining wg_cfg arguments, so that other forms of the same configuration (UNPACKED layouts) can be
   /// instantiated at run time
   int pads, padw, twm, occ, aux, staged, twl;
+  /// 1: cross-lane variant of the length (stockham_xlane.hpp); only chosen when PFFT_XLANE is set (measurement:
+  /// profiles/r2_notes.md)
+  int xlane;
 };
 
 /// One strided work-group kernel (stockham_strided.hpp): FPW FFTs side by side, any element stride / FFT distance.

@@ -17,7 +17,7 @@ const spec_kernel g_spec_f32[] = {
     make_spec_entry<wg_cfg_twl<f, radix_list<8, 4>, 256, 64, 8, 1, 4, NT, 1>>(),        // 32
     make_spec_entry<wg_cfg_twl<f, radix_list<8, 8>, 256, 32, 8, 1, 4, NT, 1>>(),        // 64
     make_spec_entry<wg_cfg_twl<f, radix_list<16, 8>, 256, 32, 16, 1, 4, NT, 1>>(),       // 128
-    make_spec_entry<wg_cfg_twl<f, radix_list<16, 16>, 256, 16, 16, 1, 4, NT>>(),         // 256
+    make_spec_entry<wg_cfg_twl<f, radix_list<16, 16>, 256, 16, 16, 1, 4, NT, 1>>(),      // 256 (LDS-staged I/O: 6.2 vs 5.6 TB/s -- direct I/O moves 128-byte pieces per FFT here)
     make_spec_entry<wg_cfg<f, radix_list<8, 8, 8>, 256, 4, 16, 1, TW_GLOBAL, 4, NT, 0, 2>>(2),  // 512 (TWL 2: 6.56 vs 6.40 with TW_REGS)
     make_spec_entry<wg_cfg<f, radix_list<16, 8, 8>, 256, 4, 16, 1, TW_GLOBAL, 4, NT, 0, 2>>(),  // 1024 (TWL 2: tools/tune.hip)
     make_spec_entry<wg_cfg<f, radix_list<16, 16, 8>, 256, 2, 16, 1, TW_GLOBAL, 4, NT, 0, 2>>(2),  // 2048 (TWL 2: 6.03 vs 5.93)
@@ -27,7 +27,7 @@ const spec_kernel g_spec_f32[] = {
     make_spec_entry<wg_cfg<f, radix_list<32, 16, 32>, 512, 1, 0, 0, TW_REGS, 2, NT>>(0),       // 16384
     // 3 * 2^k and 5 * 2^k families, powers of ten
     make_spec_entry<wg_cfg_twl<f, radix_list<12, 8>, 256, 32, 0, 0, 4, NT, 1>>(),       // 96
-    make_spec_entry<wg_cfg_twl<f, radix_list<16, 12>, 256, 16, 16, 1, 4, NT>>(),         // 192
+    make_spec_entry<wg_cfg_twl<f, radix_list<16, 12>, 256, 16, 16, 1, 4, NT, 1>>(),      // 192 (LDS-staged I/O: 5.96 vs 5.64)
     make_spec_entry<wg_cfg_twl<f, radix_list<8, 8, 6>, 256, 4, 16, 1, 4, NT>>(),         // 384
     make_spec_entry<wg_cfg_twl<f, radix_list<16, 8, 6>, 256, 4, 16, 1, 4, NT>>(),        // 768
     make_spec_entry<wg_cfg_twl<f, radix_list<16, 12, 8>, 256, 2, 16, 1, 4, NT>>(),       // 1536
@@ -44,6 +44,10 @@ const spec_kernel g_spec_f32[] = {
     make_spec_entry<wg_cfg_twl<f, radix_list<20, 16, 16>, 256, 1, 16, 1, 2, NT>>(),      // 5120
     make_spec_entry<wg_cfg_twl<f, radix_list<10, 10, 10>, 200, 2, 0, 0, 4, NT>>(),      // 1000
     make_spec_entry<wg_cfg_twl<f, radix_list<10, 10, 10, 10>, 512, 1, 0, 0, 3, NT>>(),  // 10000
+    // cross-lane (in-wave DPP / ds_swizzle transpose) variants of N = R * R: measurement only, chosen with PFFT_XLANE=1
+    make_spec_entry_xlane<wg_cfg<f, radix_list<4, 4>, 256, 64, 4, 1, TW_GLOBAL, 4, NT, 1>>(),     // 16
+    make_spec_entry_xlane<wg_cfg<f, radix_list<8, 8>, 256, 32, 8, 1, TW_GLOBAL, 4, NT, 1>>(),     // 64
+    make_spec_entry_xlane<wg_cfg<f, radix_list<16, 16>, 256, 16, 16, 1, TW_GLOBAL, 4, NT, 1>>(),  // 256
 };
 }  // namespace
 

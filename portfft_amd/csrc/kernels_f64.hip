@@ -30,6 +30,9 @@ const spec_kernel g_spec_f64[] = {
     make_spec_entry<wg_cfg_twl<d, radix_list<10, 8>, 256, 32, 0, 0, 2, NT, 1>>(),       // 80
     make_spec_entry<wg_cfg_twl<d, radix_list<10, 10>, 250, 25, 0, 0, 2, NT, 1>>(),      // 100
     make_spec_entry<wg_cfg_twl<d, radix_list<10, 10, 10>, 200, 2, 0, 0, 2, NT>>(),      // 1000
+    // cross-lane variants (see kernels_f32.hip), chosen with PFFT_XLANE=1
+    make_spec_entry_xlane<wg_cfg<d, radix_list<8, 8>, 256, 32, 8, 1, TW_GLOBAL, 2, NT, 1>>(),     // 64
+    make_spec_entry_xlane<wg_cfg<d, radix_list<16, 16>, 256, 16, 16, 1, TW_GLOBAL, 2, NT, 1>>(),  // 256
 };
 }  // namespace
 

@@ -6,6 +6,7 @@
 #include "stockham_rows2d.hpp"
 #include "stockham_strided.hpp"
 #include "stockham_wg.hpp"
+#include "stockham_xlane.hpp"
 
 namespace pfa {
 
@@ -100,6 +101,35 @@ spec_kernel make_spec_entry(int groups_per_wg) {
   k.fn_split[0] = reinterpret_cast<const void*>(&stockham_wg_split_kernel<Cfg, false>);
   k.fn_split[1] = reinterpret_cast<const void*>(&stockham_wg_split_kernel<Cfg, true>);
   k.launch_split = &launch_spec_split<Cfg>;
+  return k;
+}
+
+template <typename Cfg>
+hipError_t launch_spec_xlane(hipStream_t stream, unsigned grid, const void* in, void* out, const void* tw,
+                             long long nfft, double scale, int backward) {
+  using T = typename Cfg::T;
+  const auto* i = static_cast<const cx<T>*>(in);
+  auto* o = static_cast<cx<T>*>(out);
+  const auto* t = static_cast<const cx<T>*>(tw);
+  if (backward) {
+    hipLaunchKernelGGL((stockham_wg_xlane_kernel<Cfg, true>), dim3(grid), dim3(Cfg::WG), Cfg::LDS_BYTES, stream, i, o,
+                       t, nfft, static_cast<T>(scale));
+  } else {
+    hipLaunchKernelGGL((stockham_wg_xlane_kernel<Cfg, false>), dim3(grid), dim3(Cfg::WG), Cfg::LDS_BYTES, stream, i, o,
+                       t, nfft, static_cast<T>(scale));
+  }
+  return hipGetLastError();
+}
+
+/// cross-lane form (stockham_xlane.hpp) of an N = R * R staged variant; interleaved storage (split storage keeps
+/// the LDS form of the same configuration)
+template <typename Cfg>
+spec_kernel make_spec_entry_xlane(int groups_per_wg = 1) {
+  spec_kernel k = make_spec_entry<Cfg>(groups_per_wg);
+  k.fn[0] = reinterpret_cast<const void*>(&stockham_wg_xlane_kernel<Cfg, false>);
+  k.fn[1] = reinterpret_cast<const void*>(&stockham_wg_xlane_kernel<Cfg, true>);
+  k.launch = &launch_spec_xlane<Cfg>;
+  k.xlane = 1;
   return k;
 }
 

@@ -280,10 +280,18 @@ struct plan_t {
     int count = 0;
     const spec_kernel* k =
         desc.precision == PFFT_PRECISION_F64 ? spec_kernels_f64(&count) : spec_kernels_f32(&count);
+    // PFFT_XLANE: prefer the cross-lane variant of a length (measurement / parity of stockham_xlane.hpp)
+    const bool want_xlane = getenv("PFFT_XLANE") != nullptr && desc.complex_storage == PFFT_INTERLEAVED_COMPLEX;
+    const spec_kernel* found = nullptr;
     for (int i = 0; i < count; ++i) {
-      if (k[i].n == n && k[i].lds_bytes <= max_lds) return &k[i];
+      if (k[i].n != n || k[i].lds_bytes > max_lds) continue;
+      if (k[i].xlane != 0) {
+        if (want_xlane) return &k[i];
+        continue;
+      }
+      if (found == nullptr) found = &k[i];
     }
-    return nullptr;
+    return found;
   }
 
   /// column_both: the stage is column-shaped on both sides -> the wide-group entry of the length, when there is one

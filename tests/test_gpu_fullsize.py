@@ -156,3 +156,28 @@ def test_buffers_beyond_4gib():
     _big_case(1200, 1000000)                                      # runtime-specialised length
     _big_case(1 << 20, 1200)                                      # GLOBAL tier fp32, chunked scratch
     _big_case(65536, 10000, prec="f64")                           # GLOBAL tier fp64
+
+
+@pytest.mark.parametrize("prec", ["f32", "f64"])
+def test_cross_lane_variants(prec):
+    """The cross-lane sub-group kernels (stockham_xlane.hpp: in-wave DPP / ds_swizzle transpose instead of the LDS
+    exchange; reference role: common/subgroup.hpp:141-216) against NumPy and against the LDS-staged kernels they
+    stand next to, both directions, ragged batch counts, scale."""
+    G, pf, torch = _mods()
+    dtype = np.complex64 if prec == "f32" else np.complex128
+    tol = H.REL_L2_TOL[np.dtype(dtype)]
+    for n in ((16, 64, 256) if prec == "f32" else (64, 256)):
+        for batch in (1, 33, 1000):
+            x, y = H.gen_fourier_data(batch, [n], dtype, seed=n + batch)
+            base, _ = G.transform_packed(G.make_descriptor([n], prec, batch=batch, fwd_scale=0.5), pf.direction.FORWARD, x)
+            os.environ["PFFT_XLANE"] = "1"
+            try:
+                d = G.make_descriptor([n], prec, batch=batch, fwd_scale=0.5)
+                got, _ = G.transform_packed(d, pf.direction.FORWARD, x)
+                back, _ = G.transform_packed(d, pf.direction.BACKWARD, y)
+            finally:
+                del os.environ["PFFT_XLANE"]
+            for b in range(batch):
+                assert H.rel_l2(got[b], 0.5 * y[b]) <= tol, ("xlane fwd", prec, n, batch, b)
+                assert H.rel_l2(back[b], n * x[b].astype(np.complex128)) <= tol, ("xlane bwd", prec, n, batch, b)
+            assert H.rel_l2(got, base) <= 2 * tol, ("xlane vs staged", prec, n, batch)

@@ -7,7 +7,7 @@
 #include <functional>
 #include <string>
 #include <vector>
-#include "../portfft_amd/csrc/stockham_wg.hpp"
+#include "../portfft_amd/csrc/stockham_xlane.hpp"
 using namespace pfa;
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s line %d\n", hipGetErrorString(e_), __LINE__); exit(1);} } while (0)
 
@@ -27,6 +27,20 @@ std::vector<cx<T>> make_twiddles() {
 struct variant { std::string name; int fpw; int wg; size_t lds; const void* fn; std::function<void(unsigned, long long)> launch; };
 static std::vector<variant> g_variants;
 static void *g_in, *g_out;
+
+template <typename Cfg>
+void add_xlane(const char* name) {
+  using T = typename Cfg::T;
+  auto tw = make_twiddles<typename Cfg::Seq, T>();
+  cx<T>* d_tw;
+  CK(hipMalloc(&d_tw, tw.size() * sizeof(cx<T>)));
+  CK(hipMemcpy(d_tw, tw.data(), tw.size() * sizeof(cx<T>), hipMemcpyHostToDevice));
+  const void* fn = (const void*)&stockham_wg_xlane_kernel<Cfg, false>;
+  CK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS_BYTES));
+  g_variants.push_back({name, Cfg::FPW, Cfg::WG, Cfg::LDS_BYTES, fn, [d_tw](unsigned grid, long long nfft) {
+    hipLaunchKernelGGL((stockham_wg_xlane_kernel<Cfg, false>), dim3(grid), dim3(Cfg::WG), Cfg::LDS_BYTES, 0, (const cx<T>*)g_in, (cx<T>*)g_out, d_tw, nfft, (T)1);
+  }});
+}
 
 template <typename Cfg, bool PF>
 void add(const char* name) {
@@ -119,6 +133,37 @@ int main() {
   add<wg_cfg<d, radix_list<32, 16, 16>, 256, 1, 16, 1, TW_GLOBAL, 1, NT>, false>("f64 8192 r32.16.16 twG wg256 o1");
   add<wg_cfg<d, radix_list<32, 16, 16>, 256, 1, 0, 0, TW_GLOBAL, 1, NT>, false>("f64 8192 r32.16.16 twG wg256 nopad");
   add<wg_cfg<d, radix_list<16, 8, 8, 8>, 512, 1, 16, 1, TW_GLOBAL, 2, NT>, false>("f64 8192 r16.8.8.8 twG wg512");
+#elif TUNE_CASE == 64
+  using S = radix_list<8, 8>; using T = f; const int N = 64;
+  add<wg_cfg_twl<f, S, 256, 32, 8, 1, 4, NT, 1>, false>("64 STAGED (production)");
+  add_xlane<wg_cfg<f, S, 256, 32, 8, 1, TW_GLOBAL, 4, NT, 1>>("64 cross-lane wg256");
+  add_xlane<wg_cfg<f, S, 256, 32, 0, 0, TW_GLOBAL, 4, NT, 1>>("64 cross-lane wg256 nopad");
+  add_xlane<wg_cfg<f, S, 512, 64, 8, 1, TW_GLOBAL, 4, NT, 1>>("64 cross-lane wg512");
+#elif TUNE_CASE == 257
+  using S = radix_list<16, 16>; using T = f; const int N = 256;
+  add<wg_cfg_twl<f, S, 256, 16, 16, 1, 4, NT>, false>("256 direct I/O (production)");
+  add<wg_cfg_twl<f, S, 256, 16, 16, 1, 4, NT, 1>, false>("256 STAGED");
+  add_xlane<wg_cfg<f, S, 256, 16, 16, 1, TW_GLOBAL, 4, NT, 1>>("256 cross-lane wg256");
+  add_xlane<wg_cfg<f, S, 256, 16, 0, 0, TW_GLOBAL, 4, NT, 1>>("256 cross-lane wg256 nopad");
+  add_xlane<wg_cfg<f, S, 256, 16, 16, 1, TW_GLOBAL, 2, NT, 1>>("256 cross-lane wg256 occ2");
+#elif TUNE_CASE == 5121
+  using S = radix_list<8, 8, 8>; using T = f; const int N = 512;
+  add<wg_cfg<f, S, 256, 4, 16, 1, TW_GLOBAL, 4, NT, 0, 2>, false>("512 direct TWL2 (production)");
+  add<wg_cfg<f, S, 256, 4, 16, 1, TW_GLOBAL, 4, NT, 1, 2>, false>("512 STAGED TWL2");
+  add<wg_cfg<f, S, 256, 8, 16, 1, TW_GLOBAL, 4, NT, 1, 2>, false>("512 STAGED TWL2 fpw8 (32 lanes per FFT)");
+#elif TUNE_CASE == 10241
+  using S = radix_list<16, 8, 8>; using T = f; const int N = 1024;
+  add<wg_cfg<f, S, 256, 4, 16, 1, TW_GLOBAL, 4, NT, 0, 2>, false>("1024 direct TWL2 (production)");
+  add<wg_cfg<f, S, 256, 4, 16, 1, TW_GLOBAL, 4, NT, 1, 2>, false>("1024 STAGED TWL2");
+#elif TUNE_CASE == 25664
+  using S = radix_list<16, 16>; using T = d; const int N = 256;
+  add<wg_cfg_twl<d, S, 256, 16, 16, 1, 2, NT>, false>("f64 256 direct (production)");
+  add<wg_cfg_twl<d, S, 256, 16, 16, 1, 2, NT, 1>, false>("f64 256 STAGED");
+  add<wg_cfg_twl<d, S, 128, 8, 16, 1, 2, NT, 1>, false>("f64 256 STAGED wg128 fpw8");
+#elif TUNE_CASE == 192
+  using S = radix_list<16, 12>; using T = f; const int N = 192;
+  add<wg_cfg_twl<f, S, 256, 16, 16, 1, 4, NT>, false>("192 direct (production)");
+  add<wg_cfg_twl<f, S, 256, 16, 16, 1, 4, NT, 1>, false>("192 STAGED");
 #elif TUNE_CASE == 256
   using S = radix_list<16, 16>; using T = f; const int N = 256;
   add<wg_cfg<f, S, 256, 16, 16, 1, TW_GLOBAL, 4, NT>, false>("256 twG fpw16 o4");
