@@ -51,10 +51,10 @@ __global__ __launch_bounds__(GENERIC_WG) void generic_fft_kernel(const generic_a
   const unsigned tid = threadIdx.x;
   const unsigned n = p.n;
   const unsigned fpw = p.fpw;
-  const T* __restrict__ in_re = static_cast<const T*>(p.in_re);
-  const T* __restrict__ in_im = static_cast<const T*>(p.in_im);
-  T* __restrict__ out_re = static_cast<T*>(p.out_re);
-  T* __restrict__ out_im = static_cast<T*>(p.out_im);
+  const T* in_re = static_cast<const T*>(p.in_re);
+  const T* in_im = static_cast<const T*>(p.in_im);
+  T* out_re = static_cast<T*>(p.out_re);
+  T* out_im = static_cast<T*>(p.out_im);
   const cx<T>* __restrict__ tw = static_cast<const cx<T>*>(p.tw);
   const long long ngroups = (p.total_count + fpw - 1) / fpw;
   const T scale = static_cast<T>(p.scale);

@@ -139,8 +139,8 @@ PFA_DEV void stockham_nd_body(MakeIO&& make_io, const cx<typename Cfg::T>* __res
 
 /// interleaved complex; same launch signature as stockham_wg_kernel
 template <typename Cfg, bool BWD>
-__global__ __launch_bounds__(Cfg::WG, Cfg::OCC) void stockham_nd_kernel(const cx<typename Cfg::T>* __restrict__ in,
-                                                                        cx<typename Cfg::T>* __restrict__ out,
+__global__ __launch_bounds__(Cfg::WG, Cfg::OCC) void stockham_nd_kernel(const cx<typename Cfg::T>* in,
+                                                                        cx<typename Cfg::T>* out,
                                                                         const cx<typename Cfg::T>* __restrict__ tw,
                                                                         long long nfft, typename Cfg::T scale) {
   using T = typename Cfg::T;
@@ -152,8 +152,8 @@ __global__ __launch_bounds__(Cfg::WG, Cfg::OCC) void stockham_nd_kernel(const cx
 /// SPLIT_COMPLEX storage; same launch signature as stockham_wg_split_kernel
 template <typename Cfg, bool BWD>
 __global__ __launch_bounds__(Cfg::WG, Cfg::OCC) void stockham_nd_split_kernel(
-    const typename Cfg::T* __restrict__ in_re, const typename Cfg::T* __restrict__ in_im,
-    typename Cfg::T* __restrict__ out_re, typename Cfg::T* __restrict__ out_im,
+    const typename Cfg::T* in_re, const typename Cfg::T* in_im,
+    typename Cfg::T* out_re, typename Cfg::T* out_im,
     const cx<typename Cfg::T>* __restrict__ tw, long long nfft, typename Cfg::T scale) {
   using T = typename Cfg::T;
   stockham_nd_body<Cfg, BWD>(

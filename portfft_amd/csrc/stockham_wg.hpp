@@ -469,7 +469,7 @@ PFA_DEV void wg_pass0_compute(cx<typename Cfg::T> (&v)[Cfg::bpt(0)][Cfg::Seq::r[
 /// between a load phase and a compute phase.  Costs one extra register image of the inputs.
 template <typename Cfg, bool BWD>
 __global__ __launch_bounds__(Cfg::WG, Cfg::OCC) void stockham_wg_prefetch_kernel(
-    const cx<typename Cfg::T>* __restrict__ in, cx<typename Cfg::T>* __restrict__ out,
+    const cx<typename Cfg::T>* in, cx<typename Cfg::T>* out,
     const cx<typename Cfg::T>* __restrict__ tw, long long nfft, typename Cfg::T scale) {
   using T = typename Cfg::T;
   using Seq = typename Cfg::Seq;
@@ -609,9 +609,11 @@ PFA_DEV void stockham_wg_body(MakeIO&& make_io, const cx<typename Cfg::T>* __res
 }
 
 /// Persistent work-group kernel, interleaved complex: work-group g handles FFT groups g, g+G, ...
+/// `in` and `out` may be the same buffer (the in-place overloads, N-D passes on the output): the data pointers of the
+/// kernels in this file are deliberately NOT __restrict__; only the twiddle tables are.
 template <typename Cfg, bool BWD>
-__global__ __launch_bounds__(Cfg::WG, Cfg::OCC) void stockham_wg_kernel(const cx<typename Cfg::T>* __restrict__ in,
-                                                                        cx<typename Cfg::T>* __restrict__ out,
+__global__ __launch_bounds__(Cfg::WG, Cfg::OCC) void stockham_wg_kernel(const cx<typename Cfg::T>* in,
+                                                                        cx<typename Cfg::T>* out,
                                                                         const cx<typename Cfg::T>* __restrict__ tw,
                                                                         long long nfft, typename Cfg::T scale) {
   using T = typename Cfg::T;
@@ -623,8 +625,8 @@ __global__ __launch_bounds__(Cfg::WG, Cfg::OCC) void stockham_wg_kernel(const cx
 /// Same kernel for SPLIT_COMPLEX storage (separate real / imaginary planes).
 template <typename Cfg, bool BWD>
 __global__ __launch_bounds__(Cfg::WG, Cfg::OCC) void stockham_wg_split_kernel(
-    const typename Cfg::T* __restrict__ in_re, const typename Cfg::T* __restrict__ in_im,
-    typename Cfg::T* __restrict__ out_re, typename Cfg::T* __restrict__ out_im,
+    const typename Cfg::T* in_re, const typename Cfg::T* in_im,
+    typename Cfg::T* out_re, typename Cfg::T* out_im,
     const cx<typename Cfg::T>* __restrict__ tw, long long nfft, typename Cfg::T scale) {
   using T = typename Cfg::T;
   stockham_wg_body<Cfg, BWD>(
@@ -637,7 +639,7 @@ __global__ __launch_bounds__(Cfg::WG, Cfg::OCC) void stockham_wg_split_kernel(
 /// UNPACKED layouts, interleaved or split storage (strides and distances in elements; in_im / out_im only for SPLIT)
 template <typename Cfg, bool BWD, bool SPLIT>
 __global__ __launch_bounds__(Cfg::WG, Cfg::OCC) void stockham_wg_unpacked_kernel(
-    const void* __restrict__ in, const void* __restrict__ in_im, void* __restrict__ out, void* __restrict__ out_im,
+    const void* in, const void* in_im, void* out, void* out_im,
     const cx<typename Cfg::T>* __restrict__ tw, long long nfft, typename Cfg::T scale, unsigned in_stride,
     unsigned in_dist, unsigned out_stride, unsigned out_dist) {
   using T = typename Cfg::T;

@@ -76,7 +76,7 @@ constexpr bool xlane_supported() {
 
 template <typename Cfg, bool BWD>
 __global__ __launch_bounds__(Cfg::WG, Cfg::OCC) void stockham_wg_xlane_kernel(
-    const cx<typename Cfg::T>* __restrict__ in, cx<typename Cfg::T>* __restrict__ out,
+    const cx<typename Cfg::T>* in, cx<typename Cfg::T>* out,
     const cx<typename Cfg::T>* __restrict__ tw, long long nfft, typename Cfg::T scale) {
   using T = typename Cfg::T;
   using Seq = typename Cfg::Seq;

@@ -114,6 +114,11 @@ int main(int argc, char** argv) {
       }
     }
   }
+  {
+    long long compiled = 0, from_disk = 0;
+    pfa::jit_stats(&compiled, &from_disk);
+    std::printf("jit stats: compiled %lld from_disk %lld\n", compiled, from_disk);
+  }
   if (fails == 0) std::printf("jit planner OK\n");
   return fails == 0 ? 0 : 1;
 }
