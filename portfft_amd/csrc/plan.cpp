@@ -918,12 +918,38 @@ struct plan_t {
       const long long nb0 = n2 / sb.strided->radices[0];
       if ((1 << sh) == t && n2 % t == 0 && nb0 % t == 0 &&
           static_cast<unsigned long long>(n) * elem_bytes() < 0xFFFFFFF0ull) {
-        out.back().sa.out_gdist = n1 * t;  // stage A (already pushed)
-        out.back().sa.out_stride = static_cast<unsigned>(t);
-        out.back().sa.out_fdist = 1;
-        sb.sa.in_tile_shift = sh;
-        sb.sa.in_stride = static_cast<unsigned>(n1 * t);
-        sb.sa.in_fdist = static_cast<unsigned>(t);
+        // PFFT_GLOBAL_LAYOUT=b (experiment): intermediate contiguous per stage-B work-group instead of per stage-A
+        // work-group.  Measured on C3: 1.675-1.702 ms against 1.660-1.668 (profiles/r2_notes.md) -- stage A's tile
+        // writes at a stride lose more than stage B's contiguous reads gain, so "a" stays the default.
+        const char* lay = getenv("PFFT_GLOBAL_LAYOUT");
+        const int tb = sb.strided->fpw;
+        int shb = 0;
+        while ((1 << shb) < tb) ++shb;
+        const long long ngroups_a = n2 / t;
+        if (lay != nullptr && lay[0] == 'b' && (1 << shb) == tb && n1 % tb == 0 &&
+            (n1 / sa.strided->radices[sa.strided->n_radices - 1]) % tb == 0) {
+          // Intermediate laid out per stage-B work-group: block K = k1 / tb holds, for every stage-A group g, the tile
+          // [k1 % tb][n2 % t] -- stage B reads its n2 / t tiles as ONE contiguous block (contiguous in / strided out
+          // is the fastest shape of these kernels: 5.8 TB/s on C3), stage A writes whole tiles of tb * t elements at
+          // a stride of n2 / t tiles.
+          const long long tile = static_cast<long long>(tb) * t;
+          out.back().sa.out_gdist = tile;                                         // group g starts at tile g of block 0
+          out.back().sa.out_tile_shift = shb;                                     // k1 -> (k1 / tb, k1 % tb)
+          out.back().sa.out_stride = static_cast<unsigned>(ngroups_a * tile);     // next block K
+          out.back().sa.out_tile_mul = static_cast<unsigned>(t);                  // k1 % tb
+          out.back().sa.out_fdist = 1;                                            // n2 % t
+          sb.sa.in_gdist = ngroups_a * tile;                                      // work-group K reads block K
+          sb.sa.in_tile_shift = sh;                                               // n2 -> (n2 / t, n2 % t)
+          sb.sa.in_stride = static_cast<unsigned>(tile);
+          sb.sa.in_fdist = static_cast<unsigned>(t);
+        } else {
+          out.back().sa.out_gdist = n1 * t;  // stage A (already pushed)
+          out.back().sa.out_stride = static_cast<unsigned>(t);
+          out.back().sa.out_fdist = 1;
+          sb.sa.in_tile_shift = sh;
+          sb.sa.in_stride = static_cast<unsigned>(n1 * t);
+          sb.sa.in_fdist = static_cast<unsigned>(t);
+        }
         // square tiles: stage B takes its lanes element-fastest inside a tile (strided_pass TIN)
         if (sb.strided->launch_tin != nullptr && sb.strided->fpw == t && getenv("PFFT_NO_TILED_LANES") == nullptr) {
           sb.tiled_in = 1;

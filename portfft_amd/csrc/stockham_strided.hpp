@@ -63,8 +63,10 @@ PFA_DEV void strided_store_butterfly(const IO& io, const strided_args& a, unsign
   using T = typename Cfg::T;
   constexpr unsigned ES_OUT = IO::ES_OUT;
   const unsigned osh = static_cast<unsigned>(a.out_tile_shift);
+  const unsigned omul = a.out_tile_mul != 0 ? a.out_tile_mul : 1u;
   const unsigned voff =
-      live ? (f * a.out_fdist + (base >> osh) * a.out_stride + (base & ((1u << osh) - 1u))) * ES_OUT : 0xFFFFFFF0u;
+      live ? (f * a.out_fdist + (base >> osh) * a.out_stride + (base & ((1u << osh) - 1u)) * omul) * ES_OUT
+           : 0xFFFFFFF0u;
   const T scale = static_cast<T>(a.scale);
   // store modifier W_M^{k*c}, k = base + u*Ns: W^{base*c}, the step W^{Ns*c} and every fourth power of the step
   // come from the hi/lo tables, the other powers are one multiply away from those
@@ -309,15 +311,17 @@ PFA_DEV strided_io<typename Cfg::T, Cfg::AUX, SPLIT> strided_group(const strided
   *live = static_cast<long long>(f) < nlive;
   *c0_out = c0;
   if (nlive_out != nullptr) *nlive_out = nlive;
-  const long long ioff = a.in_gdist != 0 ? g * a.in_gdist : o * a.in_dist_outer + c0 * a.in_fdist;
-  const long long ooff = a.out_gdist != 0 ? g * a.out_gdist : o * a.out_dist_outer + c0 * a.out_fdist;
+  // group-major sides: group number (g - o * per_outer) of outer index o starts at that multiple of gdist
+  const long long gw = g - o * per_outer;
+  const long long ioff = o * a.in_dist_outer + (a.in_gdist != 0 ? gw * a.in_gdist : c0 * a.in_fdist);
+  const long long ooff = o * a.out_dist_outer + (a.out_gdist != 0 ? gw * a.out_gdist : c0 * a.out_fdist);
   // ranges: last element of the last FFT of the group (the planner guarantees < 4 GiB)
   const unsigned in_bytes = (static_cast<unsigned>(Cfg::FPW - 1) * a.in_fdist +
                              (static_cast<unsigned>(Cfg::N - 1) >> a.in_tile_shift) * a.in_stride +
                              (1u << a.in_tile_shift)) * ES_IN;
   const unsigned out_bytes = (static_cast<unsigned>(Cfg::FPW - 1) * a.out_fdist +
                               (static_cast<unsigned>(Cfg::N - 1) >> a.out_tile_shift) * a.out_stride +
-                              (1u << a.out_tile_shift)) * ES_OUT;
+                              (1u << a.out_tile_shift) * (a.out_tile_mul != 0 ? a.out_tile_mul : 1u)) * ES_OUT;
   IO io;
   char* ip = const_cast<char*>(static_cast<const char*>(a.in)) + ioff * ES_IN;
   char* op = static_cast<char*>(a.out) + ooff * ES_OUT;

@@ -28,6 +28,11 @@ struct strided_args {
   /// (i >> shift) * stride + (i & (2^shift - 1)); shift 0 = plain element stride.  Requires the first-pass (input)
   /// / last-pass (output) butterfly stride of the kernel to be a multiple of the tile.
   int in_tile_shift, out_tile_shift;
+  /// stride of the index inside an output tile (0 or 1: consecutive): element i at
+  /// (i >> shift) * out_stride + (i & (2^shift - 1)) * out_tile_mul + f * out_fdist.  With out_tile_mul = FPW and
+  /// out_fdist = 1 a stage writes [element % tile][f] tiles -- the four-step stage A filling an intermediate that is
+  /// laid out per stage-B work-group.
+  unsigned out_tile_mul;
 };
 
 /// Launch-time arguments of the first pass of the two-pass 2-D plan (stockham_rows2d.hpp): `nmat` matrices of
