@@ -835,6 +835,10 @@ struct plan_t {
         break;
       }
     }
+    if (const char* e = getenv("PFFT_GLOBAL_N1")) {  // experiments: force the first factor of the split
+      const long long c = std::atoll(e);
+      if (c >= 2 && n % c == 0 && strided_fpw(c, n / c) > 0 && strided_fpw(n / c, c) > 0) n1 = c;
+    }
     // ... otherwise the most balanced split whose two lengths both run on the generic tier
     for (long long c = static_cast<long long>(std::sqrt(static_cast<double>(n))); n1 == 0 && c >= 2; --c) {
       if (n % c == 0 && n / c <= gmax && !choose_radices(c).empty() && !choose_radices(n / c).empty()) {

@@ -1,5 +1,7 @@
 """Random descriptors against NumPy: rank, lengths (31-smooth), batch, layout (packed / batch-interleaved / unpacked rows /
-strided), storage, placement, offsets, scales, precision, direction.  usage: fuzz.py [seed] [iterations]"""
+strided), storage, placement, offsets, scales, precision, direction.  usage: fuzz.py [seed] [iterations] [big2d]
+With `big2d` the shapes are 2-D / 3-D with a long last dimension (256...2048): the two-pass 2-D plan
+(stockham_rows2d.hpp) and its fall-backs."""
 import os, sys, random
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
@@ -22,20 +24,26 @@ def smooth(rng, lo, hi):
 def main():
     seed = int(sys.argv[1]) if len(sys.argv) > 1 else 0
     iters = int(sys.argv[2]) if len(sys.argv) > 2 else 200
+    big2d = len(sys.argv) > 3 and sys.argv[3] == "big2d"
     rng = random.Random(seed)
     fails = 0
     for it in range(iters):
         prec = rng.choice(["f32", "f32", "f64"])
         dtype = np.complex64 if prec == "f32" else np.complex128
         rank = rng.choice([1, 1, 1, 2, 2, 3])
-        if rank == 1:
+        if big2d:
+            rank = rng.choice([2, 2, 3])
+            last = rng.choice([256, 512, 1024, 2048, 1000, 768])
+            mid = rng.choice([8, 16, 24, 40, 64, 96, 128, 250, 256, 512, 1024])
+            dims = ([rng.choice([2, 3, 5, 8])] if rank == 3 else []) + [mid, last]
+        elif rank == 1:
             dims = [smooth(rng, rng.choice([2, 20, 300, 3000]), rng.choice([64, 2000, 20000, 200000]))]
         else:
             dims = [smooth(rng, 2, rng.choice([12, 40, 200])) for _ in range(rank)]
         n = int(np.prod(dims))
         batch = rng.choice([1, 2, 3, 7, 16, 33, 100])
         if n * batch > 4_000_000:
-            batch = max(1, 4_000_000 // n)
+            batch = max(1, (8_000_000 if big2d else 4_000_000) // n)
         storage = rng.choice([0, 0, 1])
         kw = {}
         place = rng.choice([0, 1])
