@@ -40,6 +40,17 @@ bool choose_spec_params(int precision, long long n, size_t max_lds, wg_params* o
 bool choose_strided_params(int precision, long long n, long long inner_count, size_t max_lds, wg_params* out,
                            bool column_both = false);
 
+/// Planner of the first pass of the two-pass 2-D plan (stockham_rows2d.hpp) for rows of length n1 in a matrix of n0
+/// rows: the column radix RC taken in that pass (= rows per work-group = wg_params::fpw; n0 % RC == 0), the row
+/// radices (the last one is fused with the column radix into one 2-D butterfly: (n1 / r_last) % wg == 0) and the
+/// lanes.  False when n1 has a prime factor above 31 or nothing fits the register / LDS budget.
+bool choose_rows2d_params(int precision, long long n1, long long n0, size_t max_lds, wg_params* out);
+
+/// Runtime-compiled stockham_rows2d_kernel for row length n1 (cached per device, precision, n1 and column radix)
+const rows2d_kernel* jit_rows2d_kernel(int precision, long long n1, long long n0, size_t max_lds, std::string* why);
+hipError_t jit_launch_rows2d(const rows2d_kernel* k, hipStream_t stream, unsigned grid, const rows2d_args& args,
+                             int backward);
+
 /// LDS bytes of a packed work-group kernel with these parameters (wg_cfg::LDS_BYTES)
 size_t spec_lds_bytes(const wg_params& p);
 
@@ -113,7 +124,8 @@ hipError_t jit_launch_strided_mixed(const strided_kernel* k, hipStream_t stream,
                                     const strided_args& args, int backward, int split_mode);
 
 /// Compile (do not load) the forward + backward kernels of `p` for `arch`: needs no device, used by the build check
-/// and the CPU tests.  kind 0: packed interleaved, 1: packed split, 2: strided, 3: strided with store modifier.
+/// and the CPU tests.  kind 0: packed interleaved, 1: packed split, 2: strided, 3: strided with store modifier,
+/// 4: first pass of the two-pass 2-D plan (p from choose_rows2d_params).
 bool jit_compile_only(const wg_params& p, int kind, const char* arch, size_t* code_bytes, std::string* why);
 bool jit_compile_only_nd(const nd_kernel& p, bool split, const char* arch, size_t* code_bytes, std::string* why);
 

@@ -95,6 +95,8 @@ struct rows2d_kernel {
   int groups_per_wg;
   const void* fn[2];  // [backward]
   hipError_t (*launch)(hipStream_t stream, unsigned grid, const rows2d_args& args, int backward);
+  /// runtime-compiled entries (jit.cpp): module functions [backward]; fn / launch are null
+  hipFunction_t mfn[2];
 };
 const rows2d_kernel* rows2d_kernels(int* count);
 

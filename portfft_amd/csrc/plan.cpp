@@ -381,7 +381,7 @@ struct plan_t {
     return range_ok(ia) && range_ok(oa);
   }
 
-  const rows2d_kernel* find_rows2d(long long n1, long long n0) const {
+  const rows2d_kernel* find_rows2d(long long n1, long long n0) {
     const char* e = getenv("PFFT_2D_TWO_PASS");
     if (e != nullptr && e[0] == '0') return nullptr;  // experiments / parity A-B: rows, then full-length columns
     int count = 0;
@@ -392,7 +392,16 @@ struct plan_t {
         return &k[i];
       }
     }
-    return nullptr;
+    // other row lengths / column counts: the same template instantiated at commit (jit.cpp) -- when the full-length
+    // column pass it replaces would move segments below 256 bytes (measured, tools/perf_2d.py: 1080 x 1920 +27 %,
+    // 1536^2 +29 %, 3000 x 1000 2.6x, 4096^2 2.1x; with 256-byte column segments available, 384^2 ... 960^2, the
+    // runtime-planned first pass does not beat rows + columns)
+    const int col_fpw = strided_fpw(n0, n1);
+    if (col_fpw > 0 && static_cast<size_t>(col_fpw) * elem_bytes() >= 256) return nullptr;
+    std::string why;
+    const rows2d_kernel* jk = jit_rows2d_kernel(desc.precision, n1, n0, max_lds, &why);
+    if (jk == nullptr) jit_note("rows2d", n1, why);
+    return jk;
   }
 
   /// W_n^m for m in [0, n): the inter-pass column twiddles of the two-pass 2-D plan
@@ -428,14 +437,15 @@ struct plan_t {
     s.ra.twc = upload_unit_roots(n0);
     s.ra.nmat = nmat;
     s.ra.n0 = static_cast<int>(n0);
-    for (int d = 0; d < 2; ++d) {
+    for (int d = 0; d < 2 && k->launch != nullptr; ++d) {
       if (k->lds_bytes > 48 * 1024) {
         hip_check(hipFuncSetAttribute(k->fn[d], hipFuncAttributeMaxDynamicSharedMemorySize,
                                       static_cast<int>(k->lds_bytes)),
                   "hipFuncSetAttribute");
       }
     }
-    s.grid = persistent_grid(k->fn[backward], nullptr, k->wg, k->lds_bytes, nmat * (n0 / k->rc), k->groups_per_wg);
+    s.grid = persistent_grid(k->launch != nullptr ? k->fn[backward] : nullptr, k->mfn[backward], k->wg, k->lds_bytes,
+                             nmat * (n0 / k->rc), k->groups_per_wg);
     return s;
   }
 
@@ -1158,7 +1168,9 @@ struct plan_t {
       a.in = static_cast<const char*>(in_re) + static_cast<size_t>(s.in_offset) * elem_bytes();
       a.out = aliased ? static_cast<char*>(alias_scratch)
                       : static_cast<char*>(out_re) + static_cast<size_t>(s.out_offset) * elem_bytes();
-      hip_check(s.rows2d->launch(stream, s.grid, a, s.backward), "kernel launch");
+      hip_check(s.rows2d->launch != nullptr ? s.rows2d->launch(stream, s.grid, a, s.backward)
+                                            : jit_launch_rows2d(s.rows2d, stream, s.grid, a, s.backward),
+                "kernel launch");
       return;
     }
     if (s.strided != nullptr) {

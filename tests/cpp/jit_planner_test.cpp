@@ -72,12 +72,34 @@ int main(int argc, char** argv) {
   EXPECT(p.radices.size() == 3 && p.radices[0] == 9, "243 -> 9,9,3");
   pfa::choose_spec_params(0, 4096, max_lds, &p);
   EXPECT(p.radices.size() == 3 && p.radices[0] == 16 && p.wg == 256 && p.fpw == 1, "4096 -> 16,16,16 / 256 lanes");
+  // two-pass 2-D plan, pass 1: the planner's invariants for every row length it accepts
+  for (int prec = 0; prec < 2; ++prec) {
+    int accepted = 0;
+    for (long long n1 = 32; n1 <= 8192; ++n1) {
+      for (long long n0 : {64ll, 1000ll, 1026ll}) {
+        pfa::wg_params q;
+        if (!pfa::choose_rows2d_params(prec, n1, n0, max_lds, &q)) continue;
+        ++accepted;
+        long long prod = 1;
+        for (int r : q.radices) prod *= r;
+        const long long nbl = n1 / q.radices.back();
+        EXPECT(prod == n1 && q.radices.size() >= 2, "rows2d %lld: radices multiply to n1", n1);
+        EXPECT(n0 % q.fpw == 0 && n0 / q.fpw >= 2, "rows2d %lld x %lld: column radix %d divides n0", n1, n0, q.fpw);
+        EXPECT(nbl % q.wg == 0 && q.wg % q.fpw == 0 && q.wg <= 1024, "rows2d %lld: lanes %d", n1, q.wg);
+        EXPECT(q.regs <= (prec ? 16 : 32), "rows2d %lld: %d elements per lane", n1, q.regs);
+        EXPECT(pfa::spec_lds_bytes(q) <= max_lds, "rows2d %lld: LDS", n1);
+      }
+    }
+    EXPECT(accepted > 500, "rows2d planner accepts %d (n1, n0) pairs", accepted);
+  }
   if (argc > 1 && std::string(argv[1]) == "compile") {
-    struct { int prec; long long n; int kind; } cases[] = {{0, 1200, 0}, {1, 625, 1}, {0, 30, 0}, {0, 120, 2}, {1, 250, 3}};
+    struct { int prec; long long n; int kind; } cases[] = {{0, 1200, 0}, {1, 625, 1}, {0, 30, 0}, {0, 120, 2}, {1, 250, 3},
+                                                            {0, 1000, 4}, {1, 768, 4}};
     for (auto& c : cases) {
       pfa::wg_params q;
       const bool ok = c.kind < 2 ? pfa::choose_spec_params(c.prec, c.n, max_lds, &q)
-                                 : pfa::choose_strided_params(c.prec, c.n, 1024, max_lds, &q);
+                      : c.kind == 4 ? pfa::choose_rows2d_params(c.prec, c.n, 1200, max_lds, &q)
+                                    : pfa::choose_strided_params(c.prec, c.n, 1024, max_lds, &q);
       EXPECT(ok, "plan %lld", c.n);
       size_t bytes = 0;
       std::string why;
