@@ -684,17 +684,22 @@ struct plan_t {
     return s;
   }
 
-  /// BATCH_INTERLEAVED on both sides (element i of transform b at i * B + b), length n = n1 * n2, B transforms.
+  /// BATCH_INTERLEAVED on both sides (element i of transform b at i * B + b), length n = n1 * n2, B transforms --
+  /// `outer` such arrays n * B elements apart (the long column dimension of an N-D array: outer matrices, B adjacent
+  /// columns; outer = 1 for a batch-interleaved 1-D descriptor).
   /// Stage A: for every (c, b): FFT over r of x[(r*n2 + c)*B + b], times W_n^{k1*c}, into scratch (same layout).
   /// Stage B: for every (k1, b): FFT over c of scratch[(k1*n2 + c)*B + b] -> out[(k2*n1 + k1)*B + b].
   /// Only taken when a single work-group would hold fewer than 16 (fp32) / 8 (fp64) columns of the whole length.
-  bool plan_batch_interleaved_two_stage(std::vector<stage>& out, long long n, long long B, const addressing& ia,
-                                        const addressing& oa, double scale, int backward, pfft_dim_info_t* info) {
+  bool plan_batch_interleaved_two_stage(std::vector<stage>& out, long long n, long long B, long long outer, int in_buf,
+                                        int out_buf, const addressing& ia, const addressing& oa, double scale,
+                                        int backward, pfft_dim_info_t* info) {
     const int full_fpw = desc.precision == PFFT_PRECISION_F64 ? 8 : 16;
     if (strided_fpw(n, B) >= full_fpw) return false;
     if (static_cast<unsigned long long>(n) * static_cast<unsigned long long>(B) * elem_bytes() >= 0xFFFFFFF0ull) {
       return false;  // a stage's byte offsets must fit the 32-bit buffer addressing
     }
+    const size_t need = static_cast<size_t>(n) * static_cast<size_t>(B) * static_cast<size_t>(outer) * elem_bytes();
+    if (outer > 1 && need > global_chunk_bytes()) return false;  // the intermediate is as large as the data
     long long n1 = 0;
     for (long long c = static_cast<long long>(std::sqrt(static_cast<double>(n))); c >= 2; --c) {
       if (n % c != 0) continue;
@@ -707,21 +712,21 @@ struct plan_t {
     const long long n2 = n / n1;
     const strided_kernel* ka = get_strided(n1, n2 * B, true, false, true);  // both stages are column-shaped on both
     const strided_kernel* kb = get_strided(n2, B, false, false, true);      // sides: wide-group entries
-    addressing a_in{ia.offset, n2 * B, 1, 0};
-    addressing a_out{0, n2 * B, 1, 0};
+    addressing a_in{ia.offset, n2 * B, 1, n * B};
+    addressing a_out{0, n2 * B, 1, n * B};
     addressing b_in{0, B, 1, n2 * B};
     addressing b_out{oa.offset, n1 * B, 1, B};
-    if (!strided_fits(ka, n2 * B, BUF_IN, a_in, BUF_SCRATCH, a_out) ||
-        !strided_fits(kb, B, BUF_SCRATCH, b_in, BUF_OUT, b_out)) {
+    if (!strided_fits(ka, n2 * B, in_buf, a_in, BUF_SCRATCH, a_out) ||
+        !strided_fits(kb, B, BUF_SCRATCH, b_in, out_buf, b_out)) {
       return false;
     }
-    scratch_bytes = std::max(scratch_bytes, static_cast<size_t>(n) * static_cast<size_t>(B) * elem_bytes());
+    scratch_bytes = std::max(scratch_bytes, need);
     int shift = 0;
     while ((1ll << (2 * shift)) < n) ++shift;
     const void* stw_lo = nullptr;
     const void* stw_hi = nullptr;
     upload_store_twiddles(n, shift, &stw_lo, &stw_hi);
-    stage sa = make_strided_stage(ka, n2 * B, n2 * B, BUF_IN, a_in, BUF_SCRATCH, a_out, 1.0, backward);
+    stage sa = make_strided_stage(ka, outer * n2 * B, n2 * B, in_buf, a_in, BUF_SCRATCH, a_out, 1.0, backward);
     sa.sa.stw_lo = stw_lo;
     sa.sa.stw_hi = stw_hi;
     sa.sa.stw_shift = shift;
@@ -729,7 +734,12 @@ struct plan_t {
     sa.store_modifier = 1;
     sa.row_mode = 0;
     out.push_back(sa);
-    stage sb = make_strided_stage(kb, n1 * B, B, BUF_SCRATCH, b_in, BUF_OUT, b_out, scale, backward);
+    stage sb = make_strided_stage(kb, outer * n1 * B, B, BUF_SCRATCH, b_in, out_buf, b_out, scale, backward);
+    if (outer > 1) {  // outer index of stage B = (array, k1): the array part advances by n * B on both sides
+      sb.sa.outer_lo = n1;
+      sb.sa.in_dist_outer_hi = n * B;
+      sb.sa.out_dist_outer_hi = n * B;
+    }
     out.push_back(sb);
     if (info != nullptr) {
       info->tier = PFFT_TIER_GLOBAL;
@@ -807,7 +817,19 @@ struct plan_t {
     // split N = n1 * n2 and run both four-step stages column shaped with full-width groups, through scratch.
     if (interleaved && desc.rank == 1 && in_buf == BUF_IN && out_buf == BUF_OUT && ia.dist_inner == 1 &&
         oa.dist_inner == 1 && ia.stride == count && oa.stride == count && inner_count == count) {
-      if (plan_batch_interleaved_two_stage(out, n, count, ia, oa, scale, backward, info)) return PFFT_TIER_GLOBAL;
+      if (plan_batch_interleaved_two_stage(out, n, count, 1, in_buf, out_buf, ia, oa, scale, backward, info)) {
+        return PFFT_TIER_GLOBAL;
+      }
+    }
+    // ... and long column dimensions of N-D arrays: `inner_count` adjacent columns per array, arrays n * inner apart
+    if (interleaved && desc.rank > 1 && in_buf != BUF_SCRATCH && out_buf != BUF_SCRATCH && ia.dist_inner == 1 &&
+        oa.dist_inner == 1 && ia.stride == inner_count && oa.stride == inner_count && inner_count > 0 &&
+        count % inner_count == 0 && ia.dist_outer == n * inner_count && oa.dist_outer == n * inner_count &&
+        getenv("PFFT_ND_TWO_STAGE_COLUMNS") == nullptr) {
+      if (plan_batch_interleaved_two_stage(out, n, inner_count, count / inner_count, in_buf, out_buf, ia, oa, scale,
+                                           backward, info)) {
+        return PFFT_TIER_GLOBAL;
+      }
     }
     // the strided tier pays when at least one side is "column" shaped (consecutive FFTs adjacent in memory)
     const bool column_shaped = ia.dist_inner == 1 || oa.dist_inner == 1;

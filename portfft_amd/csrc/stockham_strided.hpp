@@ -313,8 +313,14 @@ PFA_DEV strided_io<typename Cfg::T, Cfg::AUX, SPLIT> strided_group(const strided
   if (nlive_out != nullptr) *nlive_out = nlive;
   // group-major sides: group number (g - o * per_outer) of outer index o starts at that multiple of gdist
   const long long gw = g - o * per_outer;
-  const long long ioff = o * a.in_dist_outer + (a.in_gdist != 0 ? gw * a.in_gdist : c0 * a.in_fdist);
-  const long long ooff = o * a.out_dist_outer + (a.out_gdist != 0 ? gw * a.out_gdist : c0 * a.out_fdist);
+  long long obase_in = o * a.in_dist_outer, obase_out = o * a.out_dist_outer;
+  if (a.outer_lo > 0) {
+    const long long ohi = o / a.outer_lo, olo = o - ohi * a.outer_lo;
+    obase_in = ohi * a.in_dist_outer_hi + olo * a.in_dist_outer;
+    obase_out = ohi * a.out_dist_outer_hi + olo * a.out_dist_outer;
+  }
+  const long long ioff = obase_in + (a.in_gdist != 0 ? gw * a.in_gdist : c0 * a.in_fdist);
+  const long long ooff = obase_out + (a.out_gdist != 0 ? gw * a.out_gdist : c0 * a.out_fdist);
   // ranges: last element of the last FFT of the group (the planner guarantees < 4 GiB)
   const unsigned in_bytes = (static_cast<unsigned>(Cfg::FPW - 1) * a.in_fdist +
                              (static_cast<unsigned>(Cfg::N - 1) >> a.in_tile_shift) * a.in_stride +

@@ -33,6 +33,11 @@ struct strided_args {
   /// out_fdist = 1 a stage writes [element % tile][f] tiles -- the four-step stage A filling an intermediate that is
   /// laid out per stage-B work-group.
   unsigned out_tile_mul;
+  /// two-level outer index (0 = unused): outer index o = (o / outer_lo, o % outer_lo); the high part advances by
+  /// *_dist_outer_hi, the low part by *_dist_outer.  Lets one launch cover several matrices when the stage's outer
+  /// index already has a meaning inside a matrix (second stage of a long column transform of an N-D array).
+  long long outer_lo;
+  long long in_dist_outer_hi, out_dist_outer_hi;
 };
 
 /// Launch-time arguments of the first pass of the two-pass 2-D plan (stockham_rows2d.hpp): `nmat` matrices of

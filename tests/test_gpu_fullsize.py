@@ -66,7 +66,10 @@ def test_two_pass_2d_plan(prec):
     directions, leading dimensions, an OUT_OF_PLACE plan executed with aliasing buffers."""
     G, pf, torch = _mods()
     dtype = np.complex64 if prec == "f32" else np.complex128
-    shapes = ([256, 256], [64, 1024], [1024, 1024], [512, 512], [16, 2048], [1000, 1024], [3, 128, 512], [2, 2, 64, 256])
+    # ... plus shapes whose column dimension is too long for one wide column pass (two column-shaped stages through
+    # scratch, plan_batch_interleaved_two_stage with an outer index) and a runtime-planned row length
+    shapes = ([256, 256], [64, 1024], [1024, 1024], [512, 512], [16, 2048], [1000, 1024], [3, 128, 512], [2, 2, 64, 256],
+              [4096, 64], [2048, 1536], [2, 4096, 48], [1080, 1920])
     for dims in shapes:
         n = int(np.prod(dims))
         batch = 3 if n <= (1 << 18) else 2
