@@ -18,8 +18,8 @@ const rows2d_kernel g_rows2d[] = {
     make_rows2d_entry<wg_cfg<f, radix_list<16, 16, 8>, 256, 4, 16, 1, TW_REGS, 2, NT>>(2),          // 2048
     make_rows2d_entry<wg_cfg<d, radix_list<16, 8, 2>, 128, 4, 16, 1, TW_GLOBAL, 4, NT, 0, 2>>(2),   // 256
     make_rows2d_entry<wg_cfg<d, radix_list<16, 8, 4>, 128, 4, 16, 1, TW_GLOBAL, 2, NT, 0, 2>>(2),   // 512
-    make_rows2d_entry<wg_cfg<d, radix_list<16, 16, 4>, 256, 4, 16, 1, TW_GLOBAL, 2, NT, 0, 2>>(2),  // 1024
-    make_rows2d_entry<wg_cfg<d, radix_list<16, 16, 8>, 256, 2, 16, 1, TW_GLOBAL, 2, NT, 0, 2>>(2),  // 2048
+    make_rows2d_entry<wg_cfg<d, radix_list<16, 16, 4>, 256, 4, 16, 1, TW_GLOBAL, 2, NT, 0, 1>>(1),  // 1024 (TWL 1: 73 KiB, two per CU: 6.2 TB/s; TWL 2 = 86 KiB, one per CU: 5.0)
+    make_rows2d_entry<wg_cfg<d, radix_list<16, 16, 8>, 256, 2, 16, 1, TW_GLOBAL, 2, NT, 0, 1>>(1),  // 2048 (TWL 1: two work-groups per CU)
 };
 }  // namespace
 
