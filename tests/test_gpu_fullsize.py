@@ -184,3 +184,48 @@ def test_cross_lane_variants(prec):
                 assert H.rel_l2(got[b], 0.5 * y[b]) <= tol, ("xlane fwd", prec, n, batch, b)
                 assert H.rel_l2(back[b], n * x[b].astype(np.complex128)) <= tol, ("xlane bwd", prec, n, batch, b)
             assert H.rel_l2(got, base) <= 2 * tol, ("xlane vs staged", prec, n, batch)
+
+
+def test_python_mirror_events_dependencies_and_argument_checks():
+    """portfft_amd/api.py: per-submission events, `dependencies` (this module's events and torch.cuda.Event across
+    streams), copies of a committed descriptor, and the argument checks in front of the C ABI (a tensor on the wrong
+    device / of the wrong dtype / too short / not contiguous raises invalid_configuration instead of faulting)."""
+    G, pf, torch = _mods()
+    n, batch = 4096, 64
+    x, y = H.gen_fourier_data(batch, [n], np.complex64, seed=5)
+    d = G.make_descriptor([n], "f32", batch=batch)
+    side = torch.cuda.Stream()
+    plan = d.commit()
+    xin = torch.empty(batch * n, dtype=torch.complex64, device="cuda")
+    out = torch.empty_like(xin)
+    with torch.cuda.stream(side):  # the input is produced on another stream; only the dependency orders the FFT
+        xin.copy_(torch.from_numpy(x.ravel()), non_blocking=False)
+        produced = torch.cuda.Event()
+        produced.record(side)
+    ev = plan.compute_forward(xin, out, dependencies=[produced])
+    assert isinstance(ev, pf.event)
+    ev.wait()
+    assert ev.is_complete()
+    assert H.rel_l2(out.cpu().numpy().reshape(batch, n), y) <= 2e-6
+    # chained through this module's events, then a copy of the plan (own scratch, shared twiddles)
+    back = torch.empty_like(xin)
+    e2 = plan.compute_backward(out, back, dependencies=[ev])
+    clone = plan.copy()
+    del plan
+    out2 = torch.empty_like(xin)
+    e3 = clone.compute_forward(xin, out2, dependencies=[e2])
+    e3.wait()
+    assert torch.equal(out, out2)
+    assert H.rel_l2(back.cpu().numpy().reshape(batch, n), n * x.astype(np.complex128)) <= 2e-6
+    # argument checks
+    for bad, what in ((torch.empty(batch * n, dtype=torch.complex64), "device memory"),
+                      (torch.empty(batch * n, dtype=torch.complex128, device="cuda"), "dtype"),
+                      (torch.empty(batch * n - 1, dtype=torch.complex64, device="cuda"), "elements"),
+                      (torch.empty(2 * batch * n, dtype=torch.complex64, device="cuda")[::2], "contiguous")):
+        with pytest.raises(pf.invalid_configuration, match=what):
+            clone.compute_forward(bad, out2)
+    with pytest.raises(pf.invalid_configuration):
+        clone.compute_forward(xin, out2, out2)  # not one of the overloads
+    # a float32 view of interleaved data is accepted (two scalars per element)
+    clone.compute_forward(torch.view_as_real(xin).reshape(-1), torch.view_as_real(out2).reshape(-1)).wait()
+    assert torch.equal(out, out2)
