@@ -47,7 +47,8 @@ bool choose_strided_params(int precision, long long n, long long inner_count, si
 bool choose_rows2d_params(int precision, long long n1, long long n0, size_t max_lds, wg_params* out);
 
 /// Runtime-compiled stockham_rows2d_kernel for row length n1 (cached per device, precision, n1 and column radix)
-const rows2d_kernel* jit_rows2d_kernel(int precision, long long n1, long long n0, size_t max_lds, std::string* why);
+const rows2d_kernel* jit_rows2d_kernel(int precision, long long n1, long long n0, size_t max_lds, std::string* why,
+                                       int policy = 0);
 hipError_t jit_launch_rows2d(const rows2d_kernel* k, hipStream_t stream, unsigned grid, const rows2d_args& args,
                              int backward);
 
@@ -91,7 +92,7 @@ const spec_kernel* jit_spec_kernel(int precision, long long n, bool split, size_
 /// SPLIT_COMPLEX data), 3 split output (stage B); see stockham_strided.hpp).
 const strided_kernel* jit_strided_kernel(int precision, long long n, long long inner_count, bool store_modifier,
                                          int split_mode, size_t max_lds, std::string* why,
-                                         bool column_both = false);
+                                         bool column_both = false, int policy = 0);
 
 /// UNPACKED-layout form (stockham_wg_unpacked_kernel) of the packed configuration `like` (a pre-compiled or a
 /// runtime-specialised entry): forward/backward module functions for interleaved or split storage.

@@ -76,6 +76,10 @@ struct strided_kernel {
   /// width; fn_tin[backward]; null when not instantiated
   const void* fn_tin[2];
   hipError_t (*launch_tin)(hipStream_t stream, unsigned grid, const strided_args& args, int backward);
+  /// cache policy of the entry's HBM accesses (stockham_wg.hpp, aux_of_loads / aux_of_stores): 0 everything streamed
+  /// (nt), 1 "writer" (streamed loads, default-policy stores: fills an intermediate that should stay in the
+  /// Infinity Cache), 2 "reader" (default-policy loads, streamed stores).  Policy twins carry the interleaved forms only.
+  int policy;
   /// 1: alternative entry for the same length, preferred when both sides of the stage are column-shaped
   int wide;
   /// 1: alternative entry preferred when one side of the stage is row-shaped (its `_row` forms pay at this length)
@@ -97,8 +101,13 @@ struct rows2d_kernel {
   hipError_t (*launch)(hipStream_t stream, unsigned grid, const rows2d_args& args, int backward);
   /// runtime-compiled entries (jit.cpp): module functions [backward]; fn / launch are null
   hipFunction_t mfn[2];
+  int policy;  // see strided_kernel::policy (0 or 1)
 };
 const rows2d_kernel* rows2d_kernels(int* count);
+
+/// AUX template values of the three cache policies
+enum : int { PFA_AUX_NT = 2, PFA_AUX_WRITER = 0x102, PFA_AUX_READER = 0x300 };
+inline int aux_of_policy(int policy) { return policy == 1 ? PFA_AUX_WRITER : policy == 2 ? PFA_AUX_READER : PFA_AUX_NT; }
 
 const strided_kernel* strided_kernels_f32(int* count);
 const strided_kernel* strided_kernels_f64(int* count);

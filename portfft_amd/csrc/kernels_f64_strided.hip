@@ -5,26 +5,30 @@ namespace pfa {
 
 namespace {
 using d = double;
-constexpr int NT = 2;
-const strided_kernel g_strided_f64[] = {
-    make_strided_entry<strided_cfg<d, radix_list<8, 8>, 128, 16, 2, NT>>(),         // 64
-    make_strided_entry<strided_cfg<d, radix_list<16, 8>, 128, 16, 2, NT>>(),        // 128
-    // with_tin: tiled-input forms for the four-step stage B (lanes element-fastest inside the intermediate's tiles)
-    with_tin<strided_cfg<d, radix_list<16, 16>, 128, 8, 2, NT>>(make_strided_entry<strided_cfg<d, radix_list<16, 16>, 128, 8, 2, NT>>()),        // 256
-    with_tin<strided_cfg<d, radix_list<8, 8, 8>, 512, 8, 2, NT>>(make_strided_entry<strided_cfg<d, radix_list<8, 8, 8>, 512, 8, 2, NT>>()),       // 512
-    with_tin<strided_cfg<d, radix_list<16, 8, 8>, 512, 8, 2, NT>>(make_strided_entry<strided_cfg<d, radix_list<16, 8, 8>, 512, 8, 2, NT>>()),      // 1024
-    with_tin<strided_cfg<d, radix_list<16, 16, 8>, 512, 4, 2, NT>>(make_strided_entry<strided_cfg<d, radix_list<16, 16, 8>, 512, 4, 2, NT>>()),     // 2048
-    // 16 columns per group (256-byte segments) for stages that are column-shaped on both sides (batch-interleaved
-    // layouts, N-D outer dimensions): BI N=256 4.7 -> 5.4 TB/s, N=512 4.4 -> 5.0.  The four-step stages keep the
-    // 8-column entries above (their row-shaped side gets worse with more rows per wave: N=65536 2.7 -> 2.35).
-    wide(make_strided_entry<strided_cfg<d, radix_list<16, 16>, 256, 16, 2, NT>>()),    // 256
-    wide(make_strided_entry<strided_cfg<d, radix_list<8, 8, 8>, 1024, 16, 2, NT>>()),  // 512
-};
+constexpr int NT = PFA_AUX_NT;
+// Every entry comes with its "writer" and "reader" cache-policy twins (add_strided_entries, strided_kernel::policy).
+std::vector<strided_kernel> build() {
+  std::vector<strided_kernel> v;
+  add_strided_entries<strided_cfg<d, radix_list<8, 8>, 128, 16, 2, NT>>(v);         // 64
+  add_strided_entries<strided_cfg<d, radix_list<16, 8>, 128, 16, 2, NT>>(v);        // 128
+  // SE_TIN: tiled-input forms for the four-step stage B (lanes element-fastest inside the intermediate's tiles)
+  add_strided_entries<strided_cfg<d, radix_list<16, 16>, 128, 8, 2, NT>, SE_TIN>(v);     // 256
+  add_strided_entries<strided_cfg<d, radix_list<8, 8, 8>, 512, 8, 2, NT>, SE_TIN>(v);    // 512
+  add_strided_entries<strided_cfg<d, radix_list<16, 8, 8>, 512, 8, 2, NT>, SE_TIN>(v);   // 1024
+  add_strided_entries<strided_cfg<d, radix_list<16, 16, 8>, 512, 4, 2, NT>, SE_TIN>(v);  // 2048
+  // 16 columns per group (256-byte segments) for stages that are column-shaped on both sides (batch-interleaved
+  // layouts, N-D outer dimensions): BI N=256 4.7 -> 5.4 TB/s, N=512 4.4 -> 5.0.  The four-step stages keep the
+  // 8-column entries above (their row-shaped side gets worse with more rows per wave: N=65536 2.7 -> 2.35).
+  add_strided_entries<strided_cfg<d, radix_list<16, 16>, 256, 16, 2, NT>, SE_WIDE>(v);    // 256
+  add_strided_entries<strided_cfg<d, radix_list<8, 8, 8>, 1024, 16, 2, NT>, SE_WIDE>(v);  // 512
+  return v;
+}
 }  // namespace
 
 const strided_kernel* strided_kernels_f64(int* count) {
-  *count = static_cast<int>(sizeof(g_strided_f64) / sizeof(g_strided_f64[0]));
-  return g_strided_f64;
+  static const std::vector<strided_kernel> g = build();
+  *count = static_cast<int>(g.size());
+  return g.data();
 }
 
 }  // namespace pfa

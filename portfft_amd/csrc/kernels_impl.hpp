@@ -1,5 +1,7 @@
 // Shared body of kernels_f32.hip / kernels_f64.hip: turns wg_cfg<...> variants into registry entries.
 #pragma once
+#include <vector>
+
 #include "../../include/portfft_amd.h"
 #include "generic_kernel.hpp"
 #include "kernels.hpp"
@@ -9,6 +11,17 @@
 #include "stockham_xlane.hpp"
 
 namespace pfa {
+
+/// the same configuration with another cache policy (AUX)
+template <typename Cfg, int AUX2>
+struct with_aux;
+template <typename T, typename Seq, int WG, int FPW, int PADS, int PADW, int TWM, int OCC, int AUX, int STAGED, int TWL,
+          int AUX2>
+struct with_aux<wg_cfg<T, Seq, WG, FPW, PADS, PADW, TWM, OCC, AUX, STAGED, TWL>, AUX2> {
+  using type = wg_cfg<T, Seq, WG, FPW, PADS, PADW, TWM, OCC, AUX2, STAGED, TWL>;
+};
+template <typename Cfg, int AUX2>
+using with_aux_t = typename with_aux<Cfg, AUX2>::type;
 
 template <typename Cfg>
 hipError_t launch_spec_prefetch(hipStream_t stream, unsigned grid, const void* in, void* out, const void* tw,
@@ -203,6 +216,18 @@ hipError_t launch_rows2d(hipStream_t stream, unsigned grid, const rows2d_args& a
   return hipGetLastError();
 }
 
+template <typename Cfg>
+rows2d_kernel make_rows2d_entry(int groups_per_wg);
+
+/// the entry for Cfg (cache policy nt) and its writer twin (default-policy stores)
+template <typename Cfg>
+void add_rows2d_entries(std::vector<rows2d_kernel>& v, int groups_per_wg) {
+  v.push_back(make_rows2d_entry<Cfg>(groups_per_wg));
+  rows2d_kernel w = make_rows2d_entry<with_aux_t<Cfg, PFA_AUX_WRITER>>(groups_per_wg);
+  w.policy = 1;
+  v.push_back(w);
+}
+
 /// Cfg: the row FFT's wg_cfg with FPW = rows per work-group (= the column radix)
 template <typename Cfg>
 rows2d_kernel make_rows2d_entry(int groups_per_wg) {
@@ -289,6 +314,110 @@ strided_kernel make_strided_entry_prefetch(int groups_per_wg = 4) {
   k.fn[3] = reinterpret_cast<const void*>(&stockham_strided_prefetch_kernel<Cfg, true, true>);
   k.launch = &launch_strided_prefetch<Cfg>;
   return k;
+}
+
+/// flags of add_strided_entries
+enum : unsigned { SE_ROWS = 1, SE_TIN = 2, SE_WIDE = 4, SE_ROWISH = 8, SE_PREFETCH = 16 };
+
+template <typename Cfg, unsigned F>
+strided_kernel make_strided_entry_flags(int groups_per_wg) {
+  strided_kernel k = (F & SE_PREFETCH) ? make_strided_entry_prefetch<Cfg>(groups_per_wg) : make_strided_entry<Cfg>(groups_per_wg);
+  if constexpr ((F & SE_ROWS) != 0) k = with_rows<Cfg>(k);
+  if constexpr ((F & SE_TIN) != 0) k = with_tin<Cfg>(k);
+  k.wide = (F & SE_WIDE) != 0;
+  k.rowish = (F & SE_ROWISH) != 0;
+  return k;
+}
+
+/// launchers of the policy twins: a writer only exists with the store modifier (four-step stage A), a reader only
+/// without it (stage B, second pass of the two-pass 2-D plan)
+template <typename Cfg, bool PREFETCH>
+hipError_t launch_strided_writer(hipStream_t stream, unsigned grid, const strided_args& args, int backward, int stw) {
+  if (!stw) return hipErrorInvalidValue;
+  constexpr size_t lds = strided_lds_bytes<Cfg>();
+  const dim3 g(grid), b(Cfg::WG);
+  if constexpr (PREFETCH) {
+    if (backward) hipLaunchKernelGGL((stockham_strided_prefetch_kernel<Cfg, true, true>), g, b, lds, stream, args);
+    else hipLaunchKernelGGL((stockham_strided_prefetch_kernel<Cfg, false, true>), g, b, lds, stream, args);
+  } else {
+    if (backward) hipLaunchKernelGGL((stockham_strided_kernel<Cfg, true, true>), g, b, lds, stream, args);
+    else hipLaunchKernelGGL((stockham_strided_kernel<Cfg, false, true>), g, b, lds, stream, args);
+  }
+  return hipGetLastError();
+}
+template <typename Cfg, bool PREFETCH>
+hipError_t launch_strided_reader(hipStream_t stream, unsigned grid, const strided_args& args, int backward, int stw) {
+  if (stw) return hipErrorInvalidValue;
+  constexpr size_t lds = strided_lds_bytes<Cfg>();
+  const dim3 g(grid), b(Cfg::WG);
+  if constexpr (PREFETCH) {
+    if (backward) hipLaunchKernelGGL((stockham_strided_prefetch_kernel<Cfg, true, false>), g, b, lds, stream, args);
+    else hipLaunchKernelGGL((stockham_strided_prefetch_kernel<Cfg, false, false>), g, b, lds, stream, args);
+  } else {
+    if (backward) hipLaunchKernelGGL((stockham_strided_kernel<Cfg, true, false>), g, b, lds, stream, args);
+    else hipLaunchKernelGGL((stockham_strided_kernel<Cfg, false, false>), g, b, lds, stream, args);
+  }
+  return hipGetLastError();
+}
+template <typename Cfg>
+hipError_t launch_strided_row_in(hipStream_t stream, unsigned grid, const strided_args& args, int backward, int row_out) {
+  if (row_out) return hipErrorInvalidValue;
+  constexpr size_t lds = strided_row_lds_bytes<Cfg>();
+  const dim3 g(grid), b(Cfg::WG);
+  if (backward) hipLaunchKernelGGL((stockham_strided_row_kernel<Cfg, true, true, false>), g, b, lds, stream, args);
+  else hipLaunchKernelGGL((stockham_strided_row_kernel<Cfg, false, true, false>), g, b, lds, stream, args);
+  return hipGetLastError();
+}
+
+/// policy twin of `base` (the nt entry of the same shape): Cfg carries the twin's AUX; only the forms a writer
+/// (policy 1) or a reader (policy 2) is ever launched in are instantiated, the others stay null
+template <typename Cfg, unsigned F>
+strided_kernel make_strided_twin(const strided_kernel& base, int policy) {
+  constexpr bool PF = (F & SE_PREFETCH) != 0;
+  strided_kernel k = base;
+  k.policy = policy;
+  for (auto& fp : k.fn) fp = nullptr;
+  for (auto& fp : k.fn_row) fp = nullptr;
+  k.fn_split[0] = k.fn_split[1] = nullptr;
+  k.fn_tin[0] = k.fn_tin[1] = nullptr;
+  k.launch_split = nullptr;
+  k.launch_row = nullptr;
+  k.launch_tin = nullptr;
+  if (policy == 1) {
+    if constexpr (PF) {
+      k.fn[1] = reinterpret_cast<const void*>(&stockham_strided_prefetch_kernel<Cfg, false, true>);
+      k.fn[3] = reinterpret_cast<const void*>(&stockham_strided_prefetch_kernel<Cfg, true, true>);
+    } else {
+      k.fn[1] = reinterpret_cast<const void*>(&stockham_strided_kernel<Cfg, false, true>);
+      k.fn[3] = reinterpret_cast<const void*>(&stockham_strided_kernel<Cfg, true, true>);
+    }
+    k.launch = &launch_strided_writer<Cfg, PF>;
+  } else {
+    if constexpr (PF) {
+      k.fn[0] = reinterpret_cast<const void*>(&stockham_strided_prefetch_kernel<Cfg, false, false>);
+      k.fn[2] = reinterpret_cast<const void*>(&stockham_strided_prefetch_kernel<Cfg, true, false>);
+    } else {
+      k.fn[0] = reinterpret_cast<const void*>(&stockham_strided_kernel<Cfg, false, false>);
+      k.fn[2] = reinterpret_cast<const void*>(&stockham_strided_kernel<Cfg, true, false>);
+    }
+    k.launch = &launch_strided_reader<Cfg, PF>;
+    if constexpr ((F & SE_ROWS) != 0) {
+      k.fn_row[0] = reinterpret_cast<const void*>(&stockham_strided_row_kernel<Cfg, false, true, false>);
+      k.fn_row[1] = reinterpret_cast<const void*>(&stockham_strided_row_kernel<Cfg, true, true, false>);
+      k.launch_row = &launch_strided_row_in<Cfg>;
+    }
+    if constexpr ((F & SE_TIN) != 0) k = with_tin<Cfg>(k);
+  }
+  return k;
+}
+
+/// the entry for Cfg (cache policy nt) and its writer / reader twins
+template <typename Cfg, unsigned F = 0>
+void add_strided_entries(std::vector<strided_kernel>& v, int groups_per_wg = 1) {
+  const strided_kernel base = make_strided_entry_flags<Cfg, F>(groups_per_wg);
+  v.push_back(base);
+  v.push_back(make_strided_twin<with_aux_t<Cfg, PFA_AUX_WRITER>, F>(base, 1));
+  v.push_back(make_strided_twin<with_aux_t<Cfg, PFA_AUX_READER>, F>(base, 2));
 }
 
 template <typename Cfg>

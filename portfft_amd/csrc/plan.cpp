@@ -72,6 +72,7 @@ struct stage {
   int n = 0;
   // GLOBAL tier: the stages of one transform run chunk by chunk so that the intermediate stays cache resident
   int chunk_group = -1;            // stages with the same id advance together
+  long long chunk_batches = 0;     // user transforms (2-D plan: matrices) per chunk of this group
   long long ffts_per_batch = 0;    // FFTs this stage runs per user transform
   long long in_batch_dist = 0;     // elements between consecutive user transforms in the stage's input (0: scratch)
   long long out_batch_dist = 0;
@@ -203,7 +204,8 @@ struct plan_t {
   size_t twiddle_bytes = 0;
   void* alias_scratch = nullptr;  // intermediate of the two-pass 2-D plan for aliasing (in-place) executes
   size_t alias_scratch_bytes = 0;
-  long long chunk_batches = 0;  // user transforms per chunk of the GLOBAL tier
+  size_t two_pass_chunk_bytes = 0;  // bytes of one chunk of the two-pass 2-D plan (what an aliasing execute needs)
+  int tail_policy = 0;              // cache policy plan_1d gives the strided stage it plans (two-pass 2-D plan: reader)
   int n_chunk_groups = 0;
   pfft_plan_info_t info{};
 
@@ -297,13 +299,13 @@ struct plan_t {
   /// column_both: the stage is column-shaped on both sides -> the wide-group entry of the length, when there is one
   /// row_side: one side of the stage is row-shaped -> the row-friendly entry of the length, when there is one
   const strided_kernel* find_strided(long long n, bool column_both = false, bool row_side = false,
-                                     long long inner_count = -1) const {
+                                     long long inner_count = -1, int policy = 0) const {
     int count = 0;
     const strided_kernel* k =
         desc.precision == PFFT_PRECISION_F64 ? strided_kernels_f64(&count) : strided_kernels_f32(&count);
     const strided_kernel* found = nullptr;
     for (int i = 0; i < count; ++i) {
-      if (k[i].n != n || k[i].lds_bytes > max_lds) continue;
+      if (k[i].n != n || k[i].lds_bytes > max_lds || k[i].policy != policy) continue;
       if (k[i].wide == 0 && k[i].rowish == 0 && found == nullptr) found = &k[i];
       // wide groups only pay when the stage has that many adjacent columns (surplus lanes would be masked)
       if (k[i].wide != 0 && column_both && (inner_count < 0 || inner_count >= k[i].fpw)) return &k[i];
@@ -323,13 +325,18 @@ struct plan_t {
   }
 
   /// the pre-compiled strided kernel when it suits the stage, otherwise a runtime-specialised one (jit.hpp)
+  /// policy: cache policy of the stage (strided_kernel::policy; 1 writer -- needs store_modifier --, 2 reader)
   const strided_kernel* get_strided(long long n, long long inner_count, bool store_modifier, bool user_split,
-                                    bool column_both = false, bool row_side = false) {
-    const strided_kernel* k = find_strided(n, column_both, row_side && !user_split, inner_count);
+                                    bool column_both = false, bool row_side = false, int policy = 0) {
+    if (user_split) policy = 0;
+    const strided_kernel* k = find_strided(n, column_both, row_side && !user_split, inner_count, policy);
     if (k != nullptr) return k;
+    if (find_strided(n, column_both, row_side && !user_split, inner_count, 0) != nullptr && policy != 0) {
+      return find_strided(n, column_both, row_side && !user_split, inner_count, 0);  // no twin registered
+    }
     std::string why;
     k = jit_strided_kernel(desc.precision, n, inner_count, store_modifier, user_split ? 1 : 0, max_lds, &why,
-                           column_both);
+                           column_both, policy);
     if (k == nullptr) jit_note("strided", n, why);
     return k;
   }
@@ -381,14 +388,14 @@ struct plan_t {
     return range_ok(ia) && range_ok(oa);
   }
 
-  const rows2d_kernel* find_rows2d(long long n1, long long n0) {
+  const rows2d_kernel* find_rows2d(long long n1, long long n0, int policy) {
     const char* e = getenv("PFFT_2D_TWO_PASS");
     if (e != nullptr && e[0] == '0') return nullptr;  // experiments / parity A-B: rows, then full-length columns
     int count = 0;
     const rows2d_kernel* k = rows2d_kernels(&count);
     for (int i = 0; i < count; ++i) {
       if (k[i].precision == desc.precision && k[i].n == n1 && k[i].lds_bytes <= max_lds && n0 % k[i].rc == 0 &&
-          n0 / k[i].rc >= 2) {
+          n0 / k[i].rc >= 2 && k[i].policy == policy) {
         return &k[i];
       }
     }
@@ -399,7 +406,7 @@ struct plan_t {
     const int col_fpw = strided_fpw(n0, n1);
     if (col_fpw > 0 && static_cast<size_t>(col_fpw) * elem_bytes() >= 256) return nullptr;
     std::string why;
-    const rows2d_kernel* jk = jit_rows2d_kernel(desc.precision, n1, n0, max_lds, &why);
+    const rows2d_kernel* jk = jit_rows2d_kernel(desc.precision, n1, n0, max_lds, &why, policy);
     if (jk == nullptr) jit_note("rows2d", n1, why);
     return jk;
   }
@@ -450,9 +457,11 @@ struct plan_t {
   }
 
   stage make_strided_stage(const strided_kernel* k, long long count, long long inner_count, int in_buf,
-                           const addressing& ia, int out_buf, const addressing& oa, double scale, int backward) {
+                           const addressing& ia, int out_buf, const addressing& oa, double scale, int backward,
+                           int store_modifier = 0) {
     stage s;
     s.strided = k;
+    s.store_modifier = store_modifier;
     s.n = k->n;
     s.in_buf = in_buf;
     s.out_buf = out_buf;
@@ -494,11 +503,13 @@ struct plan_t {
         s.lds_bytes = k->lds_bytes_row;
       }
     }
-    if (k->launch_row != nullptr && !user_split && k->lds_bytes_row <= max_lds) {  // pre-compiled entries
+    if (k->launch_row != nullptr && !user_split && k->lds_bytes_row <= max_lds &&
+        (want_row == 0 || k->fn_row[(want_row - 1) * 2 + backward] != nullptr)) {  // pre-compiled entries
       s.row_mode = want_row;
       if (s.row_mode != 0) {
         s.lds_bytes = k->lds_bytes_row;
         for (int i = 0; i < 4; ++i) {
+          if (k->fn_row[i] == nullptr) continue;  // policy twins carry the row-shaped-input forms only
           hip_check(hipFuncSetAttribute(k->fn_row[i], hipFuncAttributeMaxDynamicSharedMemorySize,
                                         static_cast<int>(k->lds_bytes_row)),
                     "hipFuncSetAttribute");
@@ -507,12 +518,16 @@ struct plan_t {
     }
     for (int i = 0; i < 4 && k->launch != nullptr; ++i) {
       if (k->lds_bytes > 48 * 1024) {
-        hip_check(hipFuncSetAttribute(k->fn[i], hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      static_cast<int>(k->lds_bytes)),
-                  "hipFuncSetAttribute");
-        hip_check(hipFuncSetAttribute(k->fn_split[i / 2], hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      static_cast<int>(k->lds_bytes)),
-                  "hipFuncSetAttribute");
+        if (k->fn[i] != nullptr) {
+          hip_check(hipFuncSetAttribute(k->fn[i], hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        static_cast<int>(k->lds_bytes)),
+                    "hipFuncSetAttribute");
+        }
+        if (k->fn_split[i / 2] != nullptr) {
+          hip_check(hipFuncSetAttribute(k->fn_split[i / 2], hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        static_cast<int>(k->lds_bytes)),
+                    "hipFuncSetAttribute");
+        }
         if (k->fn_tin[i / 2] != nullptr) {
           hip_check(hipFuncSetAttribute(k->fn_tin[i / 2], hipFuncAttributeMaxDynamicSharedMemorySize,
                                         static_cast<int>(k->lds_bytes)),
@@ -534,9 +549,30 @@ struct plan_t {
     } else if (s.row_mode != 0) {
       s.grid = persistent_grid(k->fn_row[(s.row_mode - 1) * 2 + backward], nullptr, k->wg, k->lds_bytes_row, groups, 1);
     } else {
-      s.grid = persistent_grid(k->fn[backward * 2], nullptr, k->wg, k->lds_bytes, groups, k->groups_per_wg);
+      const void* fn = k->fn[backward * 2 + (store_modifier ? 1 : 0)];
+      if (fn == nullptr) fn = k->fn[backward * 2] != nullptr ? k->fn[backward * 2] : k->fn[backward * 2 + 1];
+      s.grid = persistent_grid(fn, nullptr, k->wg, k->lds_bytes, groups, k->groups_per_wg);
     }
     return s;
+  }
+
+  /// the launch grid of a chunked stage is sized for ONE chunk (`count` FFTs / `nmat` matrices), not for the whole
+  /// batch: the per-kernel rule "groups_per_wg groups per work-group" must hold inside a chunk
+  void regrid_for_chunk(stage& s, long long count) {
+    if (s.strided != nullptr) {
+      const strided_kernel* k = s.strided;
+      const long long groups = strided_groups(count, s.sa.inner, k->fpw);
+      if (k->launch == nullptr) return;  // runtime-compiled entries: one group per work-group already
+      const void* fn = s.row_mode != 0 ? k->fn_row[(s.row_mode - 1) * 2 + s.backward]
+                                       : (s.tiled_in != 0 ? k->fn_tin[s.backward] : k->fn[s.backward * 2 + (s.store_modifier ? 1 : 0)]);
+      if (fn == nullptr) return;
+      s.grid = persistent_grid(fn, nullptr, k->wg, s.row_mode != 0 ? k->lds_bytes_row : k->lds_bytes, groups,
+                               s.row_mode != 0 ? 1 : k->groups_per_wg);
+    } else if (s.rows2d != nullptr) {
+      const rows2d_kernel* k = s.rows2d;
+      s.grid = persistent_grid(k->launch != nullptr ? k->fn[s.backward] : nullptr, k->mfn[s.backward], k->wg, k->lds_bytes,
+                               count / std::max<long long>(1, s.ra.n0) * (s.ra.n0 / k->rc), k->groups_per_wg);
+    }
   }
 
   /// bytes of intermediate data per chunk of the GLOBAL tier = cap of the scratch allocation
@@ -548,6 +584,20 @@ struct plan_t {
       return static_cast<size_t>(v) << 20;
     }
     return size_t{4} << 30;
+  }
+
+  /// Two-launch plans (four-step tier, two-pass 2-D plan) run chunk by chunk with the intermediate of a chunk sized
+  /// to the 256 MiB Infinity Cache: the first launch writes it with default-policy stores (streamed loads), the second
+  /// reads it with default-policy loads (streamed stores), so the intermediate's read is served on-die.  Measured on
+  /// C5 (tools/tune_2d_small.hip): 256 matrices as 8 chunks of 256 MiB 1.274 ms against 1.421 ms unchunked with
+  /// streamed accesses; chunks of 288 MiB and more fall off the cliff (1.60 ms), smaller ones pay launch tails.
+  /// PFFT_CACHE_CHUNK_MIB overrides (0: no cache-sized chunks, everything streamed as in round 1).
+  static size_t cache_chunk_bytes() {
+    if (const char* e = getenv("PFFT_CACHE_CHUNK_MIB")) {
+      const long v = std::atol(e);
+      return v <= 0 ? 0 : static_cast<size_t>(v) << 20;
+    }
+    return size_t{256} << 20;
   }
 
   /// largest length the generic tier can hold (two LDS images)
@@ -710,8 +760,12 @@ struct plan_t {
     }
     if (n1 == 0) return false;
     const long long n2 = n / n1;
-    const strided_kernel* ka = get_strided(n1, n2 * B, true, false, true);  // both stages are column-shaped on both
-    const strided_kernel* kb = get_strided(n2, B, false, false, true);      // sides: wide-group entries
+    // the intermediate is written once and read once: keep it in the Infinity Cache when all of it fits
+    // (measured with random data, tools/perf_cache.py: +4...13 % from 128 MiB of intermediate up; below that the
+    //  streamed kernels are faster -- everything sits in the cache anyway -- so small problems keep them)
+    const bool cached = cache_chunk_bytes() > 0 && need <= cache_chunk_bytes() && need >= cache_chunk_bytes() / 2;
+    const strided_kernel* ka = get_strided(n1, n2 * B, true, false, true, false, cached ? 1 : 0);  // column-shaped on
+    const strided_kernel* kb = get_strided(n2, B, false, false, true, false, cached ? 2 : 0);      // both sides: wide
     addressing a_in{ia.offset, n2 * B, 1, n * B};
     addressing a_out{0, n2 * B, 1, n * B};
     addressing b_in{0, B, 1, n2 * B};
@@ -726,7 +780,7 @@ struct plan_t {
     const void* stw_lo = nullptr;
     const void* stw_hi = nullptr;
     upload_store_twiddles(n, shift, &stw_lo, &stw_hi);
-    stage sa = make_strided_stage(ka, outer * n2 * B, n2 * B, in_buf, a_in, BUF_SCRATCH, a_out, 1.0, backward);
+    stage sa = make_strided_stage(ka, outer * n2 * B, n2 * B, in_buf, a_in, BUF_SCRATCH, a_out, 1.0, backward, 1);
     sa.sa.stw_lo = stw_lo;
     sa.sa.stw_hi = stw_hi;
     sa.sa.stw_shift = shift;
@@ -837,7 +891,7 @@ struct plan_t {
     const bool column_both = ia.dist_inner == 1 && oa.dist_inner == 1;
     const bool row_side = (ia.stride == 1 && ia.dist_inner != 1) || (oa.stride == 1 && oa.dist_inner != 1);
     if (const strided_kernel* k =
-            column_shaped ? get_strided(n, inner_count, false, user_split, column_both, row_side) : nullptr;
+            column_shaped ? get_strided(n, inner_count, false, user_split, column_both, row_side, tail_policy) : nullptr;
         strided_fits(k, inner_count, in_buf, ia, out_buf, oa)) {
       out.push_back(make_strided_stage(k, count, inner_count, in_buf, ia, out_buf, oa, scale, backward));
       record(PFFT_TIER_WORKGROUP, std::vector<int>(k->radices, k->radices + k->n_radices), k->wg, k->fpw,
@@ -886,10 +940,24 @@ struct plan_t {
     // Chunking (the reference's num_batches_in_l2 idea, committed_descriptor_impl.hpp:603-611) bounds the scratch.
     // Measured on MI355X (profiles/r1_notes.md): cache-sized chunks (16-256 MiB) do NOT make stage B's reads hit the
     // Infinity Cache -- they only shrink the launches -- so the default chunk is as large as the scratch cap allows.
+    // Round 2: with the intermediate of a chunk written by default-policy stores and read by default-policy loads
+    // (everything else streamed) a chunk of the Infinity Cache's size IS served on-die (cache_chunk_bytes()).
     const size_t per_transform = static_cast<size_t>(n) * elem_bytes();
-    long long chunk = static_cast<long long>(global_chunk_bytes() / per_transform);
+    const bool interleaved_io = desc.complex_storage == PFFT_INTERLEAVED_COMPLEX;
+    // Measured with random data (tools/perf_cache.py): fp32 N=65536 x 2048 +5.5 %, fp32 2^20 x 256 +3.3 %, fp64 65536 x
+    // 512 +7 %; below 128 MiB of intermediate the streamed kernels win (-8 % at 64 MiB), and a batch that needs
+    // several chunks of one-work-group-per-CU kernels (C3: fp64 1024-point stages, 130 KiB of LDS) loses ~1 % to the
+    // tails of the extra launches, so those two cases keep round 1's plan.
+    const size_t all_bytes = per_transform * static_cast<size_t>(count);
+    bool cached = interleaved_io && cache_chunk_bytes() >= per_transform && all_bytes >= cache_chunk_bytes() / 2;
+    if (cached && all_bytes > cache_chunk_bytes()) {
+      const strided_kernel* pa = find_strided(n1);
+      const strided_kernel* pb = find_strided(n2);
+      const size_t big = 80 * 1024;
+      if ((pa != nullptr && pa->lds_bytes > big) || (pb != nullptr && pb->lds_bytes > big)) cached = false;
+    }
+    long long chunk = static_cast<long long>((cached ? cache_chunk_bytes() : global_chunk_bytes()) / per_transform);
     chunk = std::max<long long>(1, std::min<long long>(chunk, count));
-    chunk_batches = chunk;
     const int group_id = n_chunk_groups++;
     const size_t need = static_cast<size_t>(chunk) * per_transform;
     scratch_bytes = std::max(scratch_bytes, need);
@@ -903,9 +971,9 @@ struct plan_t {
     upload_store_twiddles(n, shift, &stw_lo, &stw_hi);
     const bool interleaved_user = desc.complex_storage == PFFT_INTERLEAVED_COMPLEX;
     const bool user_io = in_buf != BUF_SCRATCH && out_buf != BUF_SCRATCH;
-    const strided_kernel* ka = interleaved_user ? get_strided(n1, n2, true, false)
+    const strided_kernel* ka = interleaved_user ? get_strided(n1, n2, true, false, false, false, cached ? 1 : 0)
                                                 : (user_io ? get_strided_mixed(n1, n2, 2) : nullptr);
-    const strided_kernel* kb = interleaved_user ? get_strided(n2, n1, false, false, false, true)  // rows in
+    const strided_kernel* kb = interleaved_user ? get_strided(n2, n1, false, false, false, true, cached ? 2 : 0)  // rows in
                                                 : (user_io ? get_strided_mixed(n2, n1, 3) : nullptr);
     const char* dbg = getenv("PFFT_DEBUG_GLOBAL");  // debugging aid: "ga" / "gb" force the generic kernel for a stage
     const bool force_generic_a = dbg != nullptr && std::strstr(dbg, "ga") != nullptr;
@@ -914,7 +982,7 @@ struct plan_t {
     if (!force_generic_a && strided_fits(ka, n2, in_buf, a_in, BUF_SCRATCH, a_out)) {
       // conjugating on load and store in both stages is the identity in between, so the backward transform can use
       // the kernels' BWD form on both
-      sa = make_strided_stage(ka, count * n2, n2, in_buf, a_in, BUF_SCRATCH, a_out, 1.0, backward);
+      sa = make_strided_stage(ka, count * n2, n2, in_buf, a_in, BUF_SCRATCH, a_out, 1.0, backward, 1);
       sa.sa.stw_lo = stw_lo;
       sa.sa.stw_hi = stw_hi;
       sa.sa.stw_shift = shift;
@@ -926,6 +994,7 @@ struct plan_t {
       sa.ga.stw_shift = shift;
     }
     sa.chunk_group = group_id;
+    sa.chunk_batches = chunk;
     sa.ffts_per_batch = n2;
     sa.in_batch_dist = n;
     sa.out_batch_dist = 0;
@@ -940,6 +1009,7 @@ struct plan_t {
       sb = make_generic_stage(n2, count * n1, n1, BUF_SCRATCH, b_in, out_buf, b_out, scale, backward, backward);
     }
     sb.chunk_group = group_id;
+    sb.chunk_batches = chunk;
     sb.ffts_per_batch = n1;
     sb.in_batch_dist = 0;
     sb.out_batch_dist = n;
@@ -991,6 +1061,10 @@ struct plan_t {
           sb.tiled_in = 1;
         }
       }
+    }
+    if (chunk < count) {
+      regrid_for_chunk(out.back(), chunk * n2);
+      regrid_for_chunk(sb, chunk * n1);
     }
     out.push_back(sb);
     record(PFFT_TIER_GLOBAL, {static_cast<int>(n1), static_cast<int>(n2)}, sb.generic ? GENERIC_WG : kb->wg,
@@ -1057,7 +1131,17 @@ struct plan_t {
       const long long n0 = static_cast<long long>(desc.lengths[rank - 2]);
       const long long n1 = static_cast<long long>(desc.lengths[rank - 1]);
       const long long nmat = B * (total / (n0 * n1));
-      const rows2d_kernel* rk = find_rows2d(n1, n0);
+      // chunk of matrices whose intermediate fits the Infinity Cache (cache_chunk_bytes): pass 1 as "writer", pass 2
+      // as "reader"; a single matrix beyond the cache keeps the streamed kernels and one launch per pass
+      const size_t matrix_bytes = static_cast<size_t>(n0) * static_cast<size_t>(n1) * elem_bytes();
+      // (random data, tools/perf_cache.py: 1024^2 x 16 / 32 / 64 / 256 +6 / +13 / +7 / +2 %, 512^2 x 128 +9 %; a 32 MiB
+      //  batch is 18 % faster with the streamed kernels, hence the lower bound)
+      const bool cached = cache_chunk_bytes() >= matrix_bytes &&
+                          matrix_bytes * static_cast<size_t>(nmat) >= cache_chunk_bytes() / 2;
+      const long long chunk_mats = cached ? std::max<long long>(1, std::min<long long>(
+                                                nmat, static_cast<long long>(cache_chunk_bytes() / matrix_bytes)))
+                                          : nmat;
+      const rows2d_kernel* rk = find_rows2d(n1, n0, cached ? 1 : 0);
       const bool range_ok = static_cast<unsigned long long>(n0) * static_cast<unsigned long long>(n1) * elem_bytes() <
                             0xFFFFFFF0ull;
       const size_t all_bytes = static_cast<size_t>(B) * static_cast<size_t>(total) * elem_bytes();
@@ -1068,13 +1152,32 @@ struct plan_t {
         addressing a{static_cast<long long>(vout.offset), cols, 1, n0 * n1};
         std::vector<stage> tail;
         pfft_dim_info_t di{};
+        tail_policy = cached ? 2 : 0;
         const int tier = plan_1d(tail, m, nmat * cols, cols, BUF_OUT, a, BUF_OUT, a, false, scale, backward, &di);
+        tail_policy = 0;
         if (tier == PFFT_TIER_WORKGROUP && tail.size() == 1 && tail[0].strided != nullptr) {
           st.push_back(make_rows2d_stage(rk, nmat, n0, static_cast<long long>(vin.offset),
                                          static_cast<long long>(vout.offset), backward));
           tail[0].alias_scratch = 2;
+          if (chunk_mats < nmat) {  // pass 1 and pass 2 advance together, chunk_mats matrices at a time
+            const int group_id = n_chunk_groups++;
+            stage& s1 = st.back();
+            s1.chunk_group = group_id;
+            s1.chunk_batches = chunk_mats;
+            s1.ffts_per_batch = n0;
+            s1.in_batch_dist = s1.out_batch_dist = n0 * n1;
+            tail[0].chunk_group = group_id;
+            tail[0].chunk_batches = chunk_mats;
+            tail[0].ffts_per_batch = cols;
+            tail[0].in_batch_dist = tail[0].out_batch_dist = n0 * n1;
+            regrid_for_chunk(s1, chunk_mats * n0);
+            regrid_for_chunk(tail[0], chunk_mats * cols);
+          }
           st.push_back(tail[0]);
-          if (desc.placement == PFFT_IN_PLACE) alias_scratch_bytes = std::max(alias_scratch_bytes, all_bytes);
+          if (desc.placement == PFFT_IN_PLACE) {
+            alias_scratch_bytes = std::max(alias_scratch_bytes, static_cast<size_t>(chunk_mats) * matrix_bytes);
+          }
+          two_pass_chunk_bytes = std::max(two_pass_chunk_bytes, static_cast<size_t>(chunk_mats) * matrix_bytes);
           if (record) {
             pfft_dim_info_t& d1 = info.dims[rank - 1];
             d1.length = static_cast<uint64_t>(n1);
@@ -1142,7 +1245,8 @@ struct plan_t {
   plan_t(const plan_t& o)
       : desc(o.desc), stream(o.stream), device(o.device), n_cus(o.n_cus), max_lds(o.max_lds), tables(o.tables),
         scratch_bytes(o.scratch_bytes), twiddle_bytes(o.twiddle_bytes), alias_scratch_bytes(o.alias_scratch_bytes),
-        chunk_batches(o.chunk_batches), n_chunk_groups(o.n_chunk_groups), info(o.info) {
+        two_pass_chunk_bytes(o.two_pass_chunk_bytes),
+        n_chunk_groups(o.n_chunk_groups), info(o.info) {
     stages[0] = o.stages[0];
     stages[1] = o.stages[1];
     device_guard dg(device);
@@ -1155,10 +1259,7 @@ struct plan_t {
   /// descriptors, on first use when an OUT_OF_PLACE plan is executed with in == out
   void ensure_alias_scratch() {
     if (alias_scratch != nullptr) return;
-    if (alias_scratch_bytes == 0) {
-      alias_scratch_bytes = static_cast<size_t>(desc.number_of_transforms) * static_cast<size_t>(flattened_length(desc)) *
-                            elem_bytes();
-    }
+    if (alias_scratch_bytes == 0) alias_scratch_bytes = two_pass_chunk_bytes;
     hip_check(hipMalloc(&alias_scratch, alias_scratch_bytes), "hipMalloc(2-D intermediate)");
   }
 
@@ -1187,11 +1288,14 @@ struct plan_t {
     if (aliased) ensure_alias_scratch();
     if (s.rows2d != nullptr) {
       rows2d_args a = s.ra;
-      a.in = static_cast<const char*>(in_re) + static_cast<size_t>(s.in_offset) * elem_bytes();
-      a.out = aliased ? static_cast<char*>(alias_scratch)
-                      : static_cast<char*>(out_re) + static_cast<size_t>(s.out_offset) * elem_bytes();
-      hip_check(s.rows2d->launch != nullptr ? s.rows2d->launch(stream, s.grid, a, s.backward)
-                                            : jit_launch_rows2d(s.rows2d, stream, s.grid, a, s.backward),
+      if (nb >= 0) a.nmat = nb;  // chunked: matrices [b0, b0 + nb)
+      a.in = static_cast<const char*>(in_re) + static_cast<size_t>(s.in_offset + in_shift) * elem_bytes();
+      a.out = aliased ? static_cast<char*>(alias_scratch)  // one chunk at a time goes through the scratch
+                      : static_cast<char*>(out_re) + static_cast<size_t>(s.out_offset + out_shift) * elem_bytes();
+      const long long groups = a.nmat * (a.n0 / s.rows2d->rc);
+      const unsigned grid = static_cast<unsigned>(std::min<long long>(s.grid, std::max<long long>(groups, 1)));
+      hip_check(s.rows2d->launch != nullptr ? s.rows2d->launch(stream, grid, a, s.backward)
+                                            : jit_launch_rows2d(s.rows2d, stream, grid, a, s.backward),
                 "kernel launch");
       return;
     }
@@ -1313,6 +1417,7 @@ struct plan_t {
       size_t j = i;
       while (j < st.size() && st[j].chunk_group == st[i].chunk_group) ++j;
       const long long batches = st[i].count / st[i].ffts_per_batch;
+      const long long chunk_batches = std::max<long long>(1, st[i].chunk_batches);
       for (long long b0 = 0; b0 < batches; b0 += chunk_batches) {
         const long long nb = std::min(chunk_batches, batches - b0);
         for (size_t k = i; k < j; ++k) run_stage(st[k], in_re, in_im, out_re, out_im, b0, nb);

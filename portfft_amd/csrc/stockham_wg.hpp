@@ -145,20 +145,28 @@ using buf_b64_t = decltype(__builtin_amdgcn_raw_buffer_load_b64(declval_of<__amd
 using buf_b128_t = decltype(__builtin_amdgcn_raw_buffer_load_b128(declval_of<__amdgpu_buffer_rsrc_t>(), 0u, 0u, 0));
 static_assert(sizeof(buf_b64_t) == 8 && sizeof(buf_b128_t) == 16, "unexpected raw buffer builtin types");
 
+/// The AUX template argument of a kernel configuration carries the cache policy of its HBM accesses: bits 0-7 the
+/// policy of the loads (0 default, 2 = nt streaming); bits 8-15, when non-zero, (policy + 1) of the stores, which
+/// otherwise follow the loads.  AUX = 2: everything streamed (multi-GiB batches); AUX = 0x102: streamed loads,
+/// default-policy stores -- the writer of an intermediate that should stay in the 256 MiB Infinity Cache;
+/// AUX = 0x300: default-policy loads, streamed stores -- its reader (profiles/r2_notes.md).
+constexpr int aux_of_loads(int aux) { return aux & 0xFF; }
+constexpr int aux_of_stores(int aux) { return (aux >> 8) != 0 ? (aux >> 8) - 1 : (aux & 0xFF); }
+
 template <typename T, int AUX>
 PFA_DEV cx<T> buf_load(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff) {
   if constexpr (sizeof(T) == 4) {
-    return __builtin_bit_cast(cx<T>, __builtin_amdgcn_raw_buffer_load_b64(rsrc, voff, soff, AUX));
+    return __builtin_bit_cast(cx<T>, __builtin_amdgcn_raw_buffer_load_b64(rsrc, voff, soff, aux_of_loads(AUX)));
   } else {
-    return __builtin_bit_cast(cx<T>, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff, AUX));
+    return __builtin_bit_cast(cx<T>, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff, aux_of_loads(AUX)));
   }
 }
 template <typename T, int AUX>
 PFA_DEV void buf_store(cx<T> v, __amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff) {
   if constexpr (sizeof(T) == 4) {
-    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(buf_b64_t, v), rsrc, voff, soff, AUX);
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(buf_b64_t, v), rsrc, voff, soff, aux_of_stores(AUX));
   } else {
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(buf_b128_t, v), rsrc, voff, soff, AUX);
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(buf_b128_t, v), rsrc, voff, soff, aux_of_stores(AUX));
     // gfx950 hazard (observed, ROCm 7.2): a >64-bit buffer store with an SGPR soffset still reads its data VGPRs for
     // two more cycles; hipcc only pads the soffset-immediate form, so a VALU write to the data registers right
     // behind the store corrupts the last quad of every 16-lane row.  Pad by hand.
@@ -203,17 +211,17 @@ using buf_b32_t = decltype(__builtin_amdgcn_raw_buffer_load_b32(declval_of<__amd
 template <typename T, int AUX>
 PFA_DEV T buf_load_scalar(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff) {
   if constexpr (sizeof(T) == 4) {
-    return __builtin_bit_cast(T, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, soff, AUX));
+    return __builtin_bit_cast(T, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, soff, aux_of_loads(AUX)));
   } else {
-    return __builtin_bit_cast(T, __builtin_amdgcn_raw_buffer_load_b64(rsrc, voff, soff, AUX));
+    return __builtin_bit_cast(T, __builtin_amdgcn_raw_buffer_load_b64(rsrc, voff, soff, aux_of_loads(AUX)));
   }
 }
 template <typename T, int AUX>
 PFA_DEV void buf_store_scalar(T v, __amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff) {
   if constexpr (sizeof(T) == 4) {
-    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(buf_b32_t, v), rsrc, voff, soff, AUX);
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(buf_b32_t, v), rsrc, voff, soff, aux_of_stores(AUX));
   } else {
-    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(buf_b64_t, v), rsrc, voff, soff, AUX);
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(buf_b64_t, v), rsrc, voff, soff, aux_of_stores(AUX));
   }
 }
 

@@ -159,6 +159,10 @@ def test_buffers_beyond_4gib():
     _big_case(1200, 1000000)                                      # runtime-specialised length
     _big_case(1 << 20, 1200)                                      # GLOBAL tier fp32, chunked scratch
     _big_case(65536, 10000, prec="f64")                           # GLOBAL tier fp64
+    # intermediates of 128-256 MiB: the cache-policy twins (writer / reader) without chunking
+    _big_case(4096, 6000, layout_in="BI", layout_out="BI")        # two column-shaped stages, 188 MiB of scratch
+    _big_case(65536, 400)                                         # four-step fp32, 200 MiB
+    _big_case(1 << 20, 12, prec="f64")                            # four-step fp64, 192 MiB
 
 
 @pytest.mark.parametrize("prec", ["f32", "f64"])
