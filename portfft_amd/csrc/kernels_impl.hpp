@@ -1,5 +1,6 @@
 // Shared body of kernels_f32.hip / kernels_f64.hip: turns wg_cfg<...> variants into registry entries.
 #pragma once
+#include <cstdlib>
 #include <vector>
 
 #include "../../include/portfft_amd.h"
@@ -30,12 +31,24 @@ hipError_t launch_spec_prefetch(hipStream_t stream, unsigned grid, const void* i
   const auto* i = static_cast<const cx<T>*>(in);
   auto* o = static_cast<cx<T>*>(out);
   const auto* t = static_cast<const cx<T>*>(tw);
+  // two-tier grid for large launches: `grid` is the planner's uniform grid (k groups per work-group); three quarters
+  // of the groups keep that shape, the last quarter goes to work-groups of 2 groups each
+  const long long ngroups = (nfft + Cfg::FPW - 1) / Cfg::FPW;
+  const long long k = grid > 0 ? (ngroups + grid - 1) / grid : 1;
+  long long n_main = 0;
+  static const bool uniform_only = getenv("PFFT_UNIFORM_GRID") != nullptr;  // A/B switch (profiles/r2_notes.md)
+  if (k >= 4 && grid >= 4096 && !uniform_only) {
+    n_main = (static_cast<long long>(grid) * 3 / 4) & ~255ll;
+    const long long rest = ngroups - k * n_main;
+    grid = static_cast<unsigned>(n_main + (rest + 1) / 2);
+  }
+  const int main_k = static_cast<int>(k);
   if (backward) {
     hipLaunchKernelGGL((stockham_wg_prefetch_kernel<Cfg, true>), dim3(grid), dim3(Cfg::WG), Cfg::LDS_BYTES, stream, i,
-                       o, t, nfft, static_cast<T>(scale));
+                       o, t, nfft, static_cast<T>(scale), n_main, main_k);
   } else {
     hipLaunchKernelGGL((stockham_wg_prefetch_kernel<Cfg, false>), dim3(grid), dim3(Cfg::WG), Cfg::LDS_BYTES, stream,
-                       i, o, t, nfft, static_cast<T>(scale));
+                       i, o, t, nfft, static_cast<T>(scale), n_main, main_k);
   }
   return hipGetLastError();
 }

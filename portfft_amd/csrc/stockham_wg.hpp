@@ -475,10 +475,15 @@ PFA_DEV void wg_pass0_compute(cx<typename Cfg::T> (&v)[Cfg::bpt(0)][Cfg::Seq::r[
 /// Software-pipelined variant: the HBM loads of the work-group's NEXT group are issued right after pass 0 of the
 /// current one, so every work-group keeps loads in flight through its LDS/compute passes instead of alternating
 /// between a load phase and a compute phase.  Costs one extra register image of the inputs.
+///
+/// Two-tier grid (n_main > 0): work-groups [0, n_main) take main_k groups each (group b, b + n_main, ...), the
+/// remaining work-groups share the groups behind main_k * n_main a few each.  The hardware hands work-groups to CUs
+/// as slots free up, so the many short work-groups at the end balance the launch at a finer grain than main_k groups
+/// (fp32 N=4096 x 65536: 12288 x 4 + 8192 x 2 FFTs 686-697 us against 704-705 us for 16384 x 4, profiles/r2_notes.md).
 template <typename Cfg, bool BWD>
 __global__ __launch_bounds__(Cfg::WG, Cfg::OCC) void stockham_wg_prefetch_kernel(
     const cx<typename Cfg::T>* in, cx<typename Cfg::T>* out,
-    const cx<typename Cfg::T>* __restrict__ tw, long long nfft, typename Cfg::T scale) {
+    const cx<typename Cfg::T>* __restrict__ tw, long long nfft, typename Cfg::T scale, long long n_main, int main_k) {
   using T = typename Cfg::T;
   using Seq = typename Cfg::Seq;
   static_assert(Cfg::NP >= 2 && !Cfg::STAGED, "prefetching needs a direct-I/O multi-pass kernel");
@@ -510,8 +515,17 @@ __global__ __launch_bounds__(Cfg::WG, Cfg::OCC) void stockham_wg_prefetch_kernel
     for (int i = threadIdx.x; i < Cfg::TWL_ELEMS; i += Cfg::WG) twl[i] = tw[i];
     __syncthreads();
   }
-  const long long ngroups = (nfft + Cfg::FPW - 1) / Cfg::FPW;
-  long long g = blockIdx.x;
+  long long ngroups = (nfft + Cfg::FPW - 1) / Cfg::FPW;
+  long long g = blockIdx.x, gstride = gridDim.x;
+  if (n_main > 0) {
+    if (g < n_main) {
+      gstride = n_main;
+      ngroups = main_k * n_main;  // this work-group's range ends where the tail's begins
+    } else {
+      gstride = static_cast<long long>(gridDim.x) - n_main;
+      g = main_k * n_main + (g - n_main);
+    }
+  }
   if (g >= ngroups) return;
   cx<T> cur[Cfg::bpt(0)][Seq::r[0]];
   cx<T> nxt[Cfg::bpt(0)][Seq::r[0]];
@@ -519,10 +533,10 @@ __global__ __launch_bounds__(Cfg::WG, Cfg::OCC) void stockham_wg_prefetch_kernel
     const IO io0(in, out, g, nfft);
     wg_pass0_load<Cfg, BWD>(io0, f, tid, cur);
   }
-  for (; g < ngroups; g += gridDim.x) {
+  for (; g < ngroups; g += gstride) {
     const IO io(in, out, g, nfft);
     wg_pass0_compute<Cfg>(cur, lds, tid);
-    const long long gn = g + gridDim.x;
+    const long long gn = g + gstride;
     if (gn < ngroups) {
       const IO ion(in, out, gn, nfft);
       wg_pass0_load<Cfg, BWD>(ion, f, tid, nxt);

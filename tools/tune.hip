@@ -53,7 +53,7 @@ void add(const char* name) {
   if constexpr (PF) fn = (const void*)&stockham_wg_prefetch_kernel<Cfg, false>; else fn = (const void*)&stockham_wg_kernel<Cfg, false>;
   CK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS_BYTES));
   g_variants.push_back({name, Cfg::FPW, Cfg::WG, Cfg::LDS_BYTES, fn, [d_tw](unsigned grid, long long nfft) {
-    if constexpr (PF) hipLaunchKernelGGL((stockham_wg_prefetch_kernel<Cfg, false>), dim3(grid), dim3(Cfg::WG), Cfg::LDS_BYTES, 0, (const cx<T>*)g_in, (cx<T>*)g_out, d_tw, nfft, (T)1);
+    if constexpr (PF) hipLaunchKernelGGL((stockham_wg_prefetch_kernel<Cfg, false>), dim3(grid), dim3(Cfg::WG), Cfg::LDS_BYTES, 0, (const cx<T>*)g_in, (cx<T>*)g_out, d_tw, nfft, (T)1, 0ll, 4);
     else hipLaunchKernelGGL((stockham_wg_kernel<Cfg, false>), dim3(grid), dim3(Cfg::WG), Cfg::LDS_BYTES, 0, (const cx<T>*)g_in, (cx<T>*)g_out, d_tw, nfft, (T)1);
   }});
 }

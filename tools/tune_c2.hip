@@ -81,6 +81,61 @@ __global__ __launch_bounds__(256, 3) void rot_kernel(const cx<T>* in, cx<T>* out
   else rot_body<12>(in, out, tw, nfft, lds);
 }
 
+// ---- stag: long-lived work-groups (persistent grid) with a staggered start instead of many short-lived ones ----
+// production de-phases the work-groups by giving each only 4 FFTs (16384 work-groups); every work-group lifetime
+// then pays its twiddle loads and one un-prefetched first load.  Here: grid = k x resident, work-group i sleeps
+// (i % PHASES) * step before its first load.
+__global__ __launch_bounds__(256, 3) void stag_kernel(const cx<T>* in, cx<T>* out, const cx<T>* __restrict__ tw,
+                                                      long long nfft, int phases, int step) {
+  extern __shared__ __attribute__((aligned(16))) char pfa_smem[];
+  cx<T>* lds = reinterpret_cast<cx<T>*>(pfa_smem);
+  if (static_cast<long long>(blockIdx.x) >= nfft) return;
+  const int ph = static_cast<int>(blockIdx.x % static_cast<unsigned>(phases));
+  for (int i = 0; i < ph * step; ++i) __builtin_amdgcn_s_sleep(32);  // 32 x 64 cycles ~ 0.85 us at 2.4 GHz
+  rot_body<0>(in, out, tw, nfft, lds);
+}
+
+// ---- tail: two-tier grid -- n_main work-groups with 4 FFTs each, then short work-groups (tail_k FFTs each) over the
+// remaining FFTs, so that the end of the launch is balanced at a finer grain ----
+template <int ROT>
+PFA_DEV void range_body(const cx<T>* in, cx<T>* out, const cx<T>* __restrict__ tw, long long first, long long stride,
+                        long long end, long long nfft, cx<T>* lds) {
+  const int tid = threadIdx.x;
+  cx<T> twr[Cfg::TWR_TOTAL];
+  load_twr(tw, tid, twr);
+  using IO = packed_io<T, N, 1, 2>;
+  long long g = first;
+  cx<T> cur[1][16], nxt[1][16];
+  {
+    const IO io0(in, out, g, nfft);
+    pass0_load_rot<ROT>(io0, tid, cur);
+  }
+  for (; g < end; g += stride) {
+    const IO io(in, out, g, nfft);
+    wg_pass0_compute<Cfg>(cur, lds, tid);
+    const long long gn = g + stride;
+    if (gn < end) {
+      const IO ion(in, out, gn, nfft);
+      pass0_load_rot<ROT>(ion, tid, nxt);
+    }
+    wg_passes<Cfg, false, 1>(io, 0u, lds, tid, tw, twr, T(1));
+    sfor<0, 16>([&](auto t_) PFA_LAMBDA { cur[0][decltype(t_)::value] = nxt[0][decltype(t_)::value]; });
+  }
+}
+__global__ __launch_bounds__(256, 3) void tail_kernel(const cx<T>* in, cx<T>* out, const cx<T>* __restrict__ tw,
+                                                      long long nfft, long long n_main, int tail_k) {
+  extern __shared__ __attribute__((aligned(16))) char pfa_smem[];
+  cx<T>* lds = reinterpret_cast<cx<T>*>(pfa_smem);
+  const long long b = blockIdx.x;
+  if (b < n_main) {
+    range_body<0>(in, out, tw, b, n_main, 4 * n_main, nfft, lds);
+  } else {
+    const long long n_tail = (nfft - 4 * n_main + tail_k - 1) / tail_k;  // tail work-groups
+    const long long t = b - n_main;
+    if (t < n_tail) range_body<0>(in, out, tw, 4 * n_main + t, n_tail, nfft, nfft, lds);
+  }
+}
+
 // ---- swz: XOR-swizzled LDS image ----
 template <bool PREFETCH, int OCC>
 __global__ __launch_bounds__(256, OCC) void swz_kernel(const cx<T>* in, cx<T>* out, const cx<T>* __restrict__ tw,
@@ -263,7 +318,7 @@ int main() {
   std::vector<variant> vs;
   auto in_ptr = [&]() { return (const cx<T>*)d_in[which & 1]; };
   vs.push_back({"base (production prefetch kernel)", Cfg::LDS_BYTES, (const void*)&stockham_wg_prefetch_kernel<Cfg, false>, [&](unsigned grid) {
-    hipLaunchKernelGGL((stockham_wg_prefetch_kernel<Cfg, false>), dim3(grid), dim3(256), Cfg::LDS_BYTES, 0, in_ptr(), (cx<T>*)d_out, d_tw, nfft, 1.0f); }});
+    hipLaunchKernelGGL((stockham_wg_prefetch_kernel<Cfg, false>), dim3(grid), dim3(256), Cfg::LDS_BYTES, 0, in_ptr(), (cx<T>*)d_out, d_tw, nfft, 1.0f, 0ll, 4); }});
   vs.push_back({"rot (legs start at 4*(wg&3))", Cfg::LDS_BYTES, (const void*)&rot_kernel, [&](unsigned grid) {
     hipLaunchKernelGGL(rot_kernel, dim3(grid), dim3(256), Cfg::LDS_BYTES, 0, in_ptr(), (cx<T>*)d_out, d_tw, nfft); }});
   vs.push_back({"swz (XOR-swizzled LDS, prefetch, 3 WG/CU)", 32768, (const void*)&swz_kernel<true, 3>, [&](unsigned grid) {
@@ -275,6 +330,18 @@ int main() {
   CK(hipFuncSetAttribute((const void*)&dma_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
   vs.push_back({"dma (LDS-DMA prefetch into a raw image, 2 WG/CU)", 65536, (const void*)&dma_kernel<2>, [&](unsigned grid) {
     hipLaunchKernelGGL((dma_kernel<2>), dim3(grid), dim3(256), 65536, 0, in_ptr(), (cx<T>*)d_out, d_tw, nfft); }});
+  for (long long n_main : {15360ll, 14336ll, 12288ll}) for (int tail_k : {1, 2}) {
+    const long long n_tail = (nfft - 4 * n_main + tail_k - 1) / tail_k;
+    char nm[96]; snprintf(nm, sizeof(nm), "tail: %lld x 4 FFTs + %lld x %d", n_main, n_tail, tail_k);
+    vs.push_back({nm, Cfg::LDS_BYTES, (const void*)&tail_kernel, [&, n_main, n_tail, tail_k](unsigned) {
+      hipLaunchKernelGGL(tail_kernel, dim3((unsigned)(n_main + n_tail)), dim3(256), Cfg::LDS_BYTES, 0, in_ptr(), (cx<T>*)d_out, d_tw, nfft, n_main, tail_k); }});
+  }
+  for (int mult : {1}) for (int step : {0}) {
+    const unsigned g = 768u * mult;
+    char nm[96]; snprintf(nm, sizeof(nm), "stag grid %u (x%d resident) 16 phases step %d", g, mult, step);
+    vs.push_back({nm, Cfg::LDS_BYTES, (const void*)&stag_kernel, [&, g, step](unsigned) {
+      hipLaunchKernelGGL(stag_kernel, dim3(g), dim3(256), Cfg::LDS_BYTES, 0, in_ptr(), (cx<T>*)d_out, d_tw, nfft, 16, step); }});
+  }
   // correctness: bit-identical to the production kernel
   vs[0].launch(16384); CK(hipDeviceSynchronize());
   CK(hipMemcpy(d_ref, d_out, bytes, hipMemcpyDeviceToDevice));
