@@ -46,6 +46,8 @@ def main():
     ap.add_argument("--cal-dir", default=None, help="directory with cal FETCH_SIZE / WRITE_SIZE passes of a copy kernel")
     ap.add_argument("--cal-kernel", default="rows_copy")
     ap.add_argument("--cal-kib", type=float, default=2 * 1024 * 1024, help="KiB the calibration kernel reads (= writes)")
+    ap.add_argument("--launches-per-execute", type=int, default=1,
+                    help="launches of EACH matching kernel per execute (plans that run chunk by chunk)")
     a = ap.parse_args()
     subs = [s for s in a.kernels.split(",") if s]
     out = {"config": a.config, "label": a.label,
@@ -76,11 +78,11 @@ def main():
         f, w = fetch.get(name, []), write.get(name, [])
         if not f or not w:
             continue
-        rb = sum(f) / len(f) * 1024 * fetch_corr
-        wb = sum(w) / len(w) * 1024 * write_corr
+        rb = sum(f) / len(f) * 1024 * fetch_corr * a.launches_per_execute
+        wb = sum(w) / len(w) * 1024 * write_corr * a.launches_per_execute
         kernels.append({"kernel": short(name), "launches_sampled": [len(f), len(w)],
                         "FETCH_SIZE_mean_KiB": sum(f) / len(f), "WRITE_SIZE_mean_KiB": sum(w) / len(w),
-                        "hbm_read_bytes_per_launch": rb, "hbm_write_bytes_per_launch": wb})
+                        "hbm_read_bytes_per_execute": rb, "hbm_write_bytes_per_execute": wb})
         read_b += rb
         write_b += wb
     out["kernels"] = kernels
@@ -89,13 +91,14 @@ def main():
     out["traffic_bytes_per_launch"] = read_b + write_b
     out["algorithmic_bytes_per_launch"] = a.alg_bytes
     out["hbm_passes"] = len(kernels)
+    out["launches_of_each_kernel_per_execute"] = a.launches_per_execute
     out["traffic_over_algorithmic"] = round((read_b + write_b) / a.alg_bytes, 4) if a.alg_bytes else None
     with open(a.dst, "w") as fh:
         json.dump(out, fh, indent=1)
     print(json.dumps({k: v for k, v in out.items() if k != "kernels"}, indent=1))
     for k in kernels:
-        print("  %-100s read %.4g B write %.4g B" % (k["kernel"][:100], k["hbm_read_bytes_per_launch"],
-                                                    k["hbm_write_bytes_per_launch"]))
+        print("  %-100s read %.4g B write %.4g B" % (k["kernel"][:100], k["hbm_read_bytes_per_execute"],
+                                                    k["hbm_write_bytes_per_execute"]))
 
 
 if __name__ == "__main__":
