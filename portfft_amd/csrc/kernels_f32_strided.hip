@@ -12,8 +12,9 @@ std::vector<strided_kernel> build() {
   std::vector<strided_kernel> v;
   add_strided_entries<strided_cfg<f, radix_list<8, 8>, 256, 32, 2, NT>, SE_ROWS>(v);           // 64
   add_strided_entries<strided_cfg<f, radix_list<16, 8>, 256, 32, 2, NT>, SE_ROWS>(v);          // 128
-  add_strided_entries<strided_cfg<f, radix_list<16, 16>, 512, 32, 2, NT>, SE_ROWS>(v);         // 256
-  add_strided_entries<strided_cfg<f, radix_list<8, 8, 8>, 1024, 32, 2, NT>, SE_ROWS>(v);       // 512
+  // groups per work-group: tools/perf_gpw.py -- four-step N=65536 x 2Ki 0.799 ms with one, 0.761 ms with four
+  add_strided_entries<strided_cfg<f, radix_list<16, 16>, 512, 32, 2, NT>, SE_ROWS>(v, 4);      // 256
+  add_strided_entries<strided_cfg<f, radix_list<8, 8, 8>, 1024, 32, 2, NT>, SE_ROWS>(v, 2);    // 512
   add_strided_entries<strided_cfg<f, radix_list<32, 32>, 512, 16, 2, NT>, SE_ROWS | SE_PREFETCH>(v, 4);  // 1024
   add_strided_entries<strided_cfg<f, radix_list<16, 16, 8>, 1024, 8, 4, NT>, SE_ROWS>(v);      // 2048
   add_strided_entries<strided_cfg<f, radix_list<16, 16, 16>, 1024, 4, 4, NT>, SE_ROWS>(v);     // 4096
@@ -25,7 +26,7 @@ std::vector<strided_kernel> build() {
   add_strided_entries<strided_cfg<f, radix_list<16, 16>, 1024, 64, 2, NT>, SE_WIDE>(v, 1);     // 256
   // n = 1024 with a row-shaped side: 16.8.8 on 1024 lanes stages rows better than the 32.32 prefetch kernel above
   // (four-step N=2^20 2.00 -> 2.15 TB/s, P->BI 3.73 -> 3.89, BI->P 3.99 -> 4.21); column/column stages keep 32.32
-  add_strided_entries<strided_cfg<f, radix_list<16, 8, 8>, 1024, 16, 4, NT>, SE_ROWS | SE_ROWISH>(v);  // 1024
+  add_strided_entries<strided_cfg<f, radix_list<16, 8, 8>, 1024, 16, 4, NT>, SE_ROWS | SE_ROWISH>(v, 4);  // 1024
   return v;
 }
 }  // namespace

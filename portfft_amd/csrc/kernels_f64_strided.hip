@@ -12,9 +12,12 @@ std::vector<strided_kernel> build() {
   add_strided_entries<strided_cfg<d, radix_list<8, 8>, 128, 16, 2, NT>>(v);         // 64
   add_strided_entries<strided_cfg<d, radix_list<16, 8>, 128, 16, 2, NT>>(v);        // 128
   // SE_TIN: tiled-input forms for the four-step stage B (lanes element-fastest inside the intermediate's tiles)
-  add_strided_entries<strided_cfg<d, radix_list<16, 16>, 128, 8, 2, NT>, SE_TIN>(v);     // 256
-  add_strided_entries<strided_cfg<d, radix_list<8, 8, 8>, 512, 8, 2, NT>, SE_TIN>(v);    // 512
-  add_strided_entries<strided_cfg<d, radix_list<16, 8, 8>, 512, 8, 2, NT>, SE_TIN>(v);   // 1024
+  // groups per work-group (last argument): tools/perf_gpw.py, random data -- four-step fp64 N=2^20 x 128 (C3) 1.733 ms
+  // with one group per work-group, 1.627 ms with four (the tail of a launch of one-work-group-per-CU kernels);
+  // N=2^18 1.500 -> 1.451 ms; N=65536 (n=256) prefers two, N=2^22 (n=2048) one
+  add_strided_entries<strided_cfg<d, radix_list<16, 16>, 128, 8, 2, NT>, SE_TIN>(v, 2);     // 256
+  add_strided_entries<strided_cfg<d, radix_list<8, 8, 8>, 512, 8, 2, NT>, SE_TIN>(v, 4);    // 512
+  add_strided_entries<strided_cfg<d, radix_list<16, 8, 8>, 512, 8, 2, NT>, SE_TIN>(v, 4);   // 1024
   add_strided_entries<strided_cfg<d, radix_list<16, 16, 8>, 512, 4, 2, NT>, SE_TIN>(v);  // 2048
   // 16 columns per group (256-byte segments) for stages that are column-shaped on both sides (batch-interleaved
   // layouts, N-D outer dimensions): BI N=256 4.7 -> 5.4 TB/s, N=512 4.4 -> 5.0.  The four-step stages keep the

@@ -547,7 +547,8 @@ struct plan_t {
       if (f == nullptr) f = k->mfn[backward * 2 + 1];
       s.grid = persistent_grid(nullptr, f, k->wg, k->lds_bytes, groups, k->groups_per_wg);
     } else if (s.row_mode != 0) {
-      s.grid = persistent_grid(k->fn_row[(s.row_mode - 1) * 2 + backward], nullptr, k->wg, k->lds_bytes_row, groups, 1);
+      s.grid = persistent_grid(k->fn_row[(s.row_mode - 1) * 2 + backward], nullptr, k->wg, k->lds_bytes_row, groups,
+                               k->groups_per_wg);
     } else {
       const void* fn = k->fn[backward * 2 + (store_modifier ? 1 : 0)];
       if (fn == nullptr) fn = k->fn[backward * 2] != nullptr ? k->fn[backward * 2] : k->fn[backward * 2 + 1];
@@ -567,7 +568,7 @@ struct plan_t {
                                        : (s.tiled_in != 0 ? k->fn_tin[s.backward] : k->fn[s.backward * 2 + (s.store_modifier ? 1 : 0)]);
       if (fn == nullptr) return;
       s.grid = persistent_grid(fn, nullptr, k->wg, s.row_mode != 0 ? k->lds_bytes_row : k->lds_bytes, groups,
-                               s.row_mode != 0 ? 1 : k->groups_per_wg);
+                               k->groups_per_wg);
     } else if (s.rows2d != nullptr) {
       const rows2d_kernel* k = s.rows2d;
       s.grid = persistent_grid(k->launch != nullptr ? k->fn[s.backward] : nullptr, k->mfn[s.backward], k->wg, k->lds_bytes,
@@ -617,6 +618,7 @@ struct plan_t {
       hip_check(hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, mfn, wg, lds), "occupancy query");
     }
     per_cu = std::max(per_cu, 1);
+    if (const char* e = getenv("PFFT_GROUPS_PER_WG")) groups_per_wg = std::atoi(e);  // grid-rule experiments
     const long long resident = static_cast<long long>(per_cu) * n_cus;
     // groups_per_wg comes from the per-kernel tuning (tools/tune.hip, profiles/r1_notes.md); 0 selects the long
     // persistent loop, which only the one-work-group-per-CU kernels (f32 N=16384) prefer

@@ -81,15 +81,17 @@ int main() {
   add<wg_cfg<d, radix_list<16, 8, 8>, 512, 8, 0, 0, TW_GLOBAL, 2, NT, 0, 1>, 0, true>("f64 16.8.8 wg512 fpw8 TWL1 (production)");
   add<wg_cfg<d, radix_list<16, 8, 8>, 512, 8, 0, 0, TW_GLOBAL, 2, NT, 0, 1>, 2>("HX f64 16.8.8 wg512 fpw8 TWL1");
   add<wg_cfg<d, radix_list<16, 8, 8>, 512, 8, 0, 0, TW_GLOBAL, 2, NT, 0, 1>, 2, true>("HX f64 16.8.8 wg512 fpw8 TWL1");
-  add<wg_cfg<d, radix_list<16, 8, 8>, 512, 8, 0, 0, TW_GLOBAL, 2, NT, 0, 2>, 2>("HX f64 16.8.8 wg512 fpw8 TWL2");
-  add<wg_cfg<d, radix_list<16, 8, 8>, 512, 8, 0, 0, TW_GLOBAL, 2, NT, 0, 2>, 2, true>("HX f64 16.8.8 wg512 fpw8 TWL2");
   add<wg_cfg<d, radix_list<16, 8, 8>, 256, 8, 0, 0, TW_GLOBAL, 1, NT, 0, 1>, 2>("HX f64 16.8.8 wg256(32pt) fpw8 TWL1");
-  add<wg_cfg<d, radix_list<16, 8, 8>, 1024, 16, 0, 0, TW_GLOBAL, 4, NT, 0, 1>, 2>("HX f64 16.8.8 wg1024 fpw16 TWL1");
-  add<wg_cfg<d, radix_list<16, 8, 8>, 1024, 16, 0, 0, TW_GLOBAL, 4, NT, 0, 1>, 2, true>("HX f64 16.8.8 wg1024 fpw16 TWL1");
   add<wg_cfg<d, radix_list<16, 8, 8>, 512, 16, 0, 0, TW_GLOBAL, 2, NT, 0, 1>, 2>("HX f64 16.8.8 wg512(32pt) fpw16 TWL1");
-  add<wg_cfg<d, radix_list<16, 8, 8>, 512, 16, 0, 0, TW_GLOBAL, 2, NT, 0, 1>, 2, true>("HX f64 16.8.8 wg512(32pt) fpw16 TWL1");
-  add<wg_cfg<d, radix_list<32, 32>, 512, 16, 0, 0, TW_GLOBAL, 2, NT, 0, 1>, 2>("HX f64 32.32 wg512 fpw16 TWL1");
-  add<wg_cfg<d, radix_list<32, 32>, 256, 8, 0, 0, TW_GLOBAL, 2, NT, 0, 1>, 2>("HX f64 32.32 wg256 fpw8 TWL1");
+  // software-pipelined loads (next group's loads in flight during the passes)
+  add<wg_cfg<d, radix_list<16, 8, 8>, 512, 8, 0, 0, TW_GLOBAL, 1, NT, 0, 1>, 1>("PF f64 16.8.8 wg512 fpw8 TWL1");
+  add<wg_cfg<d, radix_list<16, 8, 8>, 512, 8, 0, 0, TW_GLOBAL, 1, NT, 0, 1>, 1, true>("PF f64 16.8.8 wg512 fpw8 TWL1");
+  // one exchange instead of two
+  add<wg_cfg<d, radix_list<32, 32>, 256, 8, 0, 0, TW_GLOBAL, 1, NT, 0, 1>, 0>("f64 32.32 wg256 fpw8 TWL1");
+  add<wg_cfg<d, radix_list<32, 32>, 256, 8, 0, 0, TW_GLOBAL, 1, NT, 0, 1>, 0, true>("f64 32.32 wg256 fpw8 TWL1");
+  add<wg_cfg<d, radix_list<32, 32>, 512, 8, 0, 0, TW_GLOBAL, 1, NT, 0, 1>, 0>("f64 32.32 wg512(16pt, half the lanes idle per pass?) fpw8");
+  add<wg_cfg<d, radix_list<16, 8, 8>, 1024, 8, 0, 0, TW_GLOBAL, 2, NT, 0, 1>, 0>("f64 16.8.8 wg1024(8pt) fpw8 TWL1");
+  add<wg_cfg<d, radix_list<16, 8, 8>, 1024, 8, 0, 0, TW_GLOBAL, 2, NT, 0, 1>, 0, true>("f64 16.8.8 wg1024(8pt) fpw8 TWL1");
 #else
   using T = f; g_stride = 1024; g_inner = 1024; g_dist_outer = 1 << 20; g_total = 256 * 1024;
   add<wg_cfg<f, radix_list<16, 8, 8>, 1024, 16, 0, 0, TW_GLOBAL, 4, NT>, 0>("f32 16.8.8 wg1024 fpw16");
