@@ -19,7 +19,7 @@ const spec_kernel g_spec_f32[] = {
     make_spec_entry<wg_cfg_twl<f, radix_list<16, 8>, 256, 32, 16, 1, 4, NT, 1>>(),       // 128
     make_spec_entry<wg_cfg_twl<f, radix_list<16, 16>, 256, 16, 16, 1, 4, NT, 1>>(2),      // 256 (LDS-staged I/O: 6.2 vs 5.6 TB/s -- direct I/O moves 128-byte pieces per FFT here)
     make_spec_entry<wg_cfg<f, radix_list<8, 8, 8>, 256, 4, 16, 1, TW_GLOBAL, 4, NT, 0, 2>>(2),  // 512 (TWL 2: 6.56 vs 6.40 with TW_REGS)
-    make_spec_entry<wg_cfg<f, radix_list<16, 8, 8>, 256, 4, 16, 1, TW_GLOBAL, 4, NT, 0, 2>>(4),  // 1024 (TWL 2: tools/tune.hip; 4 groups per work-group: 5.61 -> 5.90 TB/s on random data, tools/perf_gpw_packed.py)
+    make_spec_entry<wg_cfg<f, radix_list<16, 8, 8>, 256, 4, 16, 1, TW_GLOBAL, 4, NT, 0, 2>>(2),  // 1024 (TWL 2: tools/tune.hip; 2 groups per work-group: library sweep 5.61 / 5.82 / 5.90 TB/s at 1 / 2 / 4, tuner 6.05-6.34 / 5.99-6.39 / 5.89-5.96)
     make_spec_entry<wg_cfg<f, radix_list<16, 16, 8>, 256, 2, 16, 1, TW_GLOBAL, 4, NT, 0, 2>>(4),  // 2048 (TWL 2: 6.03 vs 5.93; 4 groups per work-group: 5.59 -> 5.82)
     // the headline shape: register-resident twiddles + software-pipelined loads (3 work-groups per CU)
     make_spec_entry_prefetch<wg_cfg<f, radix_list<16, 16, 16>, 256, 1, 16, 1, TW_REGS, 3, NT>>(4),  // 4096

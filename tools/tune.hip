@@ -192,6 +192,11 @@ int main() {
   add<wg_cfg<f, S, 256, 4, 16, 1, TW_GLOBAL, 4, NT, 0, 1>, false>("1024 twG TWL1");
   add<wg_cfg<f, S, 256, 4, 16, 1, TW_GLOBAL, 4, NT, 0, 2>, false>("1024 twG TWL2");
   add<wg_cfg<f, S, 256, 4, 16, 1, TW_REGS, 4, NT>, false>("1024 twR");
+  add<wg_cfg<f, S, 256, 4, 16, 1, TW_REGS, 3, NT>, true>("1024 twR o3 PF");
+  add<wg_cfg<f, S, 256, 4, 16, 1, TW_GLOBAL, 3, NT, 0, 2>, true>("1024 twG TWL2 o3 PF");
+  add<wg_cfg<f, S, 256, 4, 16, 1, TW_GLOBAL, 4, NT, 0, 2>, true>("1024 twG TWL2 o4 PF");
+  add<wg_cfg<f, S, 64, 1, 16, 1, TW_REGS, 4, NT>, false>("1024 twR wg64 fpw1");
+  add<wg_cfg<f, S, 128, 2, 16, 1, TW_REGS, 3, NT>, true>("1024 twR wg128 fpw2 o3 PF");
 #elif TUNE_CASE == 3072
   using S = radix_list<16, 16, 12>; using T = f; const int N = 3072;
   add<wg_cfg<f, S, 256, 1, 16, 1, TW_GLOBAL, 4, NT>, false>("3072 twG (current)");
