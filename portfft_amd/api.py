@@ -258,12 +258,25 @@ class committed_descriptor:
             c = desc._c()
             _check(lib.pfft_plan_create(C.byref(c), C.c_void_p(_stream_handle(queue)), C.byref(self._plan)))
         self._device = None
+        self._torch = None
         try:
             import torch
+            self._torch = torch
             if torch.cuda.is_available():
                 self._device = torch.cuda.current_device()
         except ImportError:
             pass
+        # the committed descriptor is a snapshot (the reference copies `params` at commit): element counts, storage and
+        # the dtypes a buffer may have are fixed here, so that a compute call costs a few attribute reads
+        self._split = desc.complex_storage == complex_storage.SPLIT_COMPLEX
+        self._counts = {int(d): (desc.get_input_count(d), desc.get_output_count(d))
+                        for d in (direction.FORWARD, direction.BACKWARD)}
+        self._scalar = desc.scalar
+        if self._torch is not None:
+            f64 = desc.scalar == "f64"
+            self._real_dtype = self._torch.float64 if f64 else self._torch.float32
+            self._cplx_dtype = self._torch.complex128 if f64 else self._torch.complex64
+        self._no_deps = (C.c_void_p * 1)()
 
     def __del__(self):
         plan, self._plan = getattr(self, "_plan", None), None
@@ -285,27 +298,23 @@ class committed_descriptor:
     def _check_buffer(self, x, count, split_plane, what):
         """a torch tensor handed to compute_* must live on the plan's device, have the descriptor's element type, be
         contiguous and cover the descriptor's element count (raw pointers cannot be checked)"""
-        if not hasattr(x, "data_ptr") or not hasattr(x, "is_cuda"):
+        if self._torch is None or not isinstance(x, self._torch.Tensor):
             return
-        import torch
         if not x.is_cuda:
             raise invalid_configuration("%s: the buffer is not in device memory" % what)
         if self._device is not None and x.device.index != self._device:
             raise invalid_configuration("%s: the buffer lives on device %s, the plan was committed on device %d"
                                         % (what, x.device.index, self._device))
-        f64 = self.params.scalar == "f64"
+        dt = x.dtype
         if split_plane:
-            want, unit = (torch.float64 if f64 else torch.float32), 1
-            ok = x.dtype == want
+            unit = 1
+            ok = dt == self._real_dtype
         else:
-            want = torch.complex128 if f64 else torch.complex64
-            real = torch.float64 if f64 else torch.float32
-            ok = x.dtype in (want, real)  # a real view of interleaved data counts two scalars per element
-            unit = 2 if x.dtype == real else 1
+            ok = dt == self._cplx_dtype or dt == self._real_dtype  # a real view counts two scalars per element
+            unit = 2 if dt == self._real_dtype else 1
         if not ok:
             raise invalid_configuration("%s: dtype %s does not match the descriptor (%s %s storage)"
-                                        % (what, x.dtype, self.params.scalar,
-                                           "split" if split_plane else "interleaved"))
+                                        % (what, dt, self._scalar, "split" if split_plane else "interleaved"))
         if not x.is_contiguous():
             raise invalid_configuration("%s: the buffer must be contiguous" % what)
         if x.numel() < count * unit:
@@ -313,30 +322,34 @@ class committed_descriptor:
 
     def _compute(self, dir, args, dependencies=None, want_event=True):
         n = len(args)
-        split = self.params.complex_storage == complex_storage.SPLIT_COMPLEX
-        n_in, n_out = self.params.get_input_count(dir), self.params.get_output_count(dir)
-        deps = [h for h in (_dep_handle(d) for d in (dependencies or [])) if h]
-        dep_arr = (C.c_void_p * max(len(deps), 1))(*deps)
+        split = self._split
+        n_in, n_out = self._counts[int(dir)]
+        if dependencies:
+            deps = [h for h in (_dep_handle(d) for d in dependencies) if h]
+            dep_arr = (C.c_void_p * max(len(deps), 1))(*deps)
+            n_deps = len(deps)
+        else:
+            dep_arr, n_deps = self._no_deps, 0
         ev = C.c_void_p()
         ev_ref = C.byref(ev) if want_event else None
         if n == 1:  # in-place interleaved (committed_descriptor.hpp:171-176, 215-218)
             self._check_buffer(args[0], max(n_in, n_out), False, "inout")
-            _check(lib.pfft_execute_ex(self._plan, int(dir), _ptr(args[0]), _ptr(args[0]), len(deps), dep_arr, ev_ref))
+            _check(lib.pfft_execute_ex(self._plan, int(dir), _ptr(args[0]), _ptr(args[0]), n_deps, dep_arr, ev_ref))
         elif n == 2 and split and not _is_complex(args[0]):
             # in-place split (committed_descriptor.hpp:186-192, 228-232)
             for a, w in zip(args, ("inout_real", "inout_imag")):
                 self._check_buffer(a, max(n_in, n_out), True, w)
             _check(lib.pfft_execute_split_ex(self._plan, int(dir), _ptr(args[0]), _ptr(args[1]), _ptr(args[0]),
-                                             _ptr(args[1]), len(deps), dep_arr, ev_ref))
+                                             _ptr(args[1]), n_deps, dep_arr, ev_ref))
         elif n == 2:  # out-of-place interleaved (committed_descriptor.hpp:242-246, 288-293)
             self._check_buffer(args[0], n_in, False, "in")
             self._check_buffer(args[1], n_out, False, "out")
-            _check(lib.pfft_execute_ex(self._plan, int(dir), _ptr(args[0]), _ptr(args[1]), len(deps), dep_arr, ev_ref))
+            _check(lib.pfft_execute_ex(self._plan, int(dir), _ptr(args[0]), _ptr(args[1]), n_deps, dep_arr, ev_ref))
         elif n == 4:  # out-of-place split (committed_descriptor.hpp:258-263, 305-310)
             for a, w, c in zip(args, ("in_real", "in_imag", "out_real", "out_imag"), (n_in, n_in, n_out, n_out)):
                 self._check_buffer(a, c, True, w)
             _check(lib.pfft_execute_split_ex(self._plan, int(dir), _ptr(args[0]), _ptr(args[1]), _ptr(args[2]),
-                                             _ptr(args[3]), len(deps), dep_arr, ev_ref))
+                                             _ptr(args[3]), n_deps, dep_arr, ev_ref))
         else:
             raise invalid_configuration("compute_* takes (inout), (in, out), (inout_re, inout_im) or "
                                         "(in_re, in_im, out_re, out_im)")

@@ -15,6 +15,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
+#include <mutex>
 #include <memory>
 #include <vector>
 
@@ -1436,6 +1438,49 @@ struct pfft_plan_t {
 };
 
 namespace {
+/// Completion events are recycled: creating and destroying a hipEvent_t per submission costs more than the launch
+/// of a small transform.  pfft_event_destroy returns the event to this pool (per device), new events come from it.
+struct event_pool {
+  std::mutex m;
+  std::vector<std::pair<int, hipEvent_t>> free_list;  // (device, event)
+  hipEvent_t get(int device) {
+    {
+      std::lock_guard<std::mutex> lock(m);
+      for (size_t i = free_list.size(); i-- > 0;) {
+        if (free_list[i].first == device) {
+          hipEvent_t ev = free_list[i].second;
+          free_list[i] = free_list.back();
+          free_list.pop_back();
+          return ev;
+        }
+      }
+    }
+    hipEvent_t ev = nullptr;
+    const hipError_t e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+    if (e != hipSuccess) pfa::fail(PFFT_HIP_ERROR, "hipEventCreate: ", hipGetErrorString(e));
+    std::lock_guard<std::mutex> lock(m);
+    owner[ev] = device;
+    return ev;
+  }
+  /// true when the event was taken back (events not created here are destroyed by the caller)
+  bool put(hipEvent_t ev) {
+    std::lock_guard<std::mutex> lock(m);
+    const auto it = owner.find(ev);
+    if (it == owner.end()) return false;
+    if (free_list.size() >= 1024) {
+      owner.erase(it);
+      return false;
+    }
+    free_list.emplace_back(it->second, ev);
+    return true;
+  }
+  std::map<hipEvent_t, int> owner;
+};
+event_pool& events() {
+  static event_pool* p = new event_pool();  // never destroyed: events may outlive static destruction order
+  return *p;
+}
+
 /// dependencies in, completion event out (shared by the two _ex entry points)
 template <typename Run>
 void execute_with_events(pfft_plan_t* plan, int32_t n_deps, void* const* deps, void** event_out, Run&& run) {
@@ -1450,12 +1495,10 @@ void execute_with_events(pfft_plan_t* plan, int32_t n_deps, void* const* deps, v
   run();
   if (event_out != nullptr) {
     *event_out = nullptr;
-    hipEvent_t ev = nullptr;
-    hipError_t e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
-    if (e != hipSuccess) pfa::fail(PFFT_HIP_ERROR, "hipEventCreate: ", hipGetErrorString(e));
-    e = hipEventRecord(ev, p.stream);
+    hipEvent_t ev = events().get(p.device);
+    const hipError_t e = hipEventRecord(ev, p.stream);
     if (e != hipSuccess) {
-      (void)hipEventDestroy(ev);
+      (void)events().put(ev);
       pfa::fail(PFFT_HIP_ERROR, "hipEventRecord: ", hipGetErrorString(e));
     }
     *event_out = ev;
@@ -1564,6 +1607,7 @@ pfft_status pfft_event_query(void* event, int32_t* done) {
 pfft_status pfft_event_destroy(void* event) {
   return pfa::guarded([&] {
     if (event == nullptr) return;
+    if (events().put(static_cast<hipEvent_t>(event))) return;  // recycled
     const hipError_t e = hipEventDestroy(static_cast<hipEvent_t>(event));
     if (e != hipSuccess) pfa::fail(PFFT_HIP_ERROR, "hipEventDestroy: ", hipGetErrorString(e));
   });
@@ -1585,12 +1629,12 @@ pfft_status pfft_queue_copy(void* hip_stream, const void* src, void* dst, size_t
     }
     if (event_out != nullptr) {
       *event_out = nullptr;
-      hipEvent_t ev = nullptr;
-      hipError_t e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
-      if (e != hipSuccess) pfa::fail(PFFT_HIP_ERROR, "hipEventCreate: ", hipGetErrorString(e));
-      e = hipEventRecord(ev, st);
+      int device = 0;
+      (void)hipGetDevice(&device);
+      hipEvent_t ev = events().get(device);
+      const hipError_t e = hipEventRecord(ev, st);
       if (e != hipSuccess) {
-        (void)hipEventDestroy(ev);
+        (void)events().put(ev);
         pfa::fail(PFFT_HIP_ERROR, "hipEventRecord: ", hipGetErrorString(e));
       }
       *event_out = ev;
