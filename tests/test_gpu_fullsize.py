@@ -233,3 +233,55 @@ def test_python_mirror_events_dependencies_and_argument_checks():
     # a float32 view of interleaved data is accepted (two scalars per element)
     clone.compute_forward(torch.view_as_real(xin).reshape(-1), torch.view_as_real(out2).reshape(-1)).wait()
     assert torch.equal(out, out2)
+
+
+def test_cache_sized_chunks_and_policy_twins():
+    """The two-launch plans run chunk by chunk (256 MiB of intermediate per chunk) on the writer / reader cache-policy
+    twins once the intermediate reaches 128 MiB: batch counts that leave a ragged last chunk, both directions, in-place
+    (the 2-D plan then routes a chunk through its scratch), against NumPy on sampled transforms and against the same
+    plan with PFFT_CACHE_CHUNK_MIB=0 (everything streamed, one launch per pass) bit for bit."""
+    G, pf, torch = _mods()
+
+    def run_case(lengths, batch, prec, placement, env=None):
+        cdt = torch.complex64 if prec == "f32" else torch.complex128
+        n = int(np.prod(lengths))
+        g = torch.Generator(device="cuda").manual_seed(11)
+        x = torch.empty(batch * n, dtype=cdt, device="cuda")
+        torch.view_as_real(x).uniform_(-1, 1, generator=g)
+        old = {k: os.environ.get(k) for k in (env or {})}
+        os.environ.update(env or {})
+        try:
+            plan = G.make_descriptor(lengths, prec, batch=batch, placement=placement).commit()
+        finally:
+            for k, v in old.items():
+                if v is None:
+                    del os.environ[k]
+                else:
+                    os.environ[k] = v
+        if placement == 0:
+            y = x.clone()
+            plan.compute_forward(y).wait()
+        else:
+            y = torch.empty_like(x)
+            plan.compute_forward(x, y).wait()
+        return x, y, plan
+
+    tol = {"f32": 2e-6, "f64": 5e-15}
+    for lengths, batch, prec in (([1024, 1024], 37, "f32"), ([512, 2048], 70, "f32"), ([65536], 700, "f32"),
+                                 ([1 << 18], 150, "f64"), ([1 << 20], 40, "f32")):
+        n = int(np.prod(lengths))
+        for placement in (1, 0):
+            x, y, plan = run_case(lengths, batch, prec, placement)
+            for b in (0, batch // 2, batch - 1):
+                ref = np.fft.fftn(x.view(batch, n)[b].cpu().numpy().astype(np.complex128).reshape(lengths)).ravel()
+                assert H.rel_l2(y.view(batch, n)[b].cpu().numpy(), ref) <= tol[prec], (lengths, batch, prec, placement, b)
+            # same kernels, same arithmetic, other cache policy and launch structure: bit-identical
+            _, y0, _ = run_case(lengths, batch, prec, placement, {"PFFT_CACHE_CHUNK_MIB": "0"})
+            assert torch.equal(y, y0), (lengths, batch, prec, placement)
+            # backward over the chunked plan restores the input
+            z = torch.empty_like(x)
+            plan.compute_backward(y, z).wait()
+            err = float(((z / n - x).abs().double().pow(2).sum() / x.abs().double().pow(2).sum()).sqrt())
+            assert err <= tol[prec], (lengths, batch, prec, placement, err)
+            del y, y0, z
+        torch.cuda.empty_cache()
