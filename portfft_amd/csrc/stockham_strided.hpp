@@ -362,9 +362,9 @@ __global__ __launch_bounds__(Cfg::WG, Cfg::OCC) void stockham_strided_prefetch_k
   const unsigned f = threadIdx.x % Cfg::FPW;
   const unsigned tid = threadIdx.x / Cfg::FPW;
   const cx<T>* __restrict__ tw = static_cast<const cx<T>*>(a.tw);
-  const long long ngroups = strided_ngroups<Cfg>(a);
-  long long g = blockIdx.x;
-  if (g >= ngroups) return;
+  const group_range_t gr = tiered_range(strided_ngroups<Cfg>(a), a.tier_main, a.tier_k);
+  long long g = gr.g;
+  if (g >= gr.end) return;
   strided_copy_twiddles<Cfg>(lds, tw);
   cx<T> cur[Cfg::bpt(0)][Cfg::Seq::r[0]];
   cx<T> nxt[Cfg::bpt(0)][Cfg::Seq::r[0]];
@@ -373,10 +373,10 @@ __global__ __launch_bounds__(Cfg::WG, Cfg::OCC) void stockham_strided_prefetch_k
   auto io = strided_group<Cfg, SPLIT>(a, g, f, &live, &c0);
   auto io_n = io;
   strided_pass0_load<Cfg, BWD>(io, a, f, tid, live, cur);
-  for (; g < ngroups; g += gridDim.x) {
+  for (; g < gr.end; g += gr.stride) {
     strided_pass0_compute<Cfg>(cur, f, tid, lds);
-    const long long gn = g + gridDim.x;
-    if (gn < ngroups) {
+    const long long gn = g + gr.stride;
+    if (gn < gr.end) {
       io_n = strided_group<Cfg, SPLIT>(a, gn, f, &live_n, &c0_n);
       strided_pass0_load<Cfg, BWD>(io_n, a, f, tid, live_n, nxt);
     }
@@ -405,8 +405,8 @@ __global__ __launch_bounds__(Cfg::WG, Cfg::OCC) void stockham_strided_row_kernel
   const unsigned f = threadIdx.x % Cfg::FPW;
   const unsigned tid = threadIdx.x / Cfg::FPW;
   const cx<T>* __restrict__ tw = static_cast<const cx<T>*>(a.tw);
-  const long long ngroups = strided_ngroups<Cfg>(a);
-  for (long long g = blockIdx.x; g < ngroups; g += gridDim.x) {
+  const group_range_t gr = tiered_range(strided_ngroups<Cfg>(a), a.tier_main, a.tier_k);
+  for (long long g = gr.g; g < gr.end; g += gr.stride) {
     bool live;
     long long c0;
     long long left;
@@ -498,7 +498,8 @@ __global__ __launch_bounds__(Cfg::WG, Cfg::OCC) void stockham_strided_kernel(con
   const cx<T>* __restrict__ tw = static_cast<const cx<T>*>(a.tw);
   const long long ngroups = strided_ngroups<Cfg>(a);
   strided_copy_twiddles<Cfg>(lds, tw);
-  for (long long g = blockIdx.x; g < ngroups; g += gridDim.x) {
+  const group_range_t gr = tiered_range(ngroups, a.tier_main, a.tier_k);
+  for (long long g = gr.g; g < gr.end; g += gr.stride) {
     bool live;
     long long c0;
     long long nlive;
