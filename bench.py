@@ -197,6 +197,11 @@ def main():
 
     world, rank, local_rank = env_world()
     distributed = world > 1
+    if distributed:
+        # one node: keep gloo's and RCCL's bootstrap sockets on the loopback interface (the container hostname may not
+        # resolve to a usable interface); data never crosses these sockets -- the ranks exchange a few scalars
+        os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
+        os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
     if args.gpus != world and rank == 0:
         print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
     # one process per GPU; PFFT_BENCH_ONE_DEVICE=1 / PFFT_BENCH_BACKEND=gloo exist only to exercise the multi-rank

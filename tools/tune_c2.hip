@@ -330,7 +330,18 @@ int main() {
   CK(hipFuncSetAttribute((const void*)&dma_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
   vs.push_back({"dma (LDS-DMA prefetch into a raw image, 2 WG/CU)", 65536, (const void*)&dma_kernel<2>, [&](unsigned grid) {
     hipLaunchKernelGGL((dma_kernel<2>), dim3(grid), dim3(256), 65536, 0, in_ptr(), (cx<T>*)d_out, d_tw, nfft); }});
-  for (long long n_main : {15360ll, 14336ll, 12288ll}) for (int tail_k : {1, 2}) {
+  {  // cache policies of the production kernel (was nt chosen on constant data in round 1?)
+    using C0 = wg_cfg<float, Seq, 256, 1, 16, 1, TW_REGS, 3, 0>;
+    using Cw = wg_cfg<float, Seq, 256, 1, 16, 1, TW_REGS, 3, 0x102>;   // loads nt, stores default
+    using Cr = wg_cfg<float, Seq, 256, 1, 16, 1, TW_REGS, 3, 0x300>;   // loads default, stores nt
+    vs.push_back({"policy: default loads + default stores", C0::LDS_BYTES, (const void*)&stockham_wg_prefetch_kernel<C0, false>, [&](unsigned grid) {
+      hipLaunchKernelGGL((stockham_wg_prefetch_kernel<C0, false>), dim3(grid), dim3(256), C0::LDS_BYTES, 0, in_ptr(), (cx<T>*)d_out, d_tw, nfft, 1.0f, 0ll, 4); }});
+    vs.push_back({"policy: nt loads + default stores", Cw::LDS_BYTES, (const void*)&stockham_wg_prefetch_kernel<Cw, false>, [&](unsigned grid) {
+      hipLaunchKernelGGL((stockham_wg_prefetch_kernel<Cw, false>), dim3(grid), dim3(256), Cw::LDS_BYTES, 0, in_ptr(), (cx<T>*)d_out, d_tw, nfft, 1.0f, 0ll, 4); }});
+    vs.push_back({"policy: default loads + nt stores", Cr::LDS_BYTES, (const void*)&stockham_wg_prefetch_kernel<Cr, false>, [&](unsigned grid) {
+      hipLaunchKernelGGL((stockham_wg_prefetch_kernel<Cr, false>), dim3(grid), dim3(256), Cr::LDS_BYTES, 0, in_ptr(), (cx<T>*)d_out, d_tw, nfft, 1.0f, 0ll, 4); }});
+  }
+  for (long long n_main : {12288ll}) for (int tail_k : {2}) {
     const long long n_tail = (nfft - 4 * n_main + tail_k - 1) / tail_k;
     char nm[96]; snprintf(nm, sizeof(nm), "tail: %lld x 4 FFTs + %lld x %d", n_main, n_tail, tail_k);
     vs.push_back({nm, Cfg::LDS_BYTES, (const void*)&tail_kernel, [&, n_main, n_tail, tail_k](unsigned) {
