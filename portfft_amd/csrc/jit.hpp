@@ -46,9 +46,10 @@ bool choose_strided_params(int precision, long long n, long long inner_count, si
 /// lanes.  False when n1 has a prime factor above 31 or nothing fits the register / LDS budget.
 bool choose_rows2d_params(int precision, long long n1, long long n0, size_t max_lds, wg_params* out);
 
-/// Runtime-compiled stockham_rows2d_kernel for row length n1 (cached per device, precision, n1 and column radix)
+/// Runtime-compiled stockham_rows2d_kernel for row length n1 (cached per device, precision, n1, column radix, cache
+/// policy and storage); split: the SPLIT_COMPLEX form (rows2d_kernel::split)
 const rows2d_kernel* jit_rows2d_kernel(int precision, long long n1, long long n0, size_t max_lds, std::string* why,
-                                       int policy = 0);
+                                       int policy = 0, int split = 0);
 hipError_t jit_launch_rows2d(const rows2d_kernel* k, hipStream_t stream, unsigned grid, const rows2d_args& args,
                              int backward);
 

@@ -102,6 +102,10 @@ struct rows2d_kernel {
   /// runtime-compiled entries (jit.cpp): module functions [backward]; fn / launch are null
   hipFunction_t mfn[2];
   int policy;  // see strided_kernel::policy (0 or 1)
+  /// SPLIT_COMPLEX storage on both sides (rows2d_args::in_im / out_im); null on the cache-policy twins
+  const void* fn_split[2];
+  hipError_t (*launch_split)(hipStream_t stream, unsigned grid, const rows2d_args& args, int backward);
+  int split;  // runtime-compiled entries: mfn are the split-storage forms
 };
 const rows2d_kernel* rows2d_kernels(int* count);
 

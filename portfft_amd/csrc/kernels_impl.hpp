@@ -230,12 +230,26 @@ hipError_t launch_rows2d(hipStream_t stream, unsigned grid, const rows2d_args& a
 }
 
 template <typename Cfg>
+hipError_t launch_rows2d_split(hipStream_t stream, unsigned grid, const rows2d_args& args, int backward) {
+  if (backward) {
+    hipLaunchKernelGGL((stockham_rows2d_kernel<Cfg, true, true>), dim3(grid), dim3(Cfg::WG), Cfg::LDS_BYTES, stream, args);
+  } else {
+    hipLaunchKernelGGL((stockham_rows2d_kernel<Cfg, false, true>), dim3(grid), dim3(Cfg::WG), Cfg::LDS_BYTES, stream, args);
+  }
+  return hipGetLastError();
+}
+
+template <typename Cfg>
 rows2d_kernel make_rows2d_entry(int groups_per_wg);
 
 /// the entry for Cfg (cache policy nt) and its writer twin (default-policy stores)
 template <typename Cfg>
 void add_rows2d_entries(std::vector<rows2d_kernel>& v, int groups_per_wg) {
-  v.push_back(make_rows2d_entry<Cfg>(groups_per_wg));
+  rows2d_kernel k = make_rows2d_entry<Cfg>(groups_per_wg);
+  k.fn_split[0] = reinterpret_cast<const void*>(&stockham_rows2d_kernel<Cfg, false, true>);
+  k.fn_split[1] = reinterpret_cast<const void*>(&stockham_rows2d_kernel<Cfg, true, true>);
+  k.launch_split = &launch_rows2d_split<Cfg>;
+  v.push_back(k);
   rows2d_kernel w = make_rows2d_entry<with_aux_t<Cfg, PFA_AUX_WRITER>>(groups_per_wg);
   w.policy = 1;
   v.push_back(w);

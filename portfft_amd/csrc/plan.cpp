@@ -390,14 +390,14 @@ struct plan_t {
     return range_ok(ia) && range_ok(oa);
   }
 
-  const rows2d_kernel* find_rows2d(long long n1, long long n0, int policy) {
+  const rows2d_kernel* find_rows2d(long long n1, long long n0, int policy, bool split = false) {
     const char* e = getenv("PFFT_2D_TWO_PASS");
     if (e != nullptr && e[0] == '0') return nullptr;  // experiments / parity A-B: rows, then full-length columns
     int count = 0;
     const rows2d_kernel* k = rows2d_kernels(&count);
     for (int i = 0; i < count; ++i) {
       if (k[i].precision == desc.precision && k[i].n == n1 && k[i].lds_bytes <= max_lds && n0 % k[i].rc == 0 &&
-          n0 / k[i].rc >= 2 && k[i].policy == policy) {
+          n0 / k[i].rc >= 2 && k[i].policy == policy && (!split || k[i].launch_split != nullptr)) {
         return &k[i];
       }
     }
@@ -408,7 +408,7 @@ struct plan_t {
     const int col_fpw = strided_fpw(n0, n1);
     if (col_fpw > 0 && static_cast<size_t>(col_fpw) * elem_bytes() >= 256) return nullptr;
     std::string why;
-    const rows2d_kernel* jk = jit_rows2d_kernel(desc.precision, n1, n0, max_lds, &why, policy);
+    const rows2d_kernel* jk = jit_rows2d_kernel(desc.precision, n1, n0, max_lds, &why, policy, split ? 1 : 0);
     if (jk == nullptr) jit_note("rows2d", n1, why);
     return jk;
   }
@@ -446,15 +446,16 @@ struct plan_t {
     s.ra.twc = upload_unit_roots(n0);
     s.ra.nmat = nmat;
     s.ra.n0 = static_cast<int>(n0);
+    const bool split = desc.complex_storage == PFFT_SPLIT_COMPLEX;
     for (int d = 0; d < 2 && k->launch != nullptr; ++d) {
       if (k->lds_bytes > 48 * 1024) {
-        hip_check(hipFuncSetAttribute(k->fn[d], hipFuncAttributeMaxDynamicSharedMemorySize,
+        hip_check(hipFuncSetAttribute((split ? k->fn_split : k->fn)[d], hipFuncAttributeMaxDynamicSharedMemorySize,
                                       static_cast<int>(k->lds_bytes)),
                   "hipFuncSetAttribute");
       }
     }
-    s.grid = persistent_grid(k->launch != nullptr ? k->fn[backward] : nullptr, k->mfn[backward], k->wg, k->lds_bytes,
-                             nmat * (n0 / k->rc), k->groups_per_wg);
+    s.grid = persistent_grid(k->launch != nullptr ? (split ? k->fn_split : k->fn)[backward] : nullptr, k->mfn[backward],
+                             k->wg, k->lds_bytes, nmat * (n0 / k->rc), k->groups_per_wg);
     return s;
   }
 
@@ -596,7 +597,9 @@ struct plan_t {
                                k->groups_per_wg);
     } else if (s.rows2d != nullptr) {
       const rows2d_kernel* k = s.rows2d;
-      s.grid = persistent_grid(k->launch != nullptr ? k->fn[s.backward] : nullptr, k->mfn[s.backward], k->wg, k->lds_bytes,
+      const bool split = desc.complex_storage == PFFT_SPLIT_COMPLEX;
+      s.grid = persistent_grid(k->launch != nullptr ? (split ? k->fn_split : k->fn)[s.backward] : nullptr,
+                               k->mfn[s.backward], k->wg, k->lds_bytes,
                                count / std::max<long long>(1, s.ra.n0) * (s.ra.n0 / k->rc), k->groups_per_wg);
     }
   }
@@ -1154,7 +1157,8 @@ struct plan_t {
     // Two-pass plan for the last two dimensions (stockham_rows2d.hpp): pass 1 = whole rows + the first radix-RC
     // butterfly of the columns (contiguous rows on both sides), pass 2 = the remaining (n0 / RC)-point column FFTs
     // as a batch-interleaved transform over RC * n1 adjacent columns.  C5 (fp32 1024 x 1024 x 256): 1.57 -> 1.40 ms.
-    if (fused_from == rank && desc.complex_storage == PFFT_INTERLEAVED_COMPLEX) {
+    if (fused_from == rank) {
+      const bool split = desc.complex_storage == PFFT_SPLIT_COMPLEX;
       const long long n0 = static_cast<long long>(desc.lengths[rank - 2]);
       const long long n1 = static_cast<long long>(desc.lengths[rank - 1]);
       const long long nmat = B * (total / (n0 * n1));
@@ -1163,12 +1167,13 @@ struct plan_t {
       const size_t matrix_bytes = static_cast<size_t>(n0) * static_cast<size_t>(n1) * elem_bytes();
       // (random data, tools/perf_cache.py: 1024^2 x 16 / 32 / 64 / 256 +6 / +13 / +7 / +2 %, 512^2 x 128 +9 %; a 32 MiB
       //  batch is 18 % faster with the streamed kernels, hence the lower bound)
-      const bool cached = cache_chunk_bytes() >= matrix_bytes &&
+      // (SPLIT_COMPLEX storage: the streamed kernels, one launch per pass)
+      const bool cached = !split && cache_chunk_bytes() >= matrix_bytes &&
                           matrix_bytes * static_cast<size_t>(nmat) >= cache_chunk_bytes() / 2;
       const long long chunk_mats = cached ? std::max<long long>(1, std::min<long long>(
                                                 nmat, static_cast<long long>(cache_chunk_bytes() / matrix_bytes)))
                                           : nmat;
-      const rows2d_kernel* rk = find_rows2d(n1, n0, cached ? 1 : 0);
+      const rows2d_kernel* rk = find_rows2d(n1, n0, cached ? 1 : 0, split);
       const bool range_ok = static_cast<unsigned long long>(n0) * static_cast<unsigned long long>(n1) * elem_bytes() <
                             0xFFFFFFF0ull;
       const size_t all_bytes = static_cast<size_t>(B) * static_cast<size_t>(total) * elem_bytes();
@@ -1316,14 +1321,22 @@ struct plan_t {
     if (s.rows2d != nullptr) {
       rows2d_args a = s.ra;
       if (nb >= 0) a.nmat = nb;  // chunked: matrices [b0, b0 + nb)
-      a.in = static_cast<const char*>(in_re) + static_cast<size_t>(s.in_offset + in_shift) * elem_bytes();
+      const size_t unit = split ? sb : elem_bytes();
+      const size_t io = static_cast<size_t>(s.in_offset + in_shift) * unit;
+      const size_t oo = static_cast<size_t>(s.out_offset + out_shift) * unit;
+      a.in = static_cast<const char*>(in_re) + io;
       a.out = aliased ? static_cast<char*>(alias_scratch)  // one chunk at a time goes through the scratch
-                      : static_cast<char*>(out_re) + static_cast<size_t>(s.out_offset + out_shift) * elem_bytes();
+                      : static_cast<char*>(out_re) + oo;
+      if (split) {  // the scratch of an in-place execute holds the two planes one after the other
+        a.in_im = static_cast<const char*>(in_im) + io;
+        a.out_im = aliased ? static_cast<char*>(alias_scratch) + alias_scratch_bytes / 2 : static_cast<char*>(out_im) + oo;
+      }
       const long long groups = a.nmat * (a.n0 / s.rows2d->rc);
       unsigned grid = static_cast<unsigned>(std::min<long long>(s.grid, std::max<long long>(groups, 1)));
       grid = two_tier(grid, groups, &a.tier_main, &a.tier_k);
-      hip_check(s.rows2d->launch != nullptr ? s.rows2d->launch(stream, grid, a, s.backward)
-                                            : jit_launch_rows2d(s.rows2d, stream, grid, a, s.backward),
+      hip_check(s.rows2d->launch != nullptr
+                    ? (split ? s.rows2d->launch_split : s.rows2d->launch)(stream, grid, a, s.backward)
+                    : jit_launch_rows2d(s.rows2d, stream, grid, a, s.backward),
                 "kernel launch");
       return;
     }
@@ -1350,6 +1363,10 @@ struct plan_t {
         const size_t oo = static_cast<size_t>(s.out_addr.offset + out_shift) * sb;
         a.in = base_re(s.in_buf, true) + io;
         a.in_im = base_im(s.in_buf) + io;
+        if (aliased && s.alias_scratch == 2) {  // two-pass 2-D plan, in-place execute: pass 1 left planes in the scratch
+          a.in = alias_scratch;
+          a.in_im = static_cast<const char*>(alias_scratch) + alias_scratch_bytes / 2;
+        }
         a.out = const_cast<char*>(base_re(s.out_buf, false)) + oo;
         a.out_im = const_cast<char*>(base_im(s.out_buf)) + oo;
         hip_check(s.strided->launch != nullptr ? s.strided->launch_split(stream, grid, a, s.backward)

@@ -26,22 +26,36 @@
 namespace pfa {
 
 /// Addressing of pass 1: rows {M*a + b} of one matrix on the input side (lane-contiguous inside a row).
-template <typename T, int N, int RC, int AUX>
+/// SPLIT: separate real / imaginary planes (SPLIT_COMPLEX storage), element size one scalar.
+template <typename T, int N, int RC, int AUX, bool SPLIT = false>
 struct rows2d_io {
-  static constexpr unsigned ES = sizeof(cx<T>);
-  __amdgpu_buffer_rsrc_t rin, rout;
+  static constexpr unsigned ES = SPLIT ? sizeof(T) : sizeof(cx<T>);
+  __amdgpu_buffer_rsrc_t rin, rout, rin_im, rout_im;
   unsigned row_gap;  // bytes between the rows a and a + 1 of the group (M * N * ES)
   PFA_DEV unsigned in_off(unsigned a, unsigned j) const { return a * row_gap + j * ES; }
   static constexpr unsigned in_step(int k) { return k * ES; }
   // the passes before the last never store; the members exist so that wg_pass<> instantiates
   PFA_DEV unsigned out_off(unsigned a, unsigned j) const { return (a * N + j) * ES; }
   static constexpr unsigned out_step(int k) { return k * ES; }
-  PFA_DEV cx<T> load(unsigned voff, unsigned soff) const { return buf_load<T, AUX>(rin, voff, soff); }
-  PFA_DEV void store(cx<T> v, unsigned voff, unsigned soff) const { buf_store<T, AUX>(v, rout, voff, soff); }
+  PFA_DEV cx<T> load(unsigned voff, unsigned soff) const {
+    if constexpr (SPLIT) {
+      return {buf_load_scalar<T, AUX>(rin, voff, soff), buf_load_scalar<T, AUX>(rin_im, voff, soff)};
+    } else {
+      return buf_load<T, AUX>(rin, voff, soff);
+    }
+  }
+  PFA_DEV void store(cx<T> v, unsigned voff, unsigned soff) const {
+    if constexpr (SPLIT) {
+      buf_store_scalar<T, AUX>(v.re, rout, voff, soff);
+      buf_store_scalar<T, AUX>(v.im, rout_im, voff, soff);
+    } else {
+      buf_store<T, AUX>(v, rout, voff, soff);
+    }
+  }
 };
 
 /// Cfg: wg_cfg of the row FFT with FPW = RC (one LDS image per row of the group).
-template <typename Cfg, bool BWD>
+template <typename Cfg, bool BWD, bool SPLIT = false>
 __global__ __launch_bounds__(Cfg::WG, Cfg::OCC) void stockham_rows2d_kernel(const rows2d_args a) {
   using T = typename Cfg::T;
   using Seq = typename Cfg::Seq;
@@ -54,7 +68,8 @@ __global__ __launch_bounds__(Cfg::WG, Cfg::OCC) void stockham_rows2d_kernel(cons
   static_assert(NP >= 2 && !Cfg::STAGED, "rows2d needs a direct-I/O multi-pass row configuration");
   static_assert(NBL % Cfg::WG == 0, "last pass: every lane takes the same butterfly index in all RC rows");
   constexpr int BPTL = NBL / Cfg::WG;
-  constexpr unsigned ES = sizeof(cx<T>);
+  using IO = rows2d_io<T, N, RC, Cfg::AUX, SPLIT>;
+  constexpr unsigned ES = IO::ES;
   extern __shared__ __attribute__((aligned(16))) char pfa_smem[];
   cx<T>* images = reinterpret_cast<cx<T>*>(pfa_smem);
   const int f = threadIdx.x / Cfg::TPF;
@@ -101,13 +116,23 @@ __global__ __launch_bounds__(Cfg::WG, Cfg::OCC) void stockham_rows2d_kernel(cons
   for (long long g = gr.g; g < gr.end; g += gr.stride) {
     const long long m = g / M;
     const unsigned b = static_cast<unsigned>(g - m * M);
-    rows2d_io<T, N, RC, Cfg::AUX> io;
+    IO io;
     io.row_gap = row_gap;
     {
-      const cx<T>* ip = static_cast<const cx<T>*>(a.in) + (m * a.n0 + b) * N;
-      cx<T>* op = static_cast<cx<T>*>(a.out) + (m * a.n0 + static_cast<long long>(b) * RC) * N;
-      io.rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<cx<T>*>(ip), 0, (RC - 1) * row_gap + N * ES, 0x00020000);
+      const long long ioff = (m * a.n0 + b) * N, ooff = (m * a.n0 + static_cast<long long>(b) * RC) * N;  // elements
+      char* ip = const_cast<char*>(static_cast<const char*>(a.in)) + ioff * ES;
+      char* op = static_cast<char*>(a.out) + ooff * ES;
+      io.rin = __builtin_amdgcn_make_buffer_rsrc(ip, 0, (RC - 1) * row_gap + N * ES, 0x00020000);
       io.rout = __builtin_amdgcn_make_buffer_rsrc(op, 0, RC * N * ES, 0x00020000);
+      if constexpr (SPLIT) {
+        char* ipi = const_cast<char*>(static_cast<const char*>(a.in_im)) + ioff * ES;
+        char* opi = static_cast<char*>(a.out_im) + ooff * ES;
+        io.rin_im = __builtin_amdgcn_make_buffer_rsrc(ipi, 0, (RC - 1) * row_gap + N * ES, 0x00020000);
+        io.rout_im = __builtin_amdgcn_make_buffer_rsrc(opi, 0, RC * N * ES, 0x00020000);
+      } else {
+        io.rin_im = io.rin;
+        io.rout_im = io.rout;
+      }
     }
     const cx<T>* twp = tw;
     if constexpr (Cfg::TWM == TW_GLOBAL) asm volatile("" : "+s"(twp));

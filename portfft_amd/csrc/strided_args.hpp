@@ -49,7 +49,7 @@ struct strided_args {
 /// Launch-time arguments of the first pass of the two-pass 2-D plan (stockham_rows2d.hpp): `nmat` matrices of
 /// n0 rows x N columns (N is the kernel's row length), packed, interleaved.
 struct rows2d_args {
-  const void* in;
+  const void* in;  // interleaved complex, or the real plane of the split-storage form
   void* out;
   const void* tw;   // row twiddles (layout: radix_list::tw_off)
   const void* twc;  // W_n0^m, m in [0, n0)
@@ -57,6 +57,8 @@ struct rows2d_args {
   int n0;           // rows per matrix; n0 % RC == 0
   int tier_k;       // two-tier grid, as in strided_args
   long long tier_main;
+  const void* in_im;  // imaginary planes (split-storage form only)
+  void* out_im;
 };
 
 }  // namespace pfa

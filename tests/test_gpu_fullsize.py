@@ -74,16 +74,16 @@ def test_two_pass_2d_plan(prec):
         n = int(np.prod(dims))
         batch = 3 if n <= (1 << 18) else 2
         x, y = H.gen_fourier_data(batch, dims, dtype, seed=n % 1000)
-        for place in (0, 1):
-            d = G.make_descriptor(dims, prec, batch=batch, placement=place, fwd_scale=0.25, bwd_scale=2.0,
-                                  fwd_offset=7, bwd_offset=7 if place == 0 else 13)
+        for place, storage in ((0, 0), (1, 0), (0, 1), (1, 1)):  # storage 1: SPLIT_COMPLEX planes
+            d = G.make_descriptor(dims, prec, batch=batch, placement=place, storage=storage, fwd_scale=0.25,
+                                  bwd_scale=2.0, fwd_offset=7, bwd_offset=7 if place == 0 else 13)
             got, _ = G.transform_packed(d, pf.direction.FORWARD, x)
             for b in range(batch):
-                assert H.rel_l2(got[b], 0.25 * y[b]) <= H.REL_L2_TOL[np.dtype(dtype)], ("fwd", dims, place, b)
+                assert H.rel_l2(got[b], 0.25 * y[b]) <= H.REL_L2_TOL[np.dtype(dtype)], ("fwd", dims, place, storage, b)
             back, _ = G.transform_packed(d, pf.direction.BACKWARD, y)
             for b in range(batch):
                 assert H.rel_l2(back[b], 2.0 * n * x[b].astype(np.complex128)) <= H.REL_L2_TOL[np.dtype(dtype)], \
-                    ("bwd", dims, place, b)
+                    ("bwd", dims, place, storage, b)
         # the plan it replaces gives the same answer up to rounding
         d = G.make_descriptor(dims, prec, batch=batch)
         got, _ = G.transform_packed(d, pf.direction.FORWARD, x)
@@ -100,9 +100,12 @@ def test_two_pass_2d_plan(prec):
         plan.compute_forward(buf).wait()
         assert H.rel_l2(buf.cpu().numpy().reshape(batch, -1), y.reshape(batch, -1)) <= H.REL_L2_TOL[np.dtype(dtype)], \
             ("aliased", dims)
-    info = G.make_descriptor([1024, 1024], prec, batch=2).commit().info()
-    assert info.dims[1].tier == 1 and info.dims[0].tier == 1
-    assert int(np.prod(list(info.dims[0].factors)[:info.dims[0].n_factors])) == 1024
+    for storage in (0, 1):
+        plan = G.make_descriptor([1024, 1024], prec, batch=2, storage=storage).commit()
+        info = plan.info()
+        assert info.dims[1].tier == 1 and info.dims[0].tier == 1
+        assert int(np.prod(list(info.dims[0].factors)[:info.dims[0].n_factors])) == 1024
+        assert info.dims[0].factors[0] in (2, 4, 8), storage  # the column radix fused into pass 1
 
 
 def _big_case(n, batch, prec="f32", layout_in="P", layout_out="P", split=False):
