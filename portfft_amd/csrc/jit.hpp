@@ -44,12 +44,14 @@ bool choose_strided_params(int precision, long long n, long long inner_count, si
 /// rows: the column radix RC taken in that pass (= rows per work-group = wg_params::fpw; n0 % RC == 0), the row
 /// radices (the last one is fused with the column radix into one 2-D butterfly: (n1 / r_last) % wg == 0) and the
 /// lanes.  False when n1 has a prime factor above 31 or nothing fits the register / LDS budget.
-bool choose_rows2d_params(int precision, long long n1, long long n0, size_t max_lds, wg_params* out);
+/// rc_mask: the column radices (8 | 4 | 2) the caller can follow with a single column pass of length n0 / rc.
+bool choose_rows2d_params(int precision, long long n1, long long n0, size_t max_lds, wg_params* out,
+                          int rc_mask = 8 | 4 | 2);
 
 /// Runtime-compiled stockham_rows2d_kernel for row length n1 (cached per device, precision, n1, column radix, cache
 /// policy and storage); split: the SPLIT_COMPLEX form (rows2d_kernel::split)
 const rows2d_kernel* jit_rows2d_kernel(int precision, long long n1, long long n0, size_t max_lds, std::string* why,
-                                       int policy = 0, int split = 0);
+                                       int policy = 0, int split = 0, int rc_mask = 8 | 4 | 2);
 hipError_t jit_launch_rows2d(const rows2d_kernel* k, hipStream_t stream, unsigned grid, const rows2d_args& args,
                              int backward);
 

@@ -407,8 +407,21 @@ struct plan_t {
     // runtime-planned first pass does not beat rows + columns)
     const int col_fpw = strided_fpw(n0, n1);
     if (col_fpw > 0 && static_cast<size_t>(col_fpw) * elem_bytes() >= 256) return nullptr;
+    // column radices whose remaining n0 / rc points one full-width column pass can take (plan_1d would otherwise
+    // answer with two column stages through scratch, and the two-pass plan would be dropped: 3000 x 1000 with rc 2);
+    // failing that, any radix with a column kernel at all
+    const int full_fpw = desc.precision == PFFT_PRECISION_F64 ? 8 : 16;
+    int wide_mask = 0, any_mask = 0;
+    for (int rc : {8, 4, 2}) {
+      if (n0 % rc != 0 || n0 / rc < 2) continue;
+      const int fpw = strided_fpw(n0 / rc, rc * n1);
+      if (fpw >= full_fpw) wide_mask |= rc;
+      if (fpw > 0) any_mask |= rc;
+    }
+    const int rc_mask = wide_mask != 0 ? wide_mask : any_mask;
+    if (rc_mask == 0) return nullptr;
     std::string why;
-    const rows2d_kernel* jk = jit_rows2d_kernel(desc.precision, n1, n0, max_lds, &why, policy, split ? 1 : 0);
+    const rows2d_kernel* jk = jit_rows2d_kernel(desc.precision, n1, n0, max_lds, &why, policy, split ? 1 : 0, rc_mask);
     if (jk == nullptr) jit_note("rows2d", n1, why);
     return jk;
   }

@@ -91,6 +91,10 @@ int main(int argc, char** argv) {
       }
     }
     EXPECT(accepted > 500, "rows2d planner accepts %d (n1, n0) pairs", accepted);
+    // the caller's mask of usable column radices is honoured (3000 x 1000: radix 2 would leave 1500-point columns)
+    pfa::wg_params q;
+    EXPECT(pfa::choose_rows2d_params(prec, 1000, 3000, max_lds, &q, 4) && q.fpw == 4, "rows2d 3000 x 1000, mask 4");
+    EXPECT(!pfa::choose_rows2d_params(prec, 1000, 3000, max_lds, &q, 8), "rows2d 3000 x 1000: no radix-8 plan");
   }
   if (argc > 1 && std::string(argv[1]) == "compile") {
     struct { int prec; long long n; int kind; } cases[] = {{0, 1200, 0}, {1, 625, 1}, {0, 30, 0}, {0, 120, 2}, {1, 250, 3},

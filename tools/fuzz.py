@@ -34,7 +34,7 @@ def main():
         if big2d:
             rank = rng.choice([2, 2, 3])
             last = rng.choice([256, 512, 1024, 2048, 1000, 768])
-            mid = rng.choice([8, 16, 24, 40, 64, 96, 128, 250, 256, 512, 1024])
+            mid = rng.choice([8, 16, 24, 40, 64, 96, 128, 250, 256, 512, 1024, 1500, 3000, 2560])
             dims = ([rng.choice([2, 3, 5, 8])] if rank == 3 else []) + [mid, last]
         elif rank == 1:
             dims = [smooth(rng, rng.choice([2, 20, 300, 3000]), rng.choice([64, 2000, 20000, 200000]))]
