@@ -3,6 +3,8 @@
 #include <cstdlib>
 #include <vector>
 
+#include <hip/hip_ext.h>
+
 #include "../../include/portfft_amd.h"
 #include "generic_kernel.hpp"
 #include "kernels.hpp"
@@ -159,21 +161,37 @@ spec_kernel make_spec_entry_xlane(int groups_per_wg = 1) {
   return k;
 }
 
+/// Launch with one by-value argument struct.  args.any_order: the packet carries no barrier bit
+/// (hipExtAnyOrderLaunch), so the work-groups may start while the previous launch of the stream is still draining;
+/// the plan sets it only for launches that are independent of everything that can still be in flight (plan.cpp,
+/// chunk overlap).
+template <typename K, typename A>
+inline void pfa_launch(K kernel, dim3 g, dim3 b, size_t lds, hipStream_t stream, const A& args) {
+  if (args.any_order != 0) {
+    A copy = args;
+    void* p[] = {&copy};
+    (void)hipExtLaunchKernel(reinterpret_cast<const void*>(kernel), g, b, p, lds, stream, nullptr, nullptr,
+                             hipExtAnyOrderLaunch);
+  } else {
+    hipLaunchKernelGGL(kernel, g, b, lds, stream, args);
+  }
+}
+
 template <typename Cfg>
 hipError_t launch_strided(hipStream_t stream, unsigned grid, const strided_args& args, int backward, int stw) {
   constexpr size_t lds = strided_lds_bytes<Cfg>();
   const dim3 g(grid), b(Cfg::WG);
   if (backward) {
     if (stw) {
-      hipLaunchKernelGGL((stockham_strided_kernel<Cfg, true, true>), g, b, lds, stream, args);
+      pfa_launch(&stockham_strided_kernel<Cfg, true, true>, g, b, lds, stream, args);
     } else {
-      hipLaunchKernelGGL((stockham_strided_kernel<Cfg, true, false>), g, b, lds, stream, args);
+      pfa_launch(&stockham_strided_kernel<Cfg, true, false>, g, b, lds, stream, args);
     }
   } else {
     if (stw) {
-      hipLaunchKernelGGL((stockham_strided_kernel<Cfg, false, true>), g, b, lds, stream, args);
+      pfa_launch(&stockham_strided_kernel<Cfg, false, true>, g, b, lds, stream, args);
     } else {
-      hipLaunchKernelGGL((stockham_strided_kernel<Cfg, false, false>), g, b, lds, stream, args);
+      pfa_launch(&stockham_strided_kernel<Cfg, false, false>, g, b, lds, stream, args);
     }
   }
   return hipGetLastError();
@@ -185,15 +203,15 @@ hipError_t launch_strided_prefetch(hipStream_t stream, unsigned grid, const stri
   const dim3 g(grid), b(Cfg::WG);
   if (backward) {
     if (stw) {
-      hipLaunchKernelGGL((stockham_strided_prefetch_kernel<Cfg, true, true>), g, b, lds, stream, args);
+      pfa_launch(&stockham_strided_prefetch_kernel<Cfg, true, true>, g, b, lds, stream, args);
     } else {
-      hipLaunchKernelGGL((stockham_strided_prefetch_kernel<Cfg, true, false>), g, b, lds, stream, args);
+      pfa_launch(&stockham_strided_prefetch_kernel<Cfg, true, false>, g, b, lds, stream, args);
     }
   } else {
     if (stw) {
-      hipLaunchKernelGGL((stockham_strided_prefetch_kernel<Cfg, false, true>), g, b, lds, stream, args);
+      pfa_launch(&stockham_strided_prefetch_kernel<Cfg, false, true>, g, b, lds, stream, args);
     } else {
-      hipLaunchKernelGGL((stockham_strided_prefetch_kernel<Cfg, false, false>), g, b, lds, stream, args);
+      pfa_launch(&stockham_strided_prefetch_kernel<Cfg, false, false>, g, b, lds, stream, args);
     }
   }
   return hipGetLastError();
@@ -222,9 +240,9 @@ hipError_t launch_strided_row(hipStream_t stream, unsigned grid, const strided_a
 template <typename Cfg>
 hipError_t launch_rows2d(hipStream_t stream, unsigned grid, const rows2d_args& args, int backward) {
   if (backward) {
-    hipLaunchKernelGGL((stockham_rows2d_kernel<Cfg, true>), dim3(grid), dim3(Cfg::WG), Cfg::LDS_BYTES, stream, args);
+    pfa_launch(&stockham_rows2d_kernel<Cfg, true>, dim3(grid), dim3(Cfg::WG), Cfg::LDS_BYTES, stream, args);
   } else {
-    hipLaunchKernelGGL((stockham_rows2d_kernel<Cfg, false>), dim3(grid), dim3(Cfg::WG), Cfg::LDS_BYTES, stream, args);
+    pfa_launch(&stockham_rows2d_kernel<Cfg, false>, dim3(grid), dim3(Cfg::WG), Cfg::LDS_BYTES, stream, args);
   }
   return hipGetLastError();
 }
@@ -364,11 +382,11 @@ hipError_t launch_strided_writer(hipStream_t stream, unsigned grid, const stride
   constexpr size_t lds = strided_lds_bytes<Cfg>();
   const dim3 g(grid), b(Cfg::WG);
   if constexpr (PREFETCH) {
-    if (backward) hipLaunchKernelGGL((stockham_strided_prefetch_kernel<Cfg, true, true>), g, b, lds, stream, args);
-    else hipLaunchKernelGGL((stockham_strided_prefetch_kernel<Cfg, false, true>), g, b, lds, stream, args);
+    if (backward) pfa_launch(&stockham_strided_prefetch_kernel<Cfg, true, true>, g, b, lds, stream, args);
+    else pfa_launch(&stockham_strided_prefetch_kernel<Cfg, false, true>, g, b, lds, stream, args);
   } else {
-    if (backward) hipLaunchKernelGGL((stockham_strided_kernel<Cfg, true, true>), g, b, lds, stream, args);
-    else hipLaunchKernelGGL((stockham_strided_kernel<Cfg, false, true>), g, b, lds, stream, args);
+    if (backward) pfa_launch(&stockham_strided_kernel<Cfg, true, true>, g, b, lds, stream, args);
+    else pfa_launch(&stockham_strided_kernel<Cfg, false, true>, g, b, lds, stream, args);
   }
   return hipGetLastError();
 }
@@ -378,11 +396,11 @@ hipError_t launch_strided_reader(hipStream_t stream, unsigned grid, const stride
   constexpr size_t lds = strided_lds_bytes<Cfg>();
   const dim3 g(grid), b(Cfg::WG);
   if constexpr (PREFETCH) {
-    if (backward) hipLaunchKernelGGL((stockham_strided_prefetch_kernel<Cfg, true, false>), g, b, lds, stream, args);
-    else hipLaunchKernelGGL((stockham_strided_prefetch_kernel<Cfg, false, false>), g, b, lds, stream, args);
+    if (backward) pfa_launch(&stockham_strided_prefetch_kernel<Cfg, true, false>, g, b, lds, stream, args);
+    else pfa_launch(&stockham_strided_prefetch_kernel<Cfg, false, false>, g, b, lds, stream, args);
   } else {
-    if (backward) hipLaunchKernelGGL((stockham_strided_kernel<Cfg, true, false>), g, b, lds, stream, args);
-    else hipLaunchKernelGGL((stockham_strided_kernel<Cfg, false, false>), g, b, lds, stream, args);
+    if (backward) pfa_launch(&stockham_strided_kernel<Cfg, true, false>, g, b, lds, stream, args);
+    else pfa_launch(&stockham_strided_kernel<Cfg, false, false>, g, b, lds, stream, args);
   }
   return hipGetLastError();
 }

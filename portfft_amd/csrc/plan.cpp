@@ -210,12 +210,39 @@ struct plan_t {
   int tail_policy = 0;              // cache policy plan_1d gives the strided stage it plans (two-pass 2-D plan: reader)
   int n_chunk_groups = 0;
   pfft_plan_info_t info{};
+  // chunk overlap (execute): the second launch of chunk c runs on aux_stream while the first launch of chunk c + 1
+  // runs on the plan's stream, so the tail of one fills with the head of the other
+  hipStream_t aux_stream = nullptr;
+  std::vector<hipEvent_t> chunk_events;
+  bool on_aux = false;              // run_stage launches on aux_stream
+  bool any_order = false;           // run_stage launches without the in-order barrier (strided / rows2d stages)
+  size_t scratch_shift = 0;         // bytes added to the scratch base (the half of a double-buffered scratch in use)
+  size_t overlap_scratch_half = 0;  // bytes of one half when the chunks of a four-step plan double-buffer the scratch
+
+  /// How consecutive chunks of a two-launch plan overlap (PFFT_CHUNK_OVERLAP):
+  /// 0 not at all: every launch in order on the plan's stream;
+  /// 1 second launches on a second stream behind events (measured 20 % slower: profiles/r2_notes.md);
+  /// 2 (default) the first launch of chunk c + 1 is enqueued without the in-order barrier (hipExtAnyOrderLaunch), so
+  ///   it fills the tail of the second launch of chunk c.  A runtime that ignores the flag runs them in order.
+  static int chunk_overlap_mode() {
+    const char* e = getenv("PFFT_CHUNK_OVERLAP");
+    if (e == nullptr || e[0] == '\0') return 2;  // measured: C3 (with cache-sized chunks) +3.7 %, C5 / ref65536 +1.2 %
+    return std::atoi(e);
+  }
+  const int overlap_mode = chunk_overlap_mode();  // fixed at commit
+  bool chunk_overlap_enabled() const { return overlap_mode != 0; }
+
 
   int scalar_bytes() const { return desc.precision == PFFT_PRECISION_F64 ? 8 : 4; }
   size_t elem_bytes() const { return 2 * static_cast<size_t>(scalar_bytes()); }
 
   ~plan_t() {
     (void)hipStreamSynchronize(stream);
+    if (aux_stream != nullptr) {
+      (void)hipStreamSynchronize(aux_stream);
+      (void)hipStreamDestroy(aux_stream);
+    }
+    for (hipEvent_t e : chunk_events) (void)hipEventDestroy(e);
     if (scratch != nullptr) (void)hipFree(scratch);
     if (alias_scratch != nullptr) (void)hipFree(alias_scratch);
   }
@@ -997,13 +1024,21 @@ struct plan_t {
       const strided_kernel* pa = find_strided(n1);
       const strided_kernel* pb = find_strided(n2);
       const size_t big = 80 * 1024;
-      if ((pa != nullptr && pa->lds_bytes > big) || (pb != nullptr && pb->lds_bytes > big)) cached = false;
+      // (with the chunks overlapped -- chunk_overlap_mode() 2 -- those plans gain too: C3 1.652 -> 1.592 ms)
+      if (((pa != nullptr && pa->lds_bytes > big) || (pb != nullptr && pb->lds_bytes > big)) &&
+          overlap_mode != 2) {
+        cached = false;
+      }
     }
     long long chunk = static_cast<long long>((cached ? cache_chunk_bytes() : global_chunk_bytes()) / per_transform);
     chunk = std::max<long long>(1, std::min<long long>(chunk, count));
     const int group_id = n_chunk_groups++;
     const size_t need = static_cast<size_t>(chunk) * per_transform;
     scratch_bytes = std::max(scratch_bytes, need);
+    if (chunk < count && chunk_overlap_enabled()) {  // consecutive chunks overlap: two halves of the scratch alternate
+      overlap_scratch_half = std::max(overlap_scratch_half, need);
+      scratch_bytes = std::max(scratch_bytes, 2 * overlap_scratch_half);
+    }
     // stage A: for every batch b and column c: length-n1 FFT over rows (stride n2), x W_n^{k1*c}, same layout out
     addressing a_in{ia.offset, n2, 1, n};
     addressing a_out{0, n2, 1, n};
@@ -1291,7 +1326,8 @@ struct plan_t {
       : desc(o.desc), stream(o.stream), device(o.device), n_cus(o.n_cus), max_lds(o.max_lds), tables(o.tables),
         scratch_bytes(o.scratch_bytes), twiddle_bytes(o.twiddle_bytes), alias_scratch_bytes(o.alias_scratch_bytes),
         two_pass_chunk_bytes(o.two_pass_chunk_bytes),
-        n_chunk_groups(o.n_chunk_groups), info(o.info) {
+        n_chunk_groups(o.n_chunk_groups), info(o.info), overlap_scratch_half(o.overlap_scratch_half),
+        overlap_mode(o.overlap_mode) {
     stages[0] = o.stages[0];
     stages[1] = o.stages[1];
     device_guard dg(device);
@@ -1316,6 +1352,8 @@ struct plan_t {
     const long long count = nb < 0 ? s.count : nb * s.ffts_per_batch;
     const size_t sb = static_cast<size_t>(scalar_bytes());
     const bool split = desc.complex_storage == PFFT_SPLIT_COMPLEX;
+    hipStream_t stream = on_aux ? aux_stream : this->stream;
+    char* const scratch = this->scratch == nullptr ? nullptr : static_cast<char*>(this->scratch) + scratch_shift;
     // resolve buffers: user buffers follow the descriptor's storage, scratch is always interleaved
     auto base_re = [&](int buf, bool is_in) -> const char* {
       if (buf == BUF_SCRATCH) return static_cast<const char*>(scratch);
@@ -1333,6 +1371,7 @@ struct plan_t {
     if (aliased) ensure_alias_scratch();
     if (s.rows2d != nullptr) {
       rows2d_args a = s.ra;
+      a.any_order = any_order ? 1 : 0;
       if (nb >= 0) a.nmat = nb;  // chunked: matrices [b0, b0 + nb)
       const size_t unit = split ? sb : elem_bytes();
       const size_t io = static_cast<size_t>(s.in_offset + in_shift) * unit;
@@ -1355,6 +1394,7 @@ struct plan_t {
     }
     if (s.strided != nullptr) {
       strided_args a = s.sa;
+      a.any_order = any_order ? 1 : 0;
       a.total = count;
       const long long groups = strided_groups(count, a.inner, s.strided->fpw);
       unsigned grid = static_cast<unsigned>(std::min<long long>(s.grid, std::max<long long>(groups, 1)));
@@ -1460,6 +1500,70 @@ struct plan_t {
     hip_check(e, "kernel launch");
   }
 
+  /// a two-launch chunk group with several chunks whose chunks do not share an intermediate buffer
+  bool overlappable(const std::vector<stage>& st, size_t i, size_t j, bool several_chunks, bool aliased) const {
+    if (!chunk_overlap_enabled() || j - i != 2 || !several_chunks) return false;
+    hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(stream, &capturing) != hipSuccess || capturing != hipStreamCaptureStatusNone) {
+      return false;  // a captured execute is a plain chain of kernel nodes
+    }
+    const stage& a = st[i];
+    const stage& b = st[i + 1];
+    if (aliased && (a.alias_scratch != 0 || b.alias_scratch != 0)) return false;  // one scratch chunk for all chunks
+    const bool uses_scratch = a.in_buf == BUF_SCRATCH || a.out_buf == BUF_SCRATCH || b.in_buf == BUF_SCRATCH ||
+                              b.out_buf == BUF_SCRATCH;
+    return !uses_scratch || overlap_scratch_half > 0;
+  }
+
+  /// chunk c: first launch on the plan's stream, second launch on aux_stream behind an event; the plan's stream joins
+  /// at the end.  The scratch (four-step plans) alternates between its two halves.
+  void run_chunks_overlapped(const stage& a, const stage& b, long long batches, long long chunk_batches,
+                             const void* in_re, const void* in_im, void* out_re, void* out_im) {
+    if (overlap_mode == 2) {
+      // Every second launch keeps its barrier, so when the barrier-free first launch of chunk c starts, only the
+      // second launch of chunk c - 1 can still be running: other matrices, the other half of the scratch.
+      size_t c = 0;
+      for (long long b0 = 0; b0 < batches; b0 += chunk_batches, ++c) {
+        const long long nb = std::min(chunk_batches, batches - b0);
+        scratch_shift = (c & 1) * overlap_scratch_half;
+        any_order = c > 0;
+        run_stage(a, in_re, in_im, out_re, out_im, b0, nb);
+        any_order = false;
+        run_stage(b, in_re, in_im, out_re, out_im, b0, nb);
+      }
+      scratch_shift = 0;
+      return;
+    }
+    if (aux_stream == nullptr) {
+      hip_check(hipStreamCreateWithFlags(&aux_stream, hipStreamNonBlocking), "hipStreamCreate");
+    }
+    const size_t n_chunks = static_cast<size_t>((batches + chunk_batches - 1) / chunk_batches);
+    while (chunk_events.size() < 2 * n_chunks) {  // [c]: first launch of chunk c done, [n_chunks + c]: second launch
+      hipEvent_t ev = nullptr;
+      hip_check(hipEventCreateWithFlags(&ev, hipEventDisableTiming), "hipEventCreate");
+      chunk_events.push_back(ev);
+    }
+    size_t c = 0;
+    for (long long b0 = 0; b0 < batches; b0 += chunk_batches, ++c) {
+      const long long nb = std::min(chunk_batches, batches - b0);
+      scratch_shift = (c & 1) * overlap_scratch_half;
+      if (c >= 2 && overlap_scratch_half > 0) {  // this half of the scratch was last read by chunk c - 2
+        hip_check(hipStreamWaitEvent(stream, chunk_events[n_chunks + c - 2], 0), "hipStreamWaitEvent");
+      }
+      run_stage(a, in_re, in_im, out_re, out_im, b0, nb);
+      hip_check(hipEventRecord(chunk_events[c], stream), "hipEventRecord");
+      hip_check(hipStreamWaitEvent(aux_stream, chunk_events[c], 0), "hipStreamWaitEvent");
+      on_aux = true;
+      run_stage(b, in_re, in_im, out_re, out_im, b0, nb);
+      on_aux = false;
+      if (c + 1 == n_chunks || overlap_scratch_half > 0) {
+        hip_check(hipEventRecord(chunk_events[n_chunks + c], aux_stream), "hipEventRecord");
+      }
+    }
+    scratch_shift = 0;
+    hip_check(hipStreamWaitEvent(stream, chunk_events[2 * n_chunks - 1], 0), "hipStreamWaitEvent");
+  }
+
   void execute(int direction, const void* in_re, const void* in_im, void* out_re, void* out_im) {
     if (direction != PFFT_FORWARD && direction != PFFT_BACKWARD) {
       fail(PFFT_INVALID_CONFIGURATION, "Invalid direction ", direction);
@@ -1477,6 +1581,11 @@ struct plan_t {
       while (j < st.size() && st[j].chunk_group == st[i].chunk_group) ++j;
       const long long batches = st[i].count / st[i].ffts_per_batch;
       const long long chunk_batches = std::max<long long>(1, st[i].chunk_batches);
+      if (overlappable(st, i, j, batches > chunk_batches, in_re == out_re)) {
+        run_chunks_overlapped(st[i], st[i + 1], batches, chunk_batches, in_re, in_im, out_re, out_im);
+        i = j;
+        continue;
+      }
       for (long long b0 = 0; b0 < batches; b0 += chunk_batches) {
         const long long nb = std::min(chunk_batches, batches - b0);
         for (size_t k = i; k < j; ++k) run_stage(st[k], in_re, in_im, out_re, out_im, b0, nb);

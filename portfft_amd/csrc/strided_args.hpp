@@ -43,6 +43,7 @@ struct strided_args {
   /// launch balance it at a finer grain (see stockham_wg_prefetch_kernel).
   long long tier_main;
   int tier_k;
+  int any_order;  // host side only: launch without the in-order barrier (pfa_launch)
 };
 
 
@@ -59,6 +60,7 @@ struct rows2d_args {
   long long tier_main;
   const void* in_im;  // imaginary planes (split-storage form only)
   void* out_im;
+  int any_order;  // host side only: launch without the in-order barrier (pfa_launch)
 };
 
 }  // namespace pfa

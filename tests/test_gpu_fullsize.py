@@ -271,7 +271,7 @@ def test_cache_sized_chunks_and_policy_twins():
 
     tol = {"f32": 2e-6, "f64": 5e-15}
     for lengths, batch, prec in (([1024, 1024], 37, "f32"), ([512, 2048], 70, "f32"), ([65536], 700, "f32"),
-                                 ([1 << 18], 150, "f64"), ([1 << 20], 40, "f32")):
+                                 ([1 << 18], 150, "f64"), ([1 << 20], 40, "f32"), ([1 << 20], 37, "f64")):
         n = int(np.prod(lengths))
         for placement in (1, 0):
             x, y, plan = run_case(lengths, batch, prec, placement)
@@ -281,6 +281,13 @@ def test_cache_sized_chunks_and_policy_twins():
             # same kernels, same arithmetic, other cache policy and launch structure: bit-identical
             _, y0, _ = run_case(lengths, batch, prec, placement, {"PFFT_CACHE_CHUNK_MIB": "0"})
             assert torch.equal(y, y0), (lengths, batch, prec, placement)
+            # consecutive chunks overlap by default (the first launch of chunk c + 1 carries no in-order barrier and
+            # the scratch of the four-step plans is double-buffered): strictly in order and with a second stream the
+            # results are the same bits
+            for mode in ("0", "1"):
+                _, y1, _ = run_case(lengths, batch, prec, placement, {"PFFT_CHUNK_OVERLAP": mode})
+                assert torch.equal(y, y1), (lengths, batch, prec, placement, "overlap mode", mode)
+                del y1
             # backward over the chunked plan restores the input
             z = torch.empty_like(x)
             plan.compute_backward(y, z).wait()
@@ -288,3 +295,20 @@ def test_cache_sized_chunks_and_policy_twins():
             assert err <= tol[prec], (lengths, batch, prec, placement, err)
             del y, y0, z
         torch.cuda.empty_cache()
+    # a chunked execute captured into a HIP graph (in-order chain of kernel nodes) and replayed on new data
+    lengths, batch, prec = [1024, 1024], 37, "f32"
+    n = int(np.prod(lengths))
+    x, y, plan = run_case(lengths, batch, prec, 1)
+    s1 = torch.cuda.Stream()
+    plan_s = G.make_descriptor(lengths, prec, batch=batch).commit(s1)
+    xin = torch.zeros_like(x)
+    out = torch.empty_like(x)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=s1):
+        plan_s.compute_forward(xin, out, want_event=False)
+    torch.cuda.synchronize()
+    xin.copy_(x)
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, y), "graph replay of a chunked plan"
