@@ -154,6 +154,8 @@ def spawn_ranks(args):
            "--steps", str(args.steps), "--warmup", str(args.warmup), "--config", args.config]
     if args.no_cpu_baseline:
         cmd.append("--no-cpu-baseline")
+    if args.manual is not None:
+        cmd += ["--manual", args.manual, "--precision", args.precision]
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
@@ -175,13 +177,29 @@ def main():
     ap.add_argument("--config", default="c2", choices=sorted(WORKLOADS),
                     help="c2 (default, the headline line); c3 / c5: the other single-GPU configs of BASELINE.json; "
                          "ref16 / ref256 / ref4096 / ref65536: the reference's own bench set")
+    ap.add_argument("--manual", metavar="KEY=VALUE,...",
+                    help="any descriptor, in the grammar of the reference's bench_manual_float / bench_manual_double "
+                         "(register_manual_bench.hpp), e.g. d=cpx,n=1024x1024,b=64,s=split,p=ip; overrides --config")
+    ap.add_argument("--precision", default="float", choices=["float", "double"],
+                    help="with --manual: bench_manual_float or bench_manual_double")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args))
 
     import numpy as np
 
-    lengths, batch_per_gpu, prec, name, launches = WORKLOADS[args.config]
+    manual_desc = None
+    if args.manual is not None:
+        from portfft_amd import manual_bench
+        try:
+            manual_desc = manual_bench.descriptor_from_string(args.manual, "f64" if args.precision == "double" else "f32")
+        except manual_bench.bench_error as e:
+            sys.exit("%s\n%s" % (e, manual_bench.help_text("bench.py")))
+        args.config = "manual"
+        lengths, batch_per_gpu, prec = manual_desc.lengths, manual_desc.number_of_transforms, manual_desc.scalar
+        name, launches = "manual: %s:%s" % (args.precision, args.manual), None
+    else:
+        lengths, batch_per_gpu, prec, name, launches = WORKLOADS[args.config]
     n = int(np.prod(lengths))
     # the CPU baseline runs first, before this process initialises the GPU (its NumPy leg forks a worker pool)
     cpu = None
@@ -215,26 +233,51 @@ def main():
     lo, hi = shard_range(batch_per_gpu * world, world, rank)
     assert hi - lo == batch_per_gpu
 
-    # synthetic inputs resident in HBM: uniform(-1, 1) real and imaginary parts, two buffers rotated per step
-    gen = torch.Generator(device=dev).manual_seed(1234 + rank)
-    inputs = []
-    for _ in range(2):
-        x = torch.empty(batch_per_gpu * n, dtype=cdt, device=dev)
-        torch.view_as_real(x).uniform_(-1, 1, generator=gen)
-        inputs.append(x)
-    out = torch.empty(batch_per_gpu * n, dtype=cdt, device=dev)
+    if manual_desc is not None:
+        desc = manual_desc
+    else:
+        desc = pf.descriptor(lengths, prec)
+        desc.number_of_transforms = batch_per_gpu
+    split = desc.complex_storage == pf.complex_storage.SPLIT_COMPLEX
+    in_place = desc.placement == pf.placement.IN_PLACE
+    n_in, n_out = desc.get_input_count(pf.direction.FORWARD), desc.get_output_count(pf.direction.FORWARD)
+    if in_place:
+        n_in = n_out = max(n_in, n_out)
+    rdt = torch.float32 if prec == "f32" else torch.float64
 
-    desc = pf.descriptor(lengths, prec)
-    desc.number_of_transforms = batch_per_gpu
+    # synthetic inputs resident in HBM: uniform(-1, 1) real and imaginary parts, two buffers rotated per step
+    # (split storage: two planes per buffer; an in-place descriptor transforms the rotated buffers themselves)
+    gen = torch.Generator(device=dev).manual_seed(1234 + rank)
+
+    def buffer(count, fill):
+        if split:
+            planes = [torch.empty(count, dtype=rdt, device=dev) for _ in range(2)]
+            if fill:
+                for p in planes:
+                    p.uniform_(-1, 1, generator=gen)
+            return planes
+        x = torch.empty(count, dtype=cdt, device=dev)
+        if fill:
+            torch.view_as_real(x).uniform_(-1, 1, generator=gen)
+        return [x]
+
+    inputs = [buffer(n_in, True) for _ in range(2)]
+    out = None if in_place else buffer(n_out, False)
     plan = desc.commit()  # torch's current stream
 
+    def step(k):
+        if in_place:
+            plan.compute_forward(*inputs[k % 2], want_event=False)
+        else:
+            plan.compute_forward(*inputs[k % 2], *out, want_event=False)
+
     for w in range(args.warmup):
-        plan.compute_forward(inputs[w % 2], out, want_event=False)
+        step(w)
     # ---- the timed region: exactly `steps` steps, wall clock, nothing but the launches inside ----
     pg.barrier()
     t0 = time.perf_counter()
     for k in range(args.steps):
-        plan.compute_forward(inputs[k % 2], out, want_event=False)
+        step(k)
     torch.cuda.synchronize()
     my_elapsed = time.perf_counter() - t0
     pg.barrier()
@@ -246,19 +289,43 @@ def main():
     stops = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
     for k in range(args.steps):
         starts[k].record()
-        plan.compute_forward(inputs[k % 2], out, want_event=False)
+        step(k)
         stops[k].record()
     torch.cuda.synchronize()
     kernel_ms = [s.elapsed_time(e) for s, e in zip(starts, stops)]
     avg_kernel_ms = sum(kernel_ms) / len(kernel_ms)
 
-    # parity spot check of the timed output (last step's input) against NumPy
-    last_in = inputs[(args.steps - 1) % 2].view([batch_per_gpu] + lengths)
-    got_all = out.view([batch_per_gpu] + lengths)
+    # parity spot check of the timed output (last step's input) against NumPy, through the descriptor's layout
+    # (an in-place descriptor has consumed its inputs: one more execute on a fresh copy)
+    def pick(buf, index):  # elements `index` of a buffer, as complex on the host
+        if split:
+            return (buf[0][index].cpu().numpy() + 1j * buf[1][index].cpu().numpy())
+        return buf[0][index].cpu().numpy()
+
+    if in_place:
+        fresh = buffer(n_in, True)
+        x_buf = [p.clone() for p in fresh]
+        plan.compute_forward(*fresh, want_event=False)
+        torch.cuda.synchronize()
+        y_buf = fresh
+    else:
+        x_buf, y_buf = inputs[(args.steps - 1) % 2], out
+    inv = pf.inv(pf.direction.FORWARD)
+
+    def element_index(d):
+        idx = np.zeros(lengths, dtype=np.int64)
+        for axis, stride in enumerate(desc.get_strides(d)):
+            shape = [1] * len(lengths)
+            shape[axis] = lengths[axis]
+            idx = idx + np.arange(lengths[axis], dtype=np.int64).reshape(shape) * stride
+        return torch.from_numpy(idx).to(dev)
+
+    idx_in, idx_out = element_index(pf.direction.FORWARD), element_index(inv)
     worst = 0.0
     for b in sorted({0, 777 % batch_per_gpu, (batch_per_gpu * 5) // 8, batch_per_gpu - 1}):
-        ref = np.fft.fftn(last_in[b].cpu().numpy().astype(np.complex128))
-        got = got_all[b].cpu().numpy()
+        xin = pick(x_buf, idx_in + (desc.get_offset(pf.direction.FORWARD) + b * desc.get_distance(pf.direction.FORWARD)))
+        ref = desc.forward_scale * np.fft.fftn(xin.astype(np.complex128))
+        got = pick(y_buf, idx_out + (desc.get_offset(inv) + b * desc.get_distance(inv)))
         worst = max(worst, float(np.linalg.norm(got - ref) / np.linalg.norm(ref)))
     assert worst < 1e-4, "parity check failed: rel-L2 %g" % worst
 
@@ -281,7 +348,9 @@ def main():
             "vs_baseline": None,
             "dtype": prec,
             "data": "synthetic",
-            "config": {"workload": name + ", out-of-place, interleaved, inputs resident in HBM", "lengths": lengths,
+            "config": {"workload": name + ", %s, %s, inputs resident in HBM" % (
+                           "in-place" if in_place else "out-of-place", "split planes" if split else "interleaved"),
+                       "lengths": lengths,
                        "batch_per_gpu": batch_per_gpu, "global_batch": batch_per_gpu * world,
                        "sharding": "batches, no data-path collective",
                        "barrier_backend": ("rccl" if pg.backend == "nccl" else pg.backend) if distributed else None,
@@ -289,11 +358,11 @@ def main():
                        "parity_rel_l2_vs_numpy": worst},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
-                         "kernel": kernel_label(plan, lengths), "launches_per_execute": launches,
+                         "kernel": kernel_label(plan, lengths), "hbm_passes_per_execute": launches,
                          "kernel_ms": round(avg_kernel_ms, 5),
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "note": "achieved = algorithmic bytes of one execute / event-timed duration of its launches"
-                                 + ("" if launches == 1 else " (two HBM passes: 0.5 is the ceiling)")},
+                                 + (" (two HBM passes: 0.5 is the ceiling)" if launches == 2 else "")},
         }
         if pg.fallback_reason:
             result["config"]["rccl_fallback_reason"] = pg.fallback_reason
