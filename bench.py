@@ -295,6 +295,21 @@ def main():
     kernel_ms = [s.elapsed_time(e) for s, e in zip(starts, stops)]
     avg_kernel_ms = sum(kernel_ms) / len(kernel_ms)
 
+    # device-to-device copy of the same buffers (read + write = the same algorithmic bytes): the measured-bandwidth
+    # yardstick SURVEY.md 8(d) asks for beside the nominal peak
+    copy_ms = None
+    if not in_place and not split and n_in == n_out:
+        for _ in range(2):
+            out[0].copy_(inputs[0][0])
+        c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        c0.record()
+        for k in range(10):
+            out[0].copy_(inputs[k % 2][0])
+        c1.record()
+        torch.cuda.synchronize()
+        copy_ms = c0.elapsed_time(c1) / 10
+        step(args.steps - 1)  # restore the last timed step's output for the parity check
+
     # parity spot check of the timed output (last step's input) against NumPy, through the descriptor's layout
     # (an in-place descriptor has consumed its inputs: one more execute on a fresh copy)
     def pick(buf, index):  # elements `index` of a buffer, as complex on the host
@@ -360,6 +375,10 @@ def main():
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": kernel_label(plan, lengths), "hbm_passes_per_execute": launches,
                          "kernel_ms": round(avg_kernel_ms, 5),
+                         "copy_probe": None if copy_ms is None else {
+                             "what": "torch device-to-device copy_ of the same input into the same output buffer",
+                             "gbs": round(alg_bytes / (copy_ms * 1e-3) / 1e9, 1),
+                             "frac_of_copy": round(achieved / (alg_bytes / (copy_ms * 1e-3) / 1e9), 4)},
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "note": "achieved = algorithmic bytes of one execute / event-timed duration of its launches"
                                  + (" (two HBM passes: 0.5 is the ceiling)" if launches == 2 else "")},
