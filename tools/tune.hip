@@ -119,6 +119,23 @@ int main() {
   add<wg_cfg<f, S, 512, 1, 0, 0, TW_REGS, 2, NT>, false>("r32.32.16 twR wg512 nopad");
   add<wg_cfg<f, S, 512, 1, 16, 1, TW_REGS, 2, NT>, false>("r32.32.16 twR wg512 pad");
   add<wg_cfg<f, radix_list<32, 16, 32>, 512, 1, 0, 0, TW_REGS, 2, NT>, false>("r32.16.32 twR wg512 nopad");
+#elif TUNE_CASE == 16386
+  // prefetching (software-pipelined loads) forms of the one-work-group-per-CU lengths
+  using S = radix_list<32, 16, 32>; using T = f; const int N = 16384;
+  add<wg_cfg<f, S, 512, 1, 0, 0, TW_REGS, 2, NT>, false>("r32.16.32 twR wg512 (production)");
+  add<wg_cfg<f, S, 512, 1, 0, 0, TW_REGS, 1, NT>, true>("r32.16.32 twR wg512 o1 PF");
+  add<wg_cfg<f, S, 512, 1, 0, 0, TW_GLOBAL, 1, NT>, true>("r32.16.32 twG wg512 o1 PF");
+  add<wg_cfg<f, S, 512, 1, 0, 0, TW_GLOBAL, 2, NT>, true>("r32.16.32 twG wg512 o2 PF");
+  add<wg_cfg<f, radix_list<16, 32, 32>, 1024, 1, 0, 0, TW_GLOBAL, 1, NT>, true>("r16.32.32 twG wg1024 o1 PF");
+  add<wg_cfg<f, radix_list<16, 32, 32>, 1024, 1, 0, 0, TW_GLOBAL, 1, NT>, false>("r16.32.32 twG wg1024 o1");
+#elif TUNE_CASE == 8193
+  using S = radix_list<32, 16, 16>; using T = f; const int N = 8192;
+  add<wg_cfg<f, S, 256, 1, 16, 1, TW_REGS, 2, NT>, false>("r32.16.16 twR wg256 o2 (production)");
+  add<wg_cfg<f, S, 256, 1, 16, 1, TW_REGS, 2, NT>, true>("r32.16.16 twR wg256 o2 PF");
+  add<wg_cfg<f, S, 256, 1, 16, 1, TW_GLOBAL, 2, NT>, true>("r32.16.16 twG wg256 o2 PF");
+  add<wg_cfg<f, S, 256, 1, 16, 1, TW_GLOBAL, 2, NT, 0, 1>, true>("r32.16.16 twG TWL1 o2 PF");
+  add<wg_cfg<f, radix_list<16, 16, 32>, 512, 1, 16, 1, TW_GLOBAL, 2, NT>, true>("r16.16.32 twG wg512 o2 PF");
+  add<wg_cfg<f, radix_list<16, 16, 32>, 512, 1, 16, 1, TW_GLOBAL, 2, NT>, false>("r16.16.32 twG wg512 o2");
 #elif TUNE_CASE == 1024064
   using S = radix_list<16, 8, 8>; using T = d; const int N = 1024;
   add<wg_cfg<d, S, 256, 4, 16, 1, TW_GLOBAL, 2, NT>, false>("f64 1024 twG fpw4 o2");
