@@ -109,8 +109,11 @@ struct rows2d_kernel {
 };
 const rows2d_kernel* rows2d_kernels(int* count);
 
-/// AUX template values of the three cache policies
-enum : int { PFA_AUX_NT = 2, PFA_AUX_WRITER = 0x102, PFA_AUX_READER = 0x300 };
+/// AUX template values of the three cache policies (stockham_wg.hpp: loads in bits 0-7, stores + 1 in bits 8-15;
+/// hardware bits 1 = sc0, 2 = nt, 16 = sc1).  The writer's stores carry sc1: written through the XCD's L2 instead of
+/// left dirty in it until the end of the launch, still allocated in the Infinity Cache (tools/tune_2d_small.hip,
+/// TUNE_STORE_POLICY: C5 in 256 MiB chunks 1405 us with plain stores, 1378 with sc1 or sc0|sc1, 1590 with nt).
+enum : int { PFA_AUX_NT = 2, PFA_AUX_WRITER = ((16 + 1) << 8) | 2, PFA_AUX_READER = 0x300 };
 inline int aux_of_policy(int policy) { return policy == 1 ? PFA_AUX_WRITER : policy == 2 ? PFA_AUX_READER : PFA_AUX_NT; }
 
 const strided_kernel* strided_kernels_f32(int* count);

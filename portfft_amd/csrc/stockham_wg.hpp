@@ -147,7 +147,7 @@ static_assert(sizeof(buf_b64_t) == 8 && sizeof(buf_b128_t) == 16, "unexpected ra
 
 /// The AUX template argument of a kernel configuration carries the cache policy of its HBM accesses: bits 0-7 the
 /// policy of the loads (0 default, 2 = nt streaming); bits 8-15, when non-zero, (policy + 1) of the stores, which
-/// otherwise follow the loads.  AUX = 2: everything streamed (multi-GiB batches); AUX = 0x102: streamed loads,
+/// otherwise follow the loads.  AUX = 2: everything streamed (multi-GiB batches); AUX = 0x102 (0x1102 with sc1, the production writer): streamed loads,
 /// default-policy stores -- the writer of an intermediate that should stay in the 256 MiB Infinity Cache;
 /// AUX = 0x300: default-policy loads, streamed stores -- its reader (profiles/r2_notes.md).
 constexpr int aux_of_loads(int aux) { return aux & 0xFF; }

@@ -203,6 +203,17 @@ int main() {
   add<wg_cfg<f, S, 256, 1, 16, 1, TW_GLOBAL, 4, NT>, true>("twG o4 PF");
   add<wg_cfg<f, S, 256, 1, 16, 1, TW_GLOBAL, 4, NT>, false>("twG o4");
   add<wg_cfg<f, S, 256, 1, 16, 1, TW_GLOBAL, 5, NT>, false>("twG o5");
+#elif TUNE_CASE == 4098
+  // cache-policy bits of the headline kernel's loads / stores (1 = sc0, 2 = nt, 16 = sc1; AUX = (stores + 1) << 8 | loads)
+  using S = radix_list<16, 16, 16>; using T = f; const int N = 4096;
+  add<wg_cfg<f, S, 256, 1, 16, 1, TW_REGS, 3, NT>, true>("loads nt, stores nt (current)");
+  add<wg_cfg<f, S, 256, 1, 16, 1, TW_REGS, 3, ((18 + 1) << 8) | 2>, true>("loads nt, stores nt|sc1");
+  add<wg_cfg<f, S, 256, 1, 16, 1, TW_REGS, 3, ((16 + 1) << 8) | 2>, true>("loads nt, stores sc1");
+  add<wg_cfg<f, S, 256, 1, 16, 1, TW_REGS, 3, ((19 + 1) << 8) | 2>, true>("loads nt, stores nt|sc0|sc1");
+  add<wg_cfg<f, S, 256, 1, 16, 1, TW_REGS, 3, ((2 + 1) << 8) | 18>, true>("loads nt|sc1, stores nt");
+  add<wg_cfg<f, S, 256, 1, 16, 1, TW_REGS, 3, ((2 + 1) << 8) | 3>, true>("loads nt|sc0, stores nt");
+  add<wg_cfg<f, S, 256, 1, 16, 1, TW_REGS, 3, ((18 + 1) << 8) | 18>, true>("loads nt|sc1, stores nt|sc1");
+  add<wg_cfg<f, S, 256, 1, 16, 1, TW_REGS, 3, ((3 + 1) << 8) | 2>, true>("loads nt, stores nt|sc0");
 #elif TUNE_CASE == 1025
   using S = radix_list<16, 8, 8>; using T = f; const int N = 1024;
   add<wg_cfg<f, S, 256, 4, 16, 1, TW_GLOBAL, 4, NT>, false>("1024 twG (current)");
