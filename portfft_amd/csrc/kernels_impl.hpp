@@ -177,9 +177,17 @@ inline void pfa_launch(K kernel, dim3 g, dim3 b, size_t lds, hipStream_t stream,
   }
 }
 
+/// LDS behind the kernel's own for the store-modifier tables (strided_args::stw_tab)
+template <typename Cfg>
+inline size_t stw_lds_bytes(const strided_args& args, int stw) {
+  return stw != 0 && args.stw_levels > 0
+             ? (static_cast<size_t>(args.stw_levels) << args.stw_lshift) * sizeof(cx<typename Cfg::T>)
+             : 0;
+}
+
 template <typename Cfg>
 hipError_t launch_strided(hipStream_t stream, unsigned grid, const strided_args& args, int backward, int stw) {
-  constexpr size_t lds = strided_lds_bytes<Cfg>();
+  const size_t lds = strided_lds_bytes<Cfg>() + stw_lds_bytes<Cfg>(args, stw);
   const dim3 g(grid), b(Cfg::WG);
   if (backward) {
     if (stw) {
@@ -199,7 +207,7 @@ hipError_t launch_strided(hipStream_t stream, unsigned grid, const strided_args&
 
 template <typename Cfg>
 hipError_t launch_strided_prefetch(hipStream_t stream, unsigned grid, const strided_args& args, int backward, int stw) {
-  constexpr size_t lds = strided_lds_bytes<Cfg>();
+  const size_t lds = strided_lds_bytes<Cfg>() + stw_lds_bytes<Cfg>(args, stw);
   const dim3 g(grid), b(Cfg::WG);
   if (backward) {
     if (stw) {
@@ -379,7 +387,7 @@ strided_kernel make_strided_entry_flags(int groups_per_wg) {
 template <typename Cfg, bool PREFETCH>
 hipError_t launch_strided_writer(hipStream_t stream, unsigned grid, const strided_args& args, int backward, int stw) {
   if (!stw) return hipErrorInvalidValue;
-  constexpr size_t lds = strided_lds_bytes<Cfg>();
+  const size_t lds = strided_lds_bytes<Cfg>() + stw_lds_bytes<Cfg>(args, stw);
   const dim3 g(grid), b(Cfg::WG);
   if constexpr (PREFETCH) {
     if (backward) pfa_launch(&stockham_strided_prefetch_kernel<Cfg, true, true>, g, b, lds, stream, args);

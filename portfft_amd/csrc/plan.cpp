@@ -208,6 +208,7 @@ struct plan_t {
   size_t alias_scratch_bytes = 0;
   size_t two_pass_chunk_bytes = 0;  // bytes of one chunk of the two-pass 2-D plan (what an aliasing execute needs)
   int tail_policy = 0;              // cache policy plan_1d gives the strided stage it plans (two-pass 2-D plan: reader)
+  std::map<std::pair<long long, int>, const void*> store_tables;  // attach_store_tables: (M, shift) -> device tables
   int n_chunk_groups = 0;
   pfft_plan_info_t info{};
   // chunk overlap (execute): the second launch of chunk c runs on aux_stream while the first launch of chunk c + 1
@@ -304,6 +305,61 @@ struct plan_t {
       *lo = fill(float{}, nlo, 1);
       *hi = fill(float{}, nhi, nlo);
     }
+  }
+
+  /// Store-modifier tables small enough for LDS: L tables of 2^shift entries (shift <= 7), table l = W_M^(i << (l *
+  /// shift)), so that W_M^m is the product of one entry per table (stockham_strided.hpp: stw_from_lds).  The kernel
+  /// copies them behind its own LDS once per work-group; the two global tables stay as the fall-back of stages whose
+  /// LDS has no room left (or would lose a resident work-group).  PFFT_STW_LDS=0: global tables everywhere.
+  void attach_store_tables(stage& s, long long M) {
+    const strided_kernel* k = s.strided;
+    if (k == nullptr || s.store_modifier == 0) return;
+    if (const char* e = getenv("PFFT_STW_LDS"); e != nullptr && e[0] == '0') return;
+    int bits = 0;
+    while ((1ll << bits) < M) ++bits;
+    const int levels = std::max(1, (bits + 6) / 7);
+    const int shift = std::max(1, (bits + levels - 1) / levels);
+    if (levels > 4) return;
+    const size_t extra = (static_cast<size_t>(levels) << shift) * elem_bytes();
+    const size_t cu_lds = 160 * 1024, own = std::max<size_t>(k->lds_bytes, 1);
+    if (k->lds_bytes + extra > max_lds || cu_lds / (k->lds_bytes + extra) < std::min<size_t>(cu_lds / own, 8)) return;
+    auto& slot = store_tables[std::make_pair(M, shift)];
+    if (slot == nullptr) {
+      const long long per = 1ll << shift;
+      auto fill = [&](auto tag) {
+        using T = decltype(tag);
+        std::vector<T> v(static_cast<size_t>(2 * levels * per));
+        for (int l = 0; l < levels; ++l) {
+          for (long long i = 0; i < per; ++i) {
+            const long long m = static_cast<long long>((static_cast<unsigned long long>(i) << (l * shift)) %
+                                                       static_cast<unsigned long long>(M));
+            const long double a = -2.0L * static_cast<long double>(PI_L) * static_cast<long double>(m) /
+                                  static_cast<long double>(M);
+            v[static_cast<size_t>(2 * (l * per + i))] = static_cast<T>(cosl(a));
+            v[static_cast<size_t>(2 * (l * per + i) + 1)] = static_cast<T>(sinl(a));
+          }
+        }
+        return upload(v.data(), v.size() * sizeof(T));
+      };
+      slot = desc.precision == PFFT_PRECISION_F64 ? fill(double{}) : fill(float{});
+    }
+    s.sa.stw_tab = slot;
+    s.sa.stw_levels = levels;
+    s.sa.stw_lshift = shift;
+    const size_t total = k->lds_bytes + extra;
+    if (k->launch != nullptr) {  // pre-compiled: the store-modifier forms get the larger dynamic LDS limit
+      for (int d = 0; d < 2; ++d) {
+        if (k->fn[d * 2 + 1] != nullptr && total > 48 * 1024) {
+          hip_check(hipFuncSetAttribute(k->fn[d * 2 + 1], hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        static_cast<int>(total)),
+                    "hipFuncSetAttribute");
+        }
+      }
+      const long long groups = strided_groups(s.count, s.sa.inner, k->fpw);
+      const void* fn = k->fn[s.backward * 2 + 1];
+      if (fn != nullptr) s.grid = persistent_grid(fn, nullptr, k->wg, total, groups, k->groups_per_wg);
+    }
+    s.lds_bytes = total;
   }
 
   const spec_kernel* find_spec(long long n) const {
@@ -857,6 +913,7 @@ struct plan_t {
     sa.sa.stw_cdiv = B;
     sa.store_modifier = 1;
     sa.row_mode = 0;
+    attach_store_tables(sa, n);
     out.push_back(sa);
     stage sb = make_strided_stage(kb, outer * n1 * B, B, BUF_SCRATCH, b_in, out_buf, b_out, scale, backward);
     if (outer > 1) {  // outer index of stage B = (array, k1): the array part advances by n * B on both sides
@@ -1065,6 +1122,7 @@ struct plan_t {
       sa.sa.stw_hi = stw_hi;
       sa.sa.stw_shift = shift;
       sa.store_modifier = 1;
+      attach_store_tables(sa, n);
     } else {
       sa = make_generic_stage(n1, count * n2, n2, in_buf, a_in, BUF_SCRATCH, a_out, 1.0, backward, backward);
       sa.ga.stw_lo = stw_lo;

@@ -55,6 +55,41 @@ constexpr int strided_pitch() {
   return ROW ? Cfg::FPW + 1 : Cfg::FPW;
 }
 
+/// LDS copy of the store-modifier tables (strided_args::stw_tab): behind the images and the TWL tables.
+template <typename Cfg>
+PFA_DEV cx<typename Cfg::T>* stw_lds_tables() {
+  extern __shared__ __attribute__((aligned(16))) char pfa_smem_strided[];
+  constexpr size_t own = Cfg::NP > 1 ? size_t(Cfg::N) * Cfg::FPW + Cfg::TWL_ELEMS : 0;
+  return reinterpret_cast<cx<typename Cfg::T>*>(pfa_smem_strided) + own;
+}
+
+/// W_M^m as the product of one entry per level
+template <typename Cfg>
+PFA_DEV cx<typename Cfg::T> stw_from_lds(const strided_args& a, unsigned long long m) {
+  const cx<typename Cfg::T>* tab = stw_lds_tables<Cfg>();
+  const unsigned sh = static_cast<unsigned>(a.stw_lshift);
+  const unsigned mask = (1u << sh) - 1u;
+  cx<typename Cfg::T> w = tab[static_cast<unsigned>(m) & mask];
+  if (a.stw_levels > 1) w = cmul(w, tab[(1u << sh) + (static_cast<unsigned>(m >> sh) & mask)]);
+  if (a.stw_levels > 2) w = cmul(w, tab[(2u << sh) + (static_cast<unsigned>(m >> (2 * sh)) & mask)]);
+  if (a.stw_levels > 3) w = cmul(w, tab[(3u << sh) + (static_cast<unsigned>(m >> (3 * sh)) & mask)]);
+  return w;
+}
+
+/// once per work-group lifetime (STW kernels): the tables into LDS
+template <typename Cfg, bool STW>
+PFA_DEV void strided_copy_stw(const strided_args& a) {
+  if constexpr (STW) {
+    if (a.stw_levels > 0) {
+      cx<typename Cfg::T>* dst = stw_lds_tables<Cfg>();
+      const cx<typename Cfg::T>* src = static_cast<const cx<typename Cfg::T>*>(a.stw_tab);
+      const int n = a.stw_levels << a.stw_lshift;
+      for (int i = threadIdx.x; i < n; i += Cfg::WG) dst[i] = src[i];
+      __syncthreads();
+    }
+  }
+}
+
 /// The HBM side of a last pass: butterfly outputs v[u] = element (base + u * Ns) of FFT f go to memory, conjugated
 /// for the backward transform, scaled, and -- STW -- multiplied by the store modifier W_M^{k*c}.
 template <typename Cfg, bool BWD, bool STW, int R, int Ns, typename IO>
@@ -76,15 +111,27 @@ PFA_DEV void strided_store_butterfly(const IO& io, const strided_args& a, unsign
     if (a.stw_cdiv > 1) stw_c /= static_cast<unsigned long long>(a.stw_cdiv);
     const cx<T>* lo = static_cast<const cx<T>*>(a.stw_lo);
     const cx<T>* hi = static_cast<const cx<T>*>(a.stw_hi);
+#ifdef PFA_STW_FAKE_UNIFORM  // tuner only: every table index 0 (the cost of the gathers, not of the arithmetic)
+    const unsigned long long mask = 0;
+    stw_c = 0;
+#else
     const unsigned long long mask = (1ull << a.stw_shift) - 1;
+#endif
     const unsigned long long m0 = static_cast<unsigned long long>(base) * stw_c;
     const unsigned long long ms = static_cast<unsigned long long>(Ns) * stw_c;
-    const cx<T> w0 = cmul(lo[m0 & mask], hi[m0 >> a.stw_shift]);
+    // W^m: from the small multi-level tables in LDS when the plan put them there (strided_copy_stw), else from the
+    // two global tables (scattered 16-byte gathers through the vector memory path: 4.5 % of the C3 stage-A time)
+    const bool in_lds = a.stw_levels > 0;
+    auto root = [&](unsigned long long m) PFA_LAMBDA -> cx<T> {
+      if (in_lds) return stw_from_lds<Cfg>(a, m);
+      return cmul(lo[m & mask], hi[m >> a.stw_shift]);
+    };
+    const cx<T> w0 = root(m0);
     // stw[u] = W^{(base + u*Ns)*c} = w0 * step^u.  Every fourth one is w0 times a table value (anchor), the
     // three behind it are one multiply away from their anchor -- a chain of squarings of the step would amplify
     // its rounding by u (radix 32: ~45 ulp in fp32), and folding w0 into the anchors saves R multiplies.
     [[maybe_unused]] cx<T> pw[4];
-    if constexpr (R > 1) pw[1] = cmul(lo[ms & mask], hi[ms >> a.stw_shift]);
+    if constexpr (R > 1) pw[1] = root(ms);
     if constexpr (R > 2) pw[2] = cmul(pw[1], pw[1]);
     if constexpr (R > 3) pw[3] = cmul(pw[2], pw[1]);
     sfor<0, (R + 3) / 4>([&](auto k_) PFA_LAMBDA {
@@ -92,7 +139,7 @@ PFA_DEV void strided_store_butterfly(const IO& io, const strided_args& a, unsign
       cx<T> anchor = w0;
       if constexpr (k > 0) {
         const unsigned long long mu = ms * static_cast<unsigned long long>(4 * k);
-        anchor = cmul(w0, cmul(lo[mu & mask], hi[mu >> a.stw_shift]));
+        anchor = cmul(w0, root(mu));
       }
       stw[4 * k] = anchor;
       sfor<1, 4>([&](auto r_) PFA_LAMBDA {
@@ -366,6 +413,7 @@ __global__ __launch_bounds__(Cfg::WG, Cfg::OCC) void stockham_strided_prefetch_k
   long long g = gr.g;
   if (g >= gr.end) return;
   strided_copy_twiddles<Cfg>(lds, tw);
+  strided_copy_stw<Cfg, STW>(a);
   cx<T> cur[Cfg::bpt(0)][Cfg::Seq::r[0]];
   cx<T> nxt[Cfg::bpt(0)][Cfg::Seq::r[0]];
   bool live, live_n = false;
@@ -498,6 +546,7 @@ __global__ __launch_bounds__(Cfg::WG, Cfg::OCC) void stockham_strided_kernel(con
   const cx<T>* __restrict__ tw = static_cast<const cx<T>*>(a.tw);
   const long long ngroups = strided_ngroups<Cfg>(a);
   strided_copy_twiddles<Cfg>(lds, tw);
+  strided_copy_stw<Cfg, STW>(a);
   const group_range_t gr = tiered_range(ngroups, a.tier_main, a.tier_k);
   for (long long g = gr.g; g < gr.end; g += gr.stride) {
     bool live;
