@@ -374,6 +374,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": kernel_label(plan, lengths), "hbm_passes_per_execute": launches,
+                         "launches_per_execute": int(plan.info().launches[0]),
                          "kernel_ms": round(avg_kernel_ms, 5),
                          "copy_probe": None if copy_ms is None else {
                              "what": "torch device-to-device copy_ of the same input into the same output buffer",

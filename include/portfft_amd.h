@@ -98,6 +98,8 @@ typedef struct pfft_plan_info_t {
   uint64_t twiddle_bytes; /* HBM held by the plan for twiddles */
   uint64_t scratch_bytes; /* HBM held by the plan for intermediate data */
   pfft_dim_info_t dims[PFFT_MAX_RANK];
+  int32_t launches[2]; /* kernel launches of one execute [forward, backward]; plans that run chunk by chunk
+                          (intermediate sized to the Infinity Cache) count every chunk's launches */
 } pfft_plan_info_t;
 
 typedef struct pfft_plan_t pfft_plan_t; /* opaque: portfft::committed_descriptor */

@@ -55,6 +55,7 @@ class pfft_plan_info_t(C.Structure):
         ("twiddle_bytes", C.c_uint64),
         ("scratch_bytes", C.c_uint64),
         ("dims", pfft_dim_info_t * MAX_RANK),
+        ("launches", C.c_int32 * 2),
     ]
 
 

@@ -1376,6 +1376,15 @@ struct plan_t {
     if (alias_scratch_bytes > 0) ensure_alias_scratch();
     info.twiddle_bytes = twiddle_bytes;
     info.scratch_bytes = scratch_bytes + alias_scratch_bytes;
+    for (int d = 0; d < 2; ++d) {
+      long long n = 0;
+      for (const stage& st : stages[d]) {
+        const long long batches = st.chunk_group < 0 ? 1 : st.count / std::max<long long>(1, st.ffts_per_batch);
+        const long long per = std::max<long long>(1, st.chunk_batches);
+        n += st.chunk_group < 0 ? 1 : (batches + per - 1) / per;
+      }
+      info.launches[d] = static_cast<int32_t>(std::min<long long>(n, 0x7fffffff));
+    }
   }
 
   /// Copy of a committed plan (committed_descriptor_impl.hpp:774-817): the kernels and the twiddle tables are shared,

@@ -299,6 +299,9 @@ def test_cache_sized_chunks_and_policy_twins():
     lengths, batch, prec = [1024, 1024], 37, "f32"
     n = int(np.prod(lengths))
     x, y, plan = run_case(lengths, batch, prec, 1)
+    assert list(plan.info().launches) == [4, 4]  # 37 matrices of 8 MiB: chunks of 32 + 5, two launches each
+    _, _, plan0 = run_case(lengths, batch, prec, 1, {"PFFT_CACHE_CHUNK_MIB": "0"})
+    assert list(plan0.info().launches) == [2, 2]
     s1 = torch.cuda.Stream()
     plan_s = G.make_descriptor(lengths, prec, batch=batch).commit(s1)
     xin = torch.zeros_like(x)
