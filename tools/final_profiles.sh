@@ -11,3 +11,5 @@ for f in $out/r2_bench_*.json; do python3 -c "
 import json,sys
 d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1]); r=d['roofline']
 print(sys.argv[1].split('/')[-1], d['value'], d['ms_per_step'], r['kernel_ms'], r['frac'], (r.get('copy_probe') or {}).get('gbs'))" $f; done
+# PMC traffic passes of the multi-launch configs (kernel names carry the cache-policy AUX value)
+for c in c3 c5 ref65536; do tools/run_pmc.sh $c $out/pmc_$c > $out/pmc_$c.log 2>&1; done
