@@ -166,15 +166,15 @@ spec_kernel make_spec_entry_xlane(int groups_per_wg = 1) {
 /// the plan sets it only for launches that are independent of everything that can still be in flight (plan.cpp,
 /// chunk overlap).
 template <typename K, typename A>
-inline void pfa_launch(K kernel, dim3 g, dim3 b, size_t lds, hipStream_t stream, const A& args) {
+inline hipError_t pfa_launch(K kernel, dim3 g, dim3 b, size_t lds, hipStream_t stream, const A& args) {
   if (args.any_order != 0) {
     A copy = args;
     void* p[] = {&copy};
-    (void)hipExtLaunchKernel(reinterpret_cast<const void*>(kernel), g, b, p, lds, stream, nullptr, nullptr,
-                             hipExtAnyOrderLaunch);
-  } else {
-    hipLaunchKernelGGL(kernel, g, b, lds, stream, args);
+    return hipExtLaunchKernel(reinterpret_cast<const void*>(kernel), g, b, p, lds, stream, nullptr, nullptr,
+                              hipExtAnyOrderLaunch);
   }
+  hipLaunchKernelGGL(kernel, g, b, lds, stream, args);
+  return hipGetLastError();
 }
 
 /// LDS behind the kernel's own for the store-modifier tables (strided_args::stw_tab)
@@ -191,15 +191,15 @@ hipError_t launch_strided(hipStream_t stream, unsigned grid, const strided_args&
   const dim3 g(grid), b(Cfg::WG);
   if (backward) {
     if (stw) {
-      pfa_launch(&stockham_strided_kernel<Cfg, true, true>, g, b, lds, stream, args);
+      return pfa_launch(&stockham_strided_kernel<Cfg, true, true>, g, b, lds, stream, args);
     } else {
-      pfa_launch(&stockham_strided_kernel<Cfg, true, false>, g, b, lds, stream, args);
+      return pfa_launch(&stockham_strided_kernel<Cfg, true, false>, g, b, lds, stream, args);
     }
   } else {
     if (stw) {
-      pfa_launch(&stockham_strided_kernel<Cfg, false, true>, g, b, lds, stream, args);
+      return pfa_launch(&stockham_strided_kernel<Cfg, false, true>, g, b, lds, stream, args);
     } else {
-      pfa_launch(&stockham_strided_kernel<Cfg, false, false>, g, b, lds, stream, args);
+      return pfa_launch(&stockham_strided_kernel<Cfg, false, false>, g, b, lds, stream, args);
     }
   }
   return hipGetLastError();
@@ -211,15 +211,15 @@ hipError_t launch_strided_prefetch(hipStream_t stream, unsigned grid, const stri
   const dim3 g(grid), b(Cfg::WG);
   if (backward) {
     if (stw) {
-      pfa_launch(&stockham_strided_prefetch_kernel<Cfg, true, true>, g, b, lds, stream, args);
+      return pfa_launch(&stockham_strided_prefetch_kernel<Cfg, true, true>, g, b, lds, stream, args);
     } else {
-      pfa_launch(&stockham_strided_prefetch_kernel<Cfg, true, false>, g, b, lds, stream, args);
+      return pfa_launch(&stockham_strided_prefetch_kernel<Cfg, true, false>, g, b, lds, stream, args);
     }
   } else {
     if (stw) {
-      pfa_launch(&stockham_strided_prefetch_kernel<Cfg, false, true>, g, b, lds, stream, args);
+      return pfa_launch(&stockham_strided_prefetch_kernel<Cfg, false, true>, g, b, lds, stream, args);
     } else {
-      pfa_launch(&stockham_strided_prefetch_kernel<Cfg, false, false>, g, b, lds, stream, args);
+      return pfa_launch(&stockham_strided_prefetch_kernel<Cfg, false, false>, g, b, lds, stream, args);
     }
   }
   return hipGetLastError();
@@ -248,9 +248,9 @@ hipError_t launch_strided_row(hipStream_t stream, unsigned grid, const strided_a
 template <typename Cfg>
 hipError_t launch_rows2d(hipStream_t stream, unsigned grid, const rows2d_args& args, int backward) {
   if (backward) {
-    pfa_launch(&stockham_rows2d_kernel<Cfg, true>, dim3(grid), dim3(Cfg::WG), Cfg::LDS_BYTES, stream, args);
+    return pfa_launch(&stockham_rows2d_kernel<Cfg, true>, dim3(grid), dim3(Cfg::WG), Cfg::LDS_BYTES, stream, args);
   } else {
-    pfa_launch(&stockham_rows2d_kernel<Cfg, false>, dim3(grid), dim3(Cfg::WG), Cfg::LDS_BYTES, stream, args);
+    return pfa_launch(&stockham_rows2d_kernel<Cfg, false>, dim3(grid), dim3(Cfg::WG), Cfg::LDS_BYTES, stream, args);
   }
   return hipGetLastError();
 }
@@ -390,11 +390,11 @@ hipError_t launch_strided_writer(hipStream_t stream, unsigned grid, const stride
   const size_t lds = strided_lds_bytes<Cfg>() + stw_lds_bytes<Cfg>(args, stw);
   const dim3 g(grid), b(Cfg::WG);
   if constexpr (PREFETCH) {
-    if (backward) pfa_launch(&stockham_strided_prefetch_kernel<Cfg, true, true>, g, b, lds, stream, args);
-    else pfa_launch(&stockham_strided_prefetch_kernel<Cfg, false, true>, g, b, lds, stream, args);
+    if (backward) return pfa_launch(&stockham_strided_prefetch_kernel<Cfg, true, true>, g, b, lds, stream, args);
+    else return pfa_launch(&stockham_strided_prefetch_kernel<Cfg, false, true>, g, b, lds, stream, args);
   } else {
-    if (backward) pfa_launch(&stockham_strided_kernel<Cfg, true, true>, g, b, lds, stream, args);
-    else pfa_launch(&stockham_strided_kernel<Cfg, false, true>, g, b, lds, stream, args);
+    if (backward) return pfa_launch(&stockham_strided_kernel<Cfg, true, true>, g, b, lds, stream, args);
+    else return pfa_launch(&stockham_strided_kernel<Cfg, false, true>, g, b, lds, stream, args);
   }
   return hipGetLastError();
 }
@@ -404,11 +404,11 @@ hipError_t launch_strided_reader(hipStream_t stream, unsigned grid, const stride
   constexpr size_t lds = strided_lds_bytes<Cfg>();
   const dim3 g(grid), b(Cfg::WG);
   if constexpr (PREFETCH) {
-    if (backward) pfa_launch(&stockham_strided_prefetch_kernel<Cfg, true, false>, g, b, lds, stream, args);
-    else pfa_launch(&stockham_strided_prefetch_kernel<Cfg, false, false>, g, b, lds, stream, args);
+    if (backward) return pfa_launch(&stockham_strided_prefetch_kernel<Cfg, true, false>, g, b, lds, stream, args);
+    else return pfa_launch(&stockham_strided_prefetch_kernel<Cfg, false, false>, g, b, lds, stream, args);
   } else {
-    if (backward) pfa_launch(&stockham_strided_kernel<Cfg, true, false>, g, b, lds, stream, args);
-    else pfa_launch(&stockham_strided_kernel<Cfg, false, false>, g, b, lds, stream, args);
+    if (backward) return pfa_launch(&stockham_strided_kernel<Cfg, true, false>, g, b, lds, stream, args);
+    else return pfa_launch(&stockham_strided_kernel<Cfg, false, false>, g, b, lds, stream, args);
   }
   return hipGetLastError();
 }
