@@ -8,6 +8,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include <cstddef>
 
 #include "generic_args.hpp"
@@ -84,6 +86,9 @@ struct strided_kernel {
   int wide;
   /// 1: alternative entry preferred when one side of the stage is row-shaped (its `_row` forms pay at this length)
   int rowish;
+  /// where the store-modifier forms take their tables from (stockham_strided.hpp, STW): 1 small multi-level tables in
+  /// LDS (every pre-compiled entry), 2 two global tables (runtime-specialised entries without LDS headroom)
+  int stw_mode;
 };
 
 /// First pass of the two-pass 2-D plan (stockham_rows2d.hpp): whole row FFTs of length n + the first radix-rc
@@ -114,7 +119,14 @@ const rows2d_kernel* rows2d_kernels(int* count);
 /// left dirty in it until the end of the launch, still allocated in the Infinity Cache (tools/tune_2d_small.hip,
 /// TUNE_STORE_POLICY: C5 in 256 MiB chunks 1405 us with plain stores, 1378 with sc1 or sc0|sc1, 1590 with nt).
 enum : int { PFA_AUX_NT = 2, PFA_AUX_WRITER = ((16 + 1) << 8) | 2, PFA_AUX_READER = 0x300 };
-inline int aux_of_policy(int policy) { return policy == 1 ? PFA_AUX_WRITER : policy == 2 ? PFA_AUX_READER : PFA_AUX_NT; }
+/// (runtime-specialised kernels, jit.cpp; PFFT_JIT_WRITER_AUX overrides the writer's value for experiments)
+inline int aux_of_policy(int policy) {
+  if (policy == 1) {
+    if (const char* e = getenv("PFFT_JIT_WRITER_AUX")) return static_cast<int>(std::strtol(e, nullptr, 0));
+    return PFA_AUX_WRITER;
+  }
+  return policy == 2 ? PFA_AUX_READER : PFA_AUX_NT;
+}
 
 const strided_kernel* strided_kernels_f32(int* count);
 const strided_kernel* strided_kernels_f64(int* count);

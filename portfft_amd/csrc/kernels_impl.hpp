@@ -180,9 +180,7 @@ inline hipError_t pfa_launch(K kernel, dim3 g, dim3 b, size_t lds, hipStream_t s
 /// LDS behind the kernel's own for the store-modifier tables (strided_args::stw_tab)
 template <typename Cfg>
 inline size_t stw_lds_bytes(const strided_args& args, int stw) {
-  return stw != 0 && args.stw_levels > 0
-             ? (static_cast<size_t>(args.stw_levels) << args.stw_lshift) * sizeof(cx<typename Cfg::T>)
-             : 0;
+  return stw != 0 ? (static_cast<size_t>(args.stw_levels) << args.stw_lshift) * sizeof(cx<typename Cfg::T>) : 0;
 }
 
 template <typename Cfg>
@@ -482,6 +480,7 @@ strided_kernel make_strided_entry(int groups_per_wg) {
   k.wg = Cfg::WG;
   k.fpw = Cfg::FPW;
   k.lds_bytes = strided_lds_bytes<Cfg>();
+  k.stw_mode = 1;
   k.n_radices = Cfg::NP;
   for (int i = 0; i < Cfg::NP; ++i) k.radices[i] = Cfg::Seq::r[i];
   k.fn[0] = reinterpret_cast<const void*>(&stockham_strided_kernel<Cfg, false, false>);

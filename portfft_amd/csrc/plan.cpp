@@ -307,22 +307,53 @@ struct plan_t {
     }
   }
 
-  /// Store-modifier tables small enough for LDS: L tables of 2^shift entries (shift <= 7), table l = W_M^(i << (l *
-  /// shift)), so that W_M^m is the product of one entry per table (stockham_strided.hpp: stw_from_lds).  The kernel
-  /// copies them behind its own LDS once per work-group; the two global tables stay as the fall-back of stages whose
-  /// LDS has no room left (or would lose a resident work-group).  PFFT_STW_LDS=0: global tables everywhere.
-  void attach_store_tables(stage& s, long long M) {
-    const strided_kernel* k = s.strided;
-    if (k == nullptr || s.store_modifier == 0) return;
-    if (const char* e = getenv("PFFT_STW_LDS"); e != nullptr && e[0] == '0') return;
+  /// levels / shift of the store-modifier tables of an M-point plan behind kernel k's LDS: the fewest levels (fewest
+  /// multiplies per root) whose tables stay within 16 KiB and do not cost the kernel a resident work-group; failing
+  /// that the smallest tables (levels of <= 128 entries).  fp32 N <= 2^20: two levels; fp64 N = 2^20: three.
+  void store_table_shape(const strided_kernel* k, long long M, int* levels, int* shift) const {
     int bits = 0;
     while ((1ll << bits) < M) ++bits;
-    const int levels = std::max(1, (bits + 6) / 7);
-    const int shift = std::max(1, (bits + levels - 1) / levels);
-    if (levels > 4) return;
-    const size_t extra = (static_cast<size_t>(levels) << shift) * elem_bytes();
+    bits = std::max(bits, 1);
     const size_t cu_lds = 160 * 1024, own = std::max<size_t>(k->lds_bytes, 1);
-    if (k->lds_bytes + extra > max_lds || cu_lds / (k->lds_bytes + extra) < std::min<size_t>(cu_lds / own, 8)) return;
+    const size_t resident = std::min<size_t>(cu_lds / own, 8);
+    for (int l = 1; l <= 4; ++l) {
+      const int sh = (bits + l - 1) / l;
+      const size_t bytes = (static_cast<size_t>(l) << sh) * elem_bytes();
+      if (bytes <= 16 * 1024 && k->lds_bytes + bytes <= max_lds && std::min<size_t>(cu_lds / (own + bytes), 8) >= resident) {
+        *levels = l;
+        *shift = sh;
+        return;
+      }
+    }
+    *levels = std::max(1, (bits + 6) / 7);
+    *shift = std::max(1, (bits + *levels - 1) / *levels);
+  }
+  /// can stage kernel k carry the tables behind its LDS?  (always, for the kernels the planners produce: their own
+  /// LDS ends at 144 KiB and the smallest tables take at most 8 KiB)
+  bool store_tables_fit(const strided_kernel* k, long long M) const {
+    if (k == nullptr) return false;
+    if (k->stw_mode != 1) return true;  // two global tables
+    int levels = 0, shift = 0;
+    store_table_shape(k, M, &levels, &shift);
+    return levels <= 4 && k->lds_bytes + (static_cast<size_t>(levels) << shift) * elem_bytes() <= max_lds;
+  }
+
+  /// Store-modifier tables of a strided stage: L tables of 2^shift entries, table l = W_M^(i << (l * shift)), so that
+  /// W_M^m is the product of one entry per table (stockham_strided.hpp: stw_from_lds).  The kernel copies them behind
+  /// its own LDS once per work-group (round 1: two L2-resident tables read with scattered gathers).
+  void attach_store_tables(stage& s, long long M) {
+    const strided_kernel* k = s.strided;
+    s.store_modifier = 1;
+    if (k->stw_mode != 1) {  // this kernel's store-modifier forms read two global tables (strided_kernel::stw_mode)
+      int sh = 0;
+      while ((1ll << (2 * sh)) < M) ++sh;
+      upload_store_twiddles(M, sh, &s.sa.stw_lo, &s.sa.stw_hi);
+      s.sa.stw_shift = sh;
+      return;
+    }
+    int levels = 0, shift = 0;
+    store_table_shape(k, M, &levels, &shift);
+    const size_t extra = (static_cast<size_t>(levels) << shift) * elem_bytes();
     auto& slot = store_tables[std::make_pair(M, shift)];
     if (slot == nullptr) {
       const long long per = 1ll << shift;
@@ -346,6 +377,7 @@ struct plan_t {
     s.sa.stw_tab = slot;
     s.sa.stw_levels = levels;
     s.sa.stw_lshift = shift;
+    s.store_modifier = 1;
     const size_t total = k->lds_bytes + extra;
     if (k->launch != nullptr) {  // pre-compiled: the store-modifier forms get the larger dynamic LDS limit
       for (int d = 0; d < 2; ++d) {
@@ -384,7 +416,7 @@ struct plan_t {
   /// column_both: the stage is column-shaped on both sides -> the wide-group entry of the length, when there is one
   /// row_side: one side of the stage is row-shaped -> the row-friendly entry of the length, when there is one
   const strided_kernel* find_strided(long long n, bool column_both = false, bool row_side = false,
-                                     long long inner_count = -1, int policy = 0) const {
+                                     long long inner_count = -1, int policy = 0, bool store_modifier = false) const {
     int count = 0;
     const strided_kernel* k =
         desc.precision == PFFT_PRECISION_F64 ? strided_kernels_f64(&count) : strided_kernels_f32(&count);
@@ -394,7 +426,13 @@ struct plan_t {
       if (k[i].wide == 0 && k[i].rowish == 0 && found == nullptr) found = &k[i];
       // wide groups only pay when the stage has that many adjacent columns (surplus lanes would be masked)
       if (k[i].wide != 0 && column_both && (inner_count < 0 || inner_count >= k[i].fpw)) return &k[i];
-      if (k[i].rowish != 0 && row_side && k[i].lds_bytes_row <= max_lds) return &k[i];
+      // ... which is also the entry for a stage with the store modifier: its last radix is 8 (fp32 n = 1024: 16.8.8
+      // against the 32.32 prefetch kernel, whose radix-32 store butterfly holds 32 modifier values next to 32 outputs:
+      // four-step N = 2^20 stage A 147 -> 131 us per 256 MiB, 1.128 -> 1.006 ms per GiB)
+      if (k[i].rowish != 0 && (row_side || (store_modifier && getenv("PFFT_NO_STW_ROWISH") == nullptr)) &&
+          k[i].lds_bytes_row <= max_lds) {
+        return &k[i];
+      }
     }
     return found;
   }
@@ -414,10 +452,10 @@ struct plan_t {
   const strided_kernel* get_strided(long long n, long long inner_count, bool store_modifier, bool user_split,
                                     bool column_both = false, bool row_side = false, int policy = 0) {
     if (user_split) policy = 0;
-    const strided_kernel* k = find_strided(n, column_both, row_side && !user_split, inner_count, policy);
+    const strided_kernel* k = find_strided(n, column_both, row_side && !user_split, inner_count, policy, store_modifier);
     if (k != nullptr) return k;
-    if (find_strided(n, column_both, row_side && !user_split, inner_count, 0) != nullptr && policy != 0) {
-      return find_strided(n, column_both, row_side && !user_split, inner_count, 0);  // no twin registered
+    if (find_strided(n, column_both, row_side && !user_split, inner_count, 0, store_modifier) != nullptr && policy != 0) {
+      return find_strided(n, column_both, row_side && !user_split, inner_count, 0, store_modifier);  // no twin registered
     }
     std::string why;
     k = jit_strided_kernel(desc.precision, n, inner_count, store_modifier, user_split ? 1 : 0, max_lds, &why,
@@ -579,10 +617,13 @@ struct plan_t {
     a.in_fdist = static_cast<unsigned>(ia.dist_inner);
     a.out_fdist = static_cast<unsigned>(oa.dist_inner);
     a.scale = scale;
+    a.stw_tab = nullptr;
+    a.stw_levels = 0;
+    a.stw_lshift = 0;
+    a.stw_cdiv = 1;
     a.stw_lo = nullptr;
     a.stw_hi = nullptr;
     a.stw_shift = 0;
-    a.stw_cdiv = 1;
     s.lds_bytes = k->lds_bytes;
     // row-shaped side of an interleaved fp32 stage: copy it through LDS with full-line accesses
     const bool user_split =
@@ -896,22 +937,13 @@ struct plan_t {
     addressing a_out{0, n2 * B, 1, n * B};
     addressing b_in{0, B, 1, n2 * B};
     addressing b_out{oa.offset, n1 * B, 1, B};
-    if (!strided_fits(ka, n2 * B, in_buf, a_in, BUF_SCRATCH, a_out) ||
+    if (!strided_fits(ka, n2 * B, in_buf, a_in, BUF_SCRATCH, a_out) || !store_tables_fit(ka, n) ||
         !strided_fits(kb, B, BUF_SCRATCH, b_in, out_buf, b_out)) {
       return false;
     }
     scratch_bytes = std::max(scratch_bytes, need);
-    int shift = 0;
-    while ((1ll << (2 * shift)) < n) ++shift;
-    const void* stw_lo = nullptr;
-    const void* stw_hi = nullptr;
-    upload_store_twiddles(n, shift, &stw_lo, &stw_hi);
     stage sa = make_strided_stage(ka, outer * n2 * B, n2 * B, in_buf, a_in, BUF_SCRATCH, a_out, 1.0, backward, 1);
-    sa.sa.stw_lo = stw_lo;
-    sa.sa.stw_hi = stw_hi;
-    sa.sa.stw_shift = shift;
     sa.sa.stw_cdiv = B;
-    sa.store_modifier = 1;
     sa.row_mode = 0;
     attach_store_tables(sa, n);
     out.push_back(sa);
@@ -1099,11 +1131,6 @@ struct plan_t {
     // stage A: for every batch b and column c: length-n1 FFT over rows (stride n2), x W_n^{k1*c}, same layout out
     addressing a_in{ia.offset, n2, 1, n};
     addressing a_out{0, n2, 1, n};
-    int shift = 0;
-    while ((1ll << (2 * shift)) < n) ++shift;
-    const void* stw_lo = nullptr;
-    const void* stw_hi = nullptr;
-    upload_store_twiddles(n, shift, &stw_lo, &stw_hi);
     const bool interleaved_user = desc.complex_storage == PFFT_INTERLEAVED_COMPLEX;
     const bool user_io = in_buf != BUF_SCRATCH && out_buf != BUF_SCRATCH;
     const strided_kernel* ka = interleaved_user ? get_strided(n1, n2, true, false, false, false, cached ? 1 : 0)
@@ -1114,17 +1141,18 @@ struct plan_t {
     const bool force_generic_a = dbg != nullptr && std::strstr(dbg, "ga") != nullptr;
     const bool force_generic_b = dbg != nullptr && std::strstr(dbg, "gb") != nullptr;
     stage sa;
-    if (!force_generic_a && strided_fits(ka, n2, in_buf, a_in, BUF_SCRATCH, a_out)) {
+    if (!force_generic_a && strided_fits(ka, n2, in_buf, a_in, BUF_SCRATCH, a_out) && store_tables_fit(ka, n)) {
       // conjugating on load and store in both stages is the identity in between, so the backward transform can use
       // the kernels' BWD form on both
       sa = make_strided_stage(ka, count * n2, n2, in_buf, a_in, BUF_SCRATCH, a_out, 1.0, backward, 1);
-      sa.sa.stw_lo = stw_lo;
-      sa.sa.stw_hi = stw_hi;
-      sa.sa.stw_shift = shift;
-      sa.store_modifier = 1;
       attach_store_tables(sa, n);
     } else {
       sa = make_generic_stage(n1, count * n2, n2, in_buf, a_in, BUF_SCRATCH, a_out, 1.0, backward, backward);
+      int shift = 0;  // the generic kernel reads two global tables (hi/lo split of the exponent)
+      while ((1ll << (2 * shift)) < n) ++shift;
+      const void* stw_lo = nullptr;
+      const void* stw_hi = nullptr;
+      upload_store_twiddles(n, shift, &stw_lo, &stw_hi);
       sa.ga.stw_lo = stw_lo;
       sa.ga.stw_hi = stw_hi;
       sa.ga.stw_shift = shift;

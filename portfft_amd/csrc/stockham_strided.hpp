@@ -77,22 +77,20 @@ PFA_DEV cx<typename Cfg::T> stw_from_lds(const strided_args& a, unsigned long lo
 }
 
 /// once per work-group lifetime (STW kernels): the tables into LDS
-template <typename Cfg, bool STW>
+template <typename Cfg, int STW>
 PFA_DEV void strided_copy_stw(const strided_args& a) {
-  if constexpr (STW) {
-    if (a.stw_levels > 0) {
-      cx<typename Cfg::T>* dst = stw_lds_tables<Cfg>();
-      const cx<typename Cfg::T>* src = static_cast<const cx<typename Cfg::T>*>(a.stw_tab);
-      const int n = a.stw_levels << a.stw_lshift;
-      for (int i = threadIdx.x; i < n; i += Cfg::WG) dst[i] = src[i];
-      __syncthreads();
-    }
+  if constexpr (STW == 1) {
+    cx<typename Cfg::T>* dst = stw_lds_tables<Cfg>();
+    const cx<typename Cfg::T>* src = static_cast<const cx<typename Cfg::T>*>(a.stw_tab);
+    const int n = a.stw_levels << a.stw_lshift;
+    for (int i = threadIdx.x; i < n; i += Cfg::WG) dst[i] = src[i];
+    __syncthreads();
   }
 }
 
 /// The HBM side of a last pass: butterfly outputs v[u] = element (base + u * Ns) of FFT f go to memory, conjugated
 /// for the backward transform, scaled, and -- STW -- multiplied by the store modifier W_M^{k*c}.
-template <typename Cfg, bool BWD, bool STW, int R, int Ns, typename IO>
+template <typename Cfg, bool BWD, int STW, int R, int Ns, typename IO>
 PFA_DEV void strided_store_butterfly(const IO& io, const strided_args& a, unsigned f, unsigned base, bool live,
                                      long long c0, cx<typename Cfg::T> (&v)[R]) {
   using T = typename Cfg::T;
@@ -106,25 +104,24 @@ PFA_DEV void strided_store_butterfly(const IO& io, const strided_args& a, unsign
   // store modifier W_M^{k*c}, k = base + u*Ns: W^{base*c}, the step W^{Ns*c} and every fourth power of the step
   // come from the hi/lo tables, the other powers are one multiply away from those
   [[maybe_unused]] cx<T> stw[R];
-  if constexpr (STW) {
+  if constexpr (STW != 0) {
     unsigned long long stw_c = static_cast<unsigned long long>(c0 + f);
     if (a.stw_cdiv > 1) stw_c /= static_cast<unsigned long long>(a.stw_cdiv);
-    const cx<T>* lo = static_cast<const cx<T>*>(a.stw_lo);
-    const cx<T>* hi = static_cast<const cx<T>*>(a.stw_hi);
-#ifdef PFA_STW_FAKE_UNIFORM  // tuner only: every table index 0 (the cost of the gathers, not of the arithmetic)
-    const unsigned long long mask = 0;
-    stw_c = 0;
-#else
-    const unsigned long long mask = (1ull << a.stw_shift) - 1;
-#endif
     const unsigned long long m0 = static_cast<unsigned long long>(base) * stw_c;
     const unsigned long long ms = static_cast<unsigned long long>(Ns) * stw_c;
-    // W^m: from the small multi-level tables in LDS when the plan put them there (strided_copy_stw), else from the
-    // two global tables (scattered 16-byte gathers through the vector memory path: 4.5 % of the C3 stage-A time)
-    const bool in_lds = a.stw_levels > 0;
+    // W^m: STW == 1 from the small multi-level tables in LDS (strided_copy_stw) -- two L2-resident tables read with
+    // scattered 16-byte gathers cost the pre-compiled stage kernels 4.5 % (C3 stage A) to 15 % (fp32 n = 1024) --,
+    // STW == 2 from those two global tables (hi/lo split of the exponent): kernels that are bound by their
+    // arithmetic and LDS traffic, not by the vector memory path (runtime-planned odd radices with several
+    // work-groups per CU: fp32 N = 30000 stage A 144 us with gathers, 185 us with three-level LDS tables)
     auto root = [&](unsigned long long m) PFA_LAMBDA -> cx<T> {
-      if (in_lds) return stw_from_lds<Cfg>(a, m);
-      return cmul(lo[m & mask], hi[m >> a.stw_shift]);
+      if constexpr (STW == 2) {
+        const cx<T>* lo = static_cast<const cx<T>*>(a.stw_lo);
+        const cx<T>* hi = static_cast<const cx<T>*>(a.stw_hi);
+        return cmul(lo[m & ((1ull << a.stw_shift) - 1)], hi[m >> a.stw_shift]);
+      } else {
+        return stw_from_lds<Cfg>(a, m);
+      }
     };
     const cx<T> w0 = root(m0);
     // stw[u] = W^{(base + u*Ns)*c} = w0 * step^u.  Every fourth one is w0 times a table value (anchor), the
@@ -151,7 +148,7 @@ PFA_DEV void strided_store_butterfly(const IO& io, const strided_args& a, unsign
   sfor<0, R>([&](auto u_) PFA_LAMBDA {
     constexpr int u = decltype(u_)::value;
     cx<T> y = v[u];
-    if constexpr (STW) y = cmul(y, stw[u]);
+    if constexpr (STW != 0) y = cmul(y, stw[u]);
     if constexpr (BWD) y.im = -y.im;
     y.re *= scale;
     y.im *= scale;
@@ -173,7 +170,7 @@ constexpr bool tin_supported() {
          (Cfg::N / Cfg::Seq::r[0]) % Cfg::FPW == 0 && (Cfg::N / Cfg::Seq::r[0]) % Cfg::TPF == 0;
 }
 
-template <typename Cfg, bool BWD, bool STW, int P, typename IO, bool ROW_IN = false, bool ROW_OUT = false,
+template <typename Cfg, bool BWD, int STW, int P, typename IO, bool ROW_IN = false, bool ROW_OUT = false,
           bool TIN = false>
 PFA_DEV void strided_pass(const IO& io, const strided_args& a, unsigned f,
                           unsigned tid, bool live, long long c0, cx<typename Cfg::T>* lds,
@@ -277,7 +274,7 @@ PFA_DEV void strided_pass(const IO& io, const strided_args& a, unsigned f,
   if constexpr (!last) __syncthreads();
 }
 
-template <typename Cfg, bool BWD, bool STW, int P, typename IO, bool ROW_IN = false, bool ROW_OUT = false,
+template <typename Cfg, bool BWD, int STW, int P, typename IO, bool ROW_IN = false, bool ROW_OUT = false,
           bool TIN = false>
 PFA_DEV void strided_passes(const IO& io, const strided_args& a, unsigned f, unsigned tid, bool live, long long c0,
                             cx<typename Cfg::T>* lds, const cx<typename Cfg::T>* __restrict__ tw,
@@ -400,7 +397,7 @@ PFA_DEV void strided_copy_twiddles(cx<typename Cfg::T>* lds, const cx<typename C
 
 /// Software-pipelined strided kernel: the loads of the work-group's next group are in flight during the LDS passes
 /// of the current one (see stockham_wg_prefetch_kernel).
-template <typename Cfg, bool BWD, bool STW, int SPLIT = 0>
+template <typename Cfg, bool BWD, int STW, int SPLIT = 0>
 __global__ __launch_bounds__(Cfg::WG, Cfg::OCC) void stockham_strided_prefetch_kernel(const strided_args a) {
   using T = typename Cfg::T;
   static_assert(Cfg::NP >= 2, "the strided tier needs at least two passes (LDS exchange)");
@@ -535,7 +532,7 @@ PFA_DEV void strided_copy_twiddles(cx<typename Cfg::T>* lds, const cx<typename C
   }
 }
 
-template <typename Cfg, bool BWD, bool STW, int SPLIT = 0, bool TIN = false>
+template <typename Cfg, bool BWD, int STW, int SPLIT = 0, bool TIN = false>
 __global__ __launch_bounds__(Cfg::WG, Cfg::OCC) void stockham_strided_kernel(const strided_args a) {
   using T = typename Cfg::T;
   // (a single-pass plan -- one lane per FFT, the reference's WORKITEM tier on strided data -- uses no LDS at all)

@@ -110,7 +110,7 @@ PFA_DEV void hx_passes(cx<typename Cfg::T> (&v)[Cfg::bpt(P)][Cfg::Seq::r[P]], co
       constexpr int i = decltype(i_)::value;
       const unsigned j = tid + i * Cfg::TPF;
       const unsigned base = (j / Ns) * (Ns * R) + j % Ns;
-      strided_store_butterfly<Cfg, BWD, STW, R, Ns>(io, a, f, base, live, c0, v[i]);
+      strided_store_butterfly<Cfg, BWD, (STW ? 2 : 0), R, Ns>(io, a, f, base, live, c0, v[i]);  // global tables
     });
   } else {
     cx<T> n[Cfg::bpt(P + 1)][Seq::r[P + 1]];

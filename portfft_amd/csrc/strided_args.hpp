@@ -17,16 +17,18 @@ struct strided_args {
   unsigned in_stride, out_stride;  // element stride inside one FFT
   unsigned in_fdist, out_fdist;    // distance between consecutive FFTs of a group
   double scale;
-  const void* stw_lo;
-  const void* stw_hi;
-  int stw_shift;
-  long long stw_cdiv;  // store-modifier column index c = (inner index) / stw_cdiv  (1 for packed data)
-  /// Store-modifier tables in LDS (stw_levels > 0): stw_levels tables of 2^stw_lshift entries, contiguous at
-  /// stw_tab; table l holds W_M^(i << (l * stw_lshift)), so W_M^m is the product of one entry per table.  Copied
-  /// behind the kernel's own LDS once per work-group; 0: the two global tables stw_lo / stw_hi above.
+  /// Store modifier W_M^(k * c) (STW kernels): stw_levels tables of 2^stw_lshift entries, contiguous at stw_tab;
+  /// table l holds W_M^(i << (l * stw_lshift)), so W_M^m is the product of one entry per table.  The kernel copies
+  /// them behind its own LDS once per work-group (the launch adds (stw_levels << stw_lshift) complex elements).
   const void* stw_tab;
   int stw_levels;
   int stw_lshift;
+  long long stw_cdiv;  // store-modifier column index c = (inner index) / stw_cdiv  (1 for packed data)
+  /// ... or (kernels instantiated with STW == 2) two global tables: W_M^m = stw_lo[m & (2^stw_shift - 1)] *
+  /// stw_hi[m >> stw_shift]
+  const void* stw_lo;
+  const void* stw_hi;
+  int stw_shift;
   /// group-major ("tiled") sides: when non-zero, group g of that side starts at g * gdist and (o, c) play no role in
   /// its address -- an intermediate written by one stage for the next can then be contiguous per work-group
   long long in_gdist, out_gdist;

@@ -27,7 +27,7 @@ static std::vector<variant> g_variants;
 static void *g_in, *g_out;
 static long long g_total, g_inner, g_dist_outer; static unsigned g_stride; static int g_tiled = 0;
 
-static void *g_stw_lo, *g_stw_hi; static int g_stw_shift = 10;
+static void* g_stw_tab;  // store-modifier tables of M = 2^20: 3 levels x 128 entries (strided_args::stw_tab)
 template <typename Cfg, int KIND, bool STW = false>
 void add(const char* name) {
   using T = typename Cfg::T;
@@ -38,13 +38,14 @@ void add(const char* name) {
   if constexpr (KIND == 1) fn = (const void*)&stockham_strided_prefetch_kernel<Cfg, false, STW>;
   else if constexpr (KIND == 2) fn = (const void*)&stockham_strided_hx_kernel<Cfg, false, STW>;
   else fn = (const void*)&stockham_strided_kernel<Cfg, false, STW>;
-  constexpr size_t lds = KIND == 2 ? strided_hx_lds_bytes<Cfg>() : strided_lds_bytes<Cfg>();
+  static_assert(!(KIND == 2 && STW), "the half-exchange experiment has no store-modifier form");
+  constexpr size_t lds = (KIND == 2 ? strided_hx_lds_bytes<Cfg>() : strided_lds_bytes<Cfg>()) + (STW ? 3 * 128 * sizeof(cx<T>) : 0);
   CK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   g_variants.push_back({std::string(name) + (STW ? " +stw" : ""), Cfg::FPW, Cfg::WG, lds, fn, [d_tw](unsigned grid) {
     strided_args a{};
     a.in = g_in; a.out = g_out; a.tw = d_tw; a.total = g_total; a.inner = g_inner;
     a.in_dist_outer = a.out_dist_outer = g_dist_outer; a.in_stride = a.out_stride = g_stride; a.in_fdist = a.out_fdist = 1; a.scale = 1.0;
-    a.stw_lo = g_stw_lo; a.stw_hi = g_stw_hi; a.stw_shift = g_stw_shift; a.stw_cdiv = 1;
+    a.stw_tab = g_stw_tab; a.stw_levels = 3; a.stw_lshift = 7; a.stw_cdiv = 1;
     if (g_tiled & 1) { a.in_gdist = (long long)Cfg::N * Cfg::FPW; a.in_stride = Cfg::FPW; }
     if (g_tiled & 2) { a.out_gdist = (long long)Cfg::N * Cfg::FPW; a.out_stride = Cfg::FPW; }
     if constexpr (KIND == 1) hipLaunchKernelGGL((stockham_strided_prefetch_kernel<Cfg, false, STW>), dim3(grid), dim3(Cfg::WG), lds, 0, a);
@@ -63,24 +64,24 @@ int main() {
   }
   hipDeviceProp_t prop; CK(hipGetDeviceProperties(&prop, 0)); const int cus = prop.multiProcessorCount;
   using f = float; using d = double; constexpr int NT = 2;
-  {  // store-modifier tables of M = 2^20 (hi/lo split, shift 10), in the precision of the case
+  {  // store-modifier tables of M = 2^20 (three levels of 128 entries), in the precision of the case
 #if TUNE_CASE == 3
     using TT = double;
 #else
     using TT = float;
 #endif
-    std::vector<cx<TT>> lo(1 << 10), hi((1 << 10) + 1);
-    for (int i = 0; i < (1 << 10); ++i) { const long double a = -2.0L * 3.14159265358979323846264338327950288L * i / 1048576.0L; lo[i] = {(TT)cosl(a), (TT)sinl(a)}; }
-    for (int i = 0; i <= (1 << 10); ++i) { const long double a = -2.0L * 3.14159265358979323846264338327950288L * ((i * 1024) % 1048576) / 1048576.0L; hi[i] = {(TT)cosl(a), (TT)sinl(a)}; }
-    CK(hipMalloc(&g_stw_lo, lo.size() * sizeof(lo[0]))); CK(hipMemcpy(g_stw_lo, lo.data(), lo.size() * sizeof(lo[0]), hipMemcpyHostToDevice));
-    CK(hipMalloc(&g_stw_hi, hi.size() * sizeof(hi[0]))); CK(hipMemcpy(g_stw_hi, hi.data(), hi.size() * sizeof(hi[0]), hipMemcpyHostToDevice));
+    std::vector<cx<TT>> tab(3 * 128);
+    for (int l = 0; l < 3; ++l) for (int i = 0; i < 128; ++i) {
+      const long double a = -2.0L * 3.14159265358979323846264338327950288L * (((long long)i << (7 * l)) % 1048576) / 1048576.0L;
+      tab[l * 128 + i] = {(TT)cosl(a), (TT)sinl(a)};
+    }
+    CK(hipMalloc(&g_stw_tab, tab.size() * sizeof(tab[0]))); CK(hipMemcpy(g_stw_tab, tab.data(), tab.size() * sizeof(tab[0]), hipMemcpyHostToDevice));
   }
 #if TUNE_CASE == 3
   using T = d; g_stride = 1024; g_inner = 1024; g_dist_outer = 1 << 20; g_total = 128 * 1024;
   add<wg_cfg<d, radix_list<16, 8, 8>, 512, 8, 0, 0, TW_GLOBAL, 2, NT, 0, 1>, 0>("f64 16.8.8 wg512 fpw8 TWL1 (production)");
   add<wg_cfg<d, radix_list<16, 8, 8>, 512, 8, 0, 0, TW_GLOBAL, 2, NT, 0, 1>, 0, true>("f64 16.8.8 wg512 fpw8 TWL1 (production)");
   add<wg_cfg<d, radix_list<16, 8, 8>, 512, 8, 0, 0, TW_GLOBAL, 2, NT, 0, 1>, 2>("HX f64 16.8.8 wg512 fpw8 TWL1");
-  add<wg_cfg<d, radix_list<16, 8, 8>, 512, 8, 0, 0, TW_GLOBAL, 2, NT, 0, 1>, 2, true>("HX f64 16.8.8 wg512 fpw8 TWL1");
   add<wg_cfg<d, radix_list<16, 8, 8>, 256, 8, 0, 0, TW_GLOBAL, 1, NT, 0, 1>, 2>("HX f64 16.8.8 wg256(32pt) fpw8 TWL1");
   add<wg_cfg<d, radix_list<16, 8, 8>, 512, 16, 0, 0, TW_GLOBAL, 2, NT, 0, 1>, 2>("HX f64 16.8.8 wg512(32pt) fpw16 TWL1");
   // software-pipelined loads (next group's loads in flight during the passes)
@@ -102,6 +103,13 @@ int main() {
   add<wg_cfg<f, radix_list<16, 8, 8>, 1024, 16, 0, 0, TW_GLOBAL, 4, NT, 0, 2>, 0>("f32 16.8.8 wg1024 fpw16 TWL2");
   add<wg_cfg<f, radix_list<16, 8, 8>, 512, 8, 0, 0, TW_GLOBAL, 4, NT>, 0>("f32 16.8.8 wg512 fpw8");
   add<wg_cfg<f, radix_list<16, 8, 8>, 512, 8, 0, 0, TW_GLOBAL, 2, NT>, 1>("f32 16.8.8 wg512 fpw8 PF");
+  // half-exchange forms (half-size LDS image: two work-groups per CU at 16 columns)
+  add<wg_cfg<f, radix_list<32, 32>, 512, 16, 0, 0, TW_GLOBAL, 2, NT>, 2>("HX f32 32.32 wg512 fpw16");
+  add<wg_cfg<f, radix_list<16, 8, 8>, 1024, 16, 0, 0, TW_GLOBAL, 2, NT>, 2>("HX f32 16.8.8 wg1024 fpw16");
+  add<wg_cfg<f, radix_list<16, 8, 8>, 512, 16, 0, 0, TW_GLOBAL, 2, NT>, 2>("HX f32 16.8.8 wg512(32pt) fpw16");
+  add<wg_cfg<f, radix_list<32, 32>, 1024, 32, 0, 0, TW_GLOBAL, 1, NT>, 2>("HX f32 32.32 wg1024 fpw32");
+  add<wg_cfg<f, radix_list<16, 8, 8>, 1024, 32, 0, 0, TW_GLOBAL, 1, NT>, 2>("HX f32 16.8.8 wg1024(32pt) fpw32");
+  add<wg_cfg<f, radix_list<32, 32>, 512, 16, 0, 0, TW_GLOBAL, 2, NT>, 1, true>("f32 32.32 wg512 fpw16 PF");
 #endif
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   struct gridopt { const char* name; int mode; int k; };
