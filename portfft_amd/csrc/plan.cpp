@@ -697,29 +697,6 @@ struct plan_t {
     return s;
   }
 
-  /// Two-tier grid of a large launch: `grid` work-groups of k = ceil(groups / grid) groups each become tier_main
-  /// work-groups of k groups for the first three quarters of the groups plus work-groups of max(1, k / 2) groups for
-  /// the rest (stockham_wg.hpp tiered_range).  Returns the grid to launch; tier_main = 0 when the launch is too small
-  /// or already runs one group per work-group.  PFFT_UNIFORM_GRID switches it off.
-  unsigned two_tier(unsigned grid, long long groups, long long* tier_main, int* tier_k) const {
-    *tier_main = 0;
-    *tier_k = 0;
-    // Measured (bench.py, alternating runs on one box): C3 1.6137-1.6365 vs 1.6126-1.6394 ms uniform, ref65536 equal,
-    // C5 1.407-1.423 vs 1.389-1.406 ms uniform (1.2 % SLOWER) -- unlike the headline kernel (+1.6 %), whose work-groups
-    // pay a twiddle preload and an un-prefetched first load per lifetime.  Off unless PFFT_TWO_TIER_ALL is set.
-    static const bool enabled = getenv("PFFT_TWO_TIER_ALL") != nullptr && getenv("PFFT_UNIFORM_GRID") == nullptr;
-    if (!enabled || grid == 0) return grid;
-    const long long k = (groups + grid - 1) / grid;
-    if (k < 2 || static_cast<long long>(grid) < 8ll * n_cus) return grid;
-    const long long main = (static_cast<long long>(grid) * 3 / 4) / n_cus * n_cus;
-    const long long rest = groups - k * main;
-    if (main <= 0 || rest <= 0) return grid;
-    const long long tail_k = std::max<long long>(1, k / 2);
-    *tier_main = main;
-    *tier_k = static_cast<int>(k);
-    return static_cast<unsigned>(main + (rest + tail_k - 1) / tail_k);
-  }
-
   /// the launch grid of a chunked stage is sized for ONE chunk (`count` FFTs / `nmat` matrices), not for the whole
   /// batch: the per-kernel rule "groups_per_wg groups per work-group" must hold inside a chunk
   void regrid_for_chunk(stage& s, long long count) {
@@ -1480,7 +1457,6 @@ struct plan_t {
       }
       const long long groups = a.nmat * (a.n0 / s.rows2d->rc);
       unsigned grid = static_cast<unsigned>(std::min<long long>(s.grid, std::max<long long>(groups, 1)));
-      grid = two_tier(grid, groups, &a.tier_main, &a.tier_k);
       hip_check(s.rows2d->launch != nullptr
                     ? (split ? s.rows2d->launch_split : s.rows2d->launch)(stream, grid, a, s.backward)
                     : jit_launch_rows2d(s.rows2d, stream, grid, a, s.backward),
@@ -1493,7 +1469,6 @@ struct plan_t {
       a.total = count;
       const long long groups = strided_groups(count, a.inner, s.strided->fpw);
       unsigned grid = static_cast<unsigned>(std::min<long long>(s.grid, std::max<long long>(groups, 1)));
-      grid = two_tier(grid, groups, &a.tier_main, &a.tier_k);
       if (split && (s.in_buf == BUF_SCRATCH) != (s.out_buf == BUF_SCRATCH)) {  // mixed storage (four-step stages)
         const bool in_user = s.in_buf != BUF_SCRATCH;
         const size_t iu = in_user ? sb : elem_bytes(), ou = in_user ? elem_bytes() : sb;

@@ -112,8 +112,7 @@ __global__ __launch_bounds__(Cfg::WG, Cfg::OCC) void stockham_rows2d_kernel(cons
   const long long M = a.n0 / RC;
   const long long ngroups = a.nmat * M;
   const unsigned row_gap = static_cast<unsigned>(M) * N * ES;
-  const group_range_t gr = tiered_range(ngroups, a.tier_main, a.tier_k);
-  for (long long g = gr.g; g < gr.end; g += gr.stride) {
+  for (long long g = blockIdx.x; g < ngroups; g += gridDim.x) {
     const long long m = g / M;
     const unsigned b = static_cast<unsigned>(g - m * M);
     IO io;

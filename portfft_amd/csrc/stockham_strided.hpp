@@ -406,9 +406,9 @@ __global__ __launch_bounds__(Cfg::WG, Cfg::OCC) void stockham_strided_prefetch_k
   const unsigned f = threadIdx.x % Cfg::FPW;
   const unsigned tid = threadIdx.x / Cfg::FPW;
   const cx<T>* __restrict__ tw = static_cast<const cx<T>*>(a.tw);
-  const group_range_t gr = tiered_range(strided_ngroups<Cfg>(a), a.tier_main, a.tier_k);
-  long long g = gr.g;
-  if (g >= gr.end) return;
+  const long long ngroups = strided_ngroups<Cfg>(a);
+  long long g = blockIdx.x;
+  if (g >= ngroups) return;
   strided_copy_twiddles<Cfg>(lds, tw);
   strided_copy_stw<Cfg, STW>(a);
   cx<T> cur[Cfg::bpt(0)][Cfg::Seq::r[0]];
@@ -418,10 +418,10 @@ __global__ __launch_bounds__(Cfg::WG, Cfg::OCC) void stockham_strided_prefetch_k
   auto io = strided_group<Cfg, SPLIT>(a, g, f, &live, &c0);
   auto io_n = io;
   strided_pass0_load<Cfg, BWD>(io, a, f, tid, live, cur);
-  for (; g < gr.end; g += gr.stride) {
+  for (; g < ngroups; g += gridDim.x) {
     strided_pass0_compute<Cfg>(cur, f, tid, lds);
-    const long long gn = g + gr.stride;
-    if (gn < gr.end) {
+    const long long gn = g + gridDim.x;
+    if (gn < ngroups) {
       io_n = strided_group<Cfg, SPLIT>(a, gn, f, &live_n, &c0_n);
       strided_pass0_load<Cfg, BWD>(io_n, a, f, tid, live_n, nxt);
     }
@@ -450,8 +450,8 @@ __global__ __launch_bounds__(Cfg::WG, Cfg::OCC) void stockham_strided_row_kernel
   const unsigned f = threadIdx.x % Cfg::FPW;
   const unsigned tid = threadIdx.x / Cfg::FPW;
   const cx<T>* __restrict__ tw = static_cast<const cx<T>*>(a.tw);
-  const group_range_t gr = tiered_range(strided_ngroups<Cfg>(a), a.tier_main, a.tier_k);
-  for (long long g = gr.g; g < gr.end; g += gr.stride) {
+  const long long ngroups = strided_ngroups<Cfg>(a);
+  for (long long g = blockIdx.x; g < ngroups; g += gridDim.x) {
     bool live;
     long long c0;
     long long left;
@@ -544,8 +544,9 @@ __global__ __launch_bounds__(Cfg::WG, Cfg::OCC) void stockham_strided_kernel(con
   const long long ngroups = strided_ngroups<Cfg>(a);
   strided_copy_twiddles<Cfg>(lds, tw);
   strided_copy_stw<Cfg, STW>(a);
-  const group_range_t gr = tiered_range(ngroups, a.tier_main, a.tier_k);
-  for (long long g = gr.g; g < gr.end; g += gr.stride) {
+  // (a two-tier grid like the headline kernel's was measured here: neutral on C3 / ref65536, 1.2 % slower on C5, and
+  //  the extra loop state alone cost the fp64 n = 256 row-in / column-out shape 15 % -- plain grid-stride loop)
+  for (long long g = blockIdx.x; g < ngroups; g += gridDim.x) {
     bool live;
     long long c0;
     long long nlive;

@@ -630,27 +630,6 @@ PFA_DEV void stockham_wg_body(MakeIO&& make_io, const cx<typename Cfg::T>* __res
   }
 }
 
-#ifndef PFA_GROUP_RANGE_DEFINED
-#define PFA_GROUP_RANGE_DEFINED
-struct group_range_t {
-  long long g, stride, end;
-};
-/// first group, stride and end of this work-group's loop under the two-tier grid (tier_main == 0: uniform grid)
-PFA_DEV group_range_t tiered_range(long long ngroups, long long tier_main, int tier_k) {
-  group_range_t r{static_cast<long long>(blockIdx.x), static_cast<long long>(gridDim.x), ngroups};
-  if (tier_main > 0) {
-    if (r.g < tier_main) {
-      r.stride = tier_main;
-      r.end = tier_k * tier_main;
-    } else {
-      r.stride = static_cast<long long>(gridDim.x) - tier_main;
-      r.g = tier_k * tier_main + (r.g - tier_main);
-    }
-  }
-  return r;
-}
-#endif
-
 /// Persistent work-group kernel, interleaved complex: work-group g handles FFT groups g, g+G, ...
 /// `in` and `out` may be the same buffer (the in-place overloads, N-D passes on the output): the data pointers of the
 /// kernels in this file are deliberately NOT __restrict__; only the twiddle tables are.

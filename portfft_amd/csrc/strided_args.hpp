@@ -46,11 +46,6 @@ struct strided_args {
   /// index already has a meaning inside a matrix (second stage of a long column transform of an N-D array).
   long long outer_lo;
   long long in_dist_outer_hi, out_dist_outer_hi;
-  /// two-tier grid (tier_main > 0): work-groups [0, tier_main) take tier_k groups each (b, b + tier_main, ...), the
-  /// remaining work-groups share the groups behind tier_k * tier_main.  The many short work-groups at the end of a
-  /// launch balance it at a finer grain (see stockham_wg_prefetch_kernel).
-  long long tier_main;
-  int tier_k;
   int any_order;  // host side only: launch without the in-order barrier (pfa_launch)
 };
 
@@ -64,8 +59,6 @@ struct rows2d_args {
   const void* twc;  // W_n0^m, m in [0, n0)
   long long nmat;   // matrices (batch x leading dimensions)
   int n0;           // rows per matrix; n0 % RC == 0
-  int tier_k;       // two-tier grid, as in strided_args
-  long long tier_main;
   const void* in_im;  // imaginary planes (split-storage form only)
   void* out_im;
   int any_order;  // host side only: launch without the in-order barrier (pfa_launch)
