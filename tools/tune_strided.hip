@@ -65,7 +65,7 @@ int main() {
   hipDeviceProp_t prop; CK(hipGetDeviceProperties(&prop, 0)); const int cus = prop.multiProcessorCount;
   using f = float; using d = double; constexpr int NT = 2;
   {  // store-modifier tables of M = 2^20 (three levels of 128 entries), in the precision of the case
-#if TUNE_CASE == 3
+#if TUNE_CASE == 3 || TUNE_CASE == 4
     using TT = double;
 #else
     using TT = float;
@@ -77,7 +77,17 @@ int main() {
     }
     CK(hipMalloc(&g_stw_tab, tab.size() * sizeof(tab[0]))); CK(hipMemcpy(g_stw_tab, tab.data(), tab.size() * sizeof(tab[0]), hipMemcpyHostToDevice));
   }
-#if TUNE_CASE == 3
+#if TUNE_CASE == 4
+  // cache-policy bits of the loads of the C3 stage kernel (1 = sc0, 2 = nt, 16 = sc1; AUX = (stores + 1) << 8 | loads)
+  using T = d; g_stride = 1024; g_inner = 1024; g_dist_outer = 1 << 20; g_total = 128 * 1024;
+  add<wg_cfg<d, radix_list<16, 8, 8>, 512, 8, 0, 0, TW_GLOBAL, 2, NT, 0, 1>, 0, true>("loads nt stores nt");
+  add<wg_cfg<d, radix_list<16, 8, 8>, 512, 8, 0, 0, TW_GLOBAL, 2, ((2 + 1) << 8) | 0, 0, 1>, 0, true>("loads plain stores nt");
+  add<wg_cfg<d, radix_list<16, 8, 8>, 512, 8, 0, 0, TW_GLOBAL, 2, ((2 + 1) << 8) | 1, 0, 1>, 0, true>("loads sc0 stores nt");
+  add<wg_cfg<d, radix_list<16, 8, 8>, 512, 8, 0, 0, TW_GLOBAL, 2, ((2 + 1) << 8) | 16, 0, 1>, 0, true>("loads sc1 stores nt");
+  add<wg_cfg<d, radix_list<16, 8, 8>, 512, 8, 0, 0, TW_GLOBAL, 2, ((2 + 1) << 8) | 18, 0, 1>, 0, true>("loads nt|sc1 stores nt");
+  add<wg_cfg<d, radix_list<16, 8, 8>, 512, 8, 0, 0, TW_GLOBAL, 2, ((2 + 1) << 8) | 3, 0, 1>, 0, true>("loads nt|sc0 stores nt");
+  add<wg_cfg<d, radix_list<16, 8, 8>, 512, 8, 0, 0, TW_GLOBAL, 2, ((18 + 1) << 8) | 2, 0, 1>, 0, true>("loads nt stores nt|sc1");
+#elif TUNE_CASE == 3
   using T = d; g_stride = 1024; g_inner = 1024; g_dist_outer = 1 << 20; g_total = 128 * 1024;
   add<wg_cfg<d, radix_list<16, 8, 8>, 512, 8, 0, 0, TW_GLOBAL, 2, NT, 0, 1>, 0>("f64 16.8.8 wg512 fpw8 TWL1 (production)");
   add<wg_cfg<d, radix_list<16, 8, 8>, 512, 8, 0, 0, TW_GLOBAL, 2, NT, 0, 1>, 0, true>("f64 16.8.8 wg512 fpw8 TWL1 (production)");
