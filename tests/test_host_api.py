@@ -32,6 +32,29 @@ def test_struct_layout_matches_between_binding_and_oracle(oracle):
         assert getattr(_lib.pfft_desc_t, n1).offset == getattr(oracle.Desc, n2).offset
 
 
+def test_struct_layout_matches_the_header(tmp_path):
+    """sizes and field offsets of the C structs in include/portfft_amd.h (compiled with gcc) against the ctypes mirror"""
+    import subprocess
+    from portfft_amd import _lib
+    structs = {"pfft_desc_t": _lib.pfft_desc_t, "pfft_dim_info_t": _lib.pfft_dim_info_t,
+               "pfft_plan_info_t": _lib.pfft_plan_info_t}
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "portfft_amd.h"', 'int main(void) {']
+    for name, cls in structs.items():
+        lines.append('  printf("%s %%zu\\n", sizeof(%s));' % (name, name))
+        for field, _ in cls._fields_:
+            lines.append('  printf("%s.%s %%zu\\n", offsetof(%s, %s));' % (name, field, name, field))
+    lines += ['  return 0;', '}']
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+    got = dict(l.split() for l in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.splitlines())
+    for name, cls in structs.items():
+        assert int(got[name]) == ctypes.sizeof(cls), name
+        for field, _ in cls._fields_:
+            assert int(got["%s.%s" % (name, field)]) == getattr(cls, field).offset, (name, field)
+
+
 def test_descriptor_defaults_and_getters():
     """test/unit_test/descriptor.cpp:29-74"""
     import portfft_amd as pf
