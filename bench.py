@@ -214,7 +214,8 @@ def main():
     esz = 8 if prec == "f32" else 16
 
     world, rank, local_rank = env_world()
-    distributed = world > 1
+    # PFFT_BENCH_FORCE_DIST=1: run the multi-rank plumbing (gloo control group + RCCL sub-group) at any world size
+    distributed = world > 1 or os.environ.get("PFFT_BENCH_FORCE_DIST") == "1"
     if distributed:
         # one node: keep gloo's and RCCL's bootstrap sockets on the loopback interface (the container hostname may not
         # resolve to a usable interface); data never crosses these sockets -- the ranks exchange a few scalars

@@ -193,6 +193,14 @@ struct device_guard {
   device_guard& operator=(const device_guard&) = delete;
 };
 
+/// Per-launch state of the chunk-overlap paths.  It travels as an argument of run_stage, never as plan state: a
+/// launch that throws cannot leave a later execute() with a barrier-free launch or a shifted scratch base.
+struct launch_ctx {
+  bool on_aux = false;       // launch on aux_stream
+  bool any_order = false;    // launch without the in-order barrier (strided / rows2d stages)
+  size_t scratch_shift = 0;  // bytes added to the scratch base (the half of a double-buffered scratch in use)
+};
+
 struct plan_t {
   pfft_desc_t desc{};
   hipStream_t stream = nullptr;
@@ -215,9 +223,6 @@ struct plan_t {
   // runs on the plan's stream, so the tail of one fills with the head of the other
   hipStream_t aux_stream = nullptr;
   std::vector<hipEvent_t> chunk_events;
-  bool on_aux = false;              // run_stage launches on aux_stream
-  bool any_order = false;           // run_stage launches without the in-order barrier (strided / rows2d stages)
-  size_t scratch_shift = 0;         // bytes added to the scratch base (the half of a double-buffered scratch in use)
   size_t overlap_scratch_half = 0;  // bytes of one half when the chunks of a four-step plan double-buffer the scratch
 
   /// How consecutive chunks of a two-launch plan overlap (PFFT_CHUNK_OVERLAP):
@@ -1418,7 +1423,9 @@ struct plan_t {
 
   /// run stage `s` for the user transforms [b0, b0 + nb) (chunked stages) or entirely (nb < 0)
   void run_stage(const stage& s, const void* in_re, const void* in_im, void* out_re, void* out_im, long long b0 = 0,
-                 long long nb = -1) {
+                 long long nb = -1, const launch_ctx& lc = launch_ctx()) {
+    const bool on_aux = lc.on_aux, any_order = lc.any_order;
+    const size_t scratch_shift = lc.scratch_shift;
     const long long in_shift = nb < 0 ? 0 : b0 * s.in_batch_dist;    // elements
     const long long out_shift = nb < 0 ? 0 : b0 * s.out_batch_dist;  // elements
     const long long count = nb < 0 ? s.count : nb * s.ffts_per_batch;
@@ -1595,13 +1602,13 @@ struct plan_t {
       size_t c = 0;
       for (long long b0 = 0; b0 < batches; b0 += chunk_batches, ++c) {
         const long long nb = std::min(chunk_batches, batches - b0);
-        scratch_shift = (c & 1) * overlap_scratch_half;
-        any_order = c > 0;
-        run_stage(a, in_re, in_im, out_re, out_im, b0, nb);
-        any_order = false;
-        run_stage(b, in_re, in_im, out_re, out_im, b0, nb);
+        launch_ctx lc;
+        lc.scratch_shift = (c & 1) * overlap_scratch_half;
+        lc.any_order = c > 0;
+        run_stage(a, in_re, in_im, out_re, out_im, b0, nb, lc);
+        lc.any_order = false;
+        run_stage(b, in_re, in_im, out_re, out_im, b0, nb, lc);
       }
-      scratch_shift = 0;
       return;
     }
     if (aux_stream == nullptr) {
@@ -1616,21 +1623,20 @@ struct plan_t {
     size_t c = 0;
     for (long long b0 = 0; b0 < batches; b0 += chunk_batches, ++c) {
       const long long nb = std::min(chunk_batches, batches - b0);
-      scratch_shift = (c & 1) * overlap_scratch_half;
+      launch_ctx lc;
+      lc.scratch_shift = (c & 1) * overlap_scratch_half;
       if (c >= 2 && overlap_scratch_half > 0) {  // this half of the scratch was last read by chunk c - 2
         hip_check(hipStreamWaitEvent(stream, chunk_events[n_chunks + c - 2], 0), "hipStreamWaitEvent");
       }
-      run_stage(a, in_re, in_im, out_re, out_im, b0, nb);
+      run_stage(a, in_re, in_im, out_re, out_im, b0, nb, lc);
       hip_check(hipEventRecord(chunk_events[c], stream), "hipEventRecord");
       hip_check(hipStreamWaitEvent(aux_stream, chunk_events[c], 0), "hipStreamWaitEvent");
-      on_aux = true;
-      run_stage(b, in_re, in_im, out_re, out_im, b0, nb);
-      on_aux = false;
+      lc.on_aux = true;
+      run_stage(b, in_re, in_im, out_re, out_im, b0, nb, lc);
       if (c + 1 == n_chunks || overlap_scratch_half > 0) {
         hip_check(hipEventRecord(chunk_events[n_chunks + c], aux_stream), "hipEventRecord");
       }
     }
-    scratch_shift = 0;
     hip_check(hipStreamWaitEvent(stream, chunk_events[2 * n_chunks - 1], 0), "hipStreamWaitEvent");
   }
 

@@ -35,14 +35,17 @@ class process_group:
     and scalar collectives over RCCL or every rank runs them over gloo; a rank never changes backend on its own.
     `backend` after construction says which one carries the barrier ('nccl' or 'gloo')."""
 
-    def __init__(self, backend, device=None, timeout_s=120):
+    def __init__(self, backend, device=None, timeout_s=120, probe_timeout_s=45):
         import datetime
         import torch
         import torch.distributed as dist
         self.torch, self.dist = torch, dist
         self.world, self.rank, self.local_rank = env_world()
         self.device = device if device is not None else torch.device("cpu")
-        self.active = self.world > 1
+        # PFFT_BENCH_FORCE_DIST=1: build the control group and the RCCL sub-group even at world size 1, so that the
+        # whole multi-rank code path (rendezvous, communicator, probe, barrier, max, gather) runs on a 1-GPU box
+        force = os.environ.get("PFFT_BENCH_FORCE_DIST") == "1"
+        self.active = self.world > 1 or force
         self.backend = backend
         self.group = None  # the group the barrier / scalars travel on (None = the default gloo group)
         self.fallback_reason = None
@@ -51,28 +54,52 @@ class process_group:
         if not dist.is_initialized():
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29511")
+            os.environ.setdefault("RANK", str(self.rank))
+            os.environ.setdefault("WORLD_SIZE", str(self.world))
             dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=timeout_s))
         if backend != "nccl":
             self.backend = "gloo"
             self.device = torch.device("cpu")
             return
-        ok, reason, group = 1, "", None
+        # a failed or timed-out RCCL collective must RAISE in the caller (not abort the process from the watchdog
+        # thread), or the collective verdict below is never reached
+        os.environ.setdefault("TORCH_NCCL_BLOCKING_WAIT", "1")
+        os.environ.setdefault("TORCH_NCCL_ASYNC_ERROR_HANDLING", "0")
+
+        def agree(ok):  # over gloo: every rank sees the same verdict
+            flag = torch.tensor([1 if ok else 0], dtype=torch.int32)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            return int(flag.item()) == 1
+
+        reason, group = "", None
+        # step 1: every rank creates the sub-group (no RCCL traffic yet) and the ranks agree that all of them could,
+        # BEFORE the first RCCL collective -- a rank that failed here never leaves the others waiting inside RCCL
         try:
-            # collective: every rank calls new_group; the first all-reduce creates the RCCL communicator -- here, not
-            # inside the timed region
-            group = dist.new_group(backend="nccl", timeout=datetime.timedelta(seconds=timeout_s))
-            probe = torch.ones(1, device=self.device)
-            dist.all_reduce(probe, group=group)
-            torch.cuda.synchronize()
-            if int(probe.item()) != self.world:
-                ok, reason = 0, "probe all-reduce returned %r" % probe.item()
+            group = dist.new_group(backend="nccl", timeout=datetime.timedelta(seconds=probe_timeout_s))
         except Exception as e:  # noqa: BLE001 -- reported below, decided collectively
-            ok, reason = 0, "%s: %s" % (type(e).__name__, str(e).splitlines()[0] if str(e) else "")
-        flag = torch.tensor([ok], dtype=torch.int32)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)  # over gloo: every rank sees the same verdict
-        if int(flag.item()) == 1:
+            reason = "new_group: %s: %s" % (type(e).__name__, str(e).splitlines()[0] if str(e) else "")
+        usable = agree(group is not None)
+        if usable:
+            # step 2: the first all-reduce creates the RCCL communicator -- here, not inside the timed region; the
+            # short group timeout bounds how long healthy ranks wait for one that failed inside RCCL
+            ok = True
+            try:
+                probe = torch.ones(1, device=self.device)
+                dist.all_reduce(probe, group=group)
+                torch.cuda.synchronize()
+                if int(probe.item()) != self.world:
+                    ok, reason = False, "probe all-reduce returned %r" % probe.item()
+            except Exception as e:  # noqa: BLE001
+                ok, reason = False, "probe: %s: %s" % (type(e).__name__, str(e).splitlines()[0] if str(e) else "")
+            usable = agree(ok)
+        if usable:
             self.group = group
         else:
+            if group is not None:
+                try:
+                    dist.destroy_process_group(group)
+                except Exception:  # noqa: BLE001 -- a half-built communicator may refuse; gloo carries on
+                    pass
             self.backend = "gloo"
             self.device = torch.device("cpu")
             self.fallback_reason = reason or "RCCL failed on another rank"
