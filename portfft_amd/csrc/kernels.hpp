@@ -89,6 +89,13 @@ struct strided_kernel {
   /// where the store-modifier forms take their tables from (stockham_strided.hpp, STW): 1 small multi-level tables in
   /// LDS (every pre-compiled entry), 2 two global tables (runtime-specialised entries without LDS headroom)
   int stw_mode;
+  /// four-step (GLOBAL tier) stage entries: fs_a = the entry of its length for stage A (store modifier, writes the
+  /// group-major intermediate), fs_b = for stage B (tiled-input form, launch_tin).  A pair (fs_a, fs_b) with equal
+  /// group widths replaces the default entries of the two lengths (tools/tune_fourstep.hip, profiles/r3_notes.md:
+  /// narrow groups at two to four work-groups per CU beat wide ones at one).  fs_groups_per_wg: grid rule inside
+  /// such a pair (0: groups_per_wg).
+  int fs_a, fs_b, fs_groups_per_wg;
+  int fs_only;  // 1: the entry exists only for such pairs (never the default entry of its length)
 };
 
 /// First pass of the two-pass 2-D plan (stockham_rows2d.hpp): whole row FFTs of length n + the first radix-rc

@@ -15,8 +15,10 @@ std::vector<strided_kernel> build() {
   // groups per work-group: tools/perf_gpw.py -- four-step N=65536 x 2Ki 0.799 ms with one, 0.761 ms with four
   add_strided_entries<strided_cfg<f, radix_list<16, 16>, 512, 32, 2, NT>, SE_ROWS>(v, 4);      // 256
   add_strided_entries<strided_cfg<f, radix_list<8, 8, 8>, 1024, 32, 2, NT>, SE_ROWS>(v, 2);    // 512
-  add_strided_entries<strided_cfg<f, radix_list<32, 32>, 512, 16, 2, NT>, SE_ROWS | SE_PREFETCH>(v, 4);  // 1024
-  add_strided_entries<strided_cfg<f, radix_list<16, 16, 8>, 1024, 8, 4, NT>, SE_ROWS>(v);      // 2048
+  // (SE_FS_B: the four-step stage B of n2 = 1024 -- software-pipelined, lanes element-fastest inside the tiles of the
+  //  group-major intermediate: 86 us per 256 MiB chunk against 113-120 for the row-staged 16.8.8 form)
+  add_strided_entries<strided_cfg<f, radix_list<32, 32>, 512, 16, 2, NT>, SE_ROWS | SE_PREFETCH | SE_TIN | SE_FS_B>(v, 4);  // 1024
+  add_strided_entries<strided_cfg<f, radix_list<16, 16, 8>, 1024, 8, 4, NT>, SE_ROWS | SE_TIN | SE_FS_A | SE_FS_B>(v, 1, 4);  // 2048
   add_strided_entries<strided_cfg<f, radix_list<16, 16, 16>, 1024, 4, 4, NT>, SE_ROWS>(v);     // 4096
   // wide groups (512-byte segments) for stages that are column-shaped on both sides with >= 64 adjacent columns: the
   // second pass of the two-pass 2-D plan (1024 x 1024: n = 128 over 8192 columns) and wide batch-interleaved
@@ -26,7 +28,13 @@ std::vector<strided_kernel> build() {
   add_strided_entries<strided_cfg<f, radix_list<16, 16>, 1024, 64, 2, NT>, SE_WIDE>(v, 1);     // 256
   // n = 1024 with a row-shaped side: 16.8.8 on 1024 lanes stages rows better than the 32.32 prefetch kernel above
   // (four-step N=2^20 2.00 -> 2.15 TB/s, P->BI 3.73 -> 3.89, BI->P 3.99 -> 4.21); column/column stages keep 32.32
-  add_strided_entries<strided_cfg<f, radix_list<16, 8, 8>, 1024, 16, 4, NT>, SE_ROWS | SE_ROWISH>(v, 4);  // 1024
+  add_strided_entries<strided_cfg<f, radix_list<16, 8, 8>, 1024, 16, 4, NT>, SE_ROWS | SE_ROWISH | SE_TIN | SE_FS_A>(v, 4, 8);  // 1024
+  // Four-step stage pairs (tools/tune_fourstep.hip, 256 MiB chunks, writer / reader policies, us per chunk A + B):
+  // 16 columns per group (128-byte segments) at two to four work-groups per CU beat 32 columns at one or two --
+  // N = 65536: 108 + 90 (16.16 on 512 lanes x 32 columns, row-staged stage B) -> 91 + 82; N = 2^18: 117 + 108
+  // (8.8.8 on 1024 lanes x 32 columns) -> 101 + 84.  Only chosen as a pair (strided_kernel::fs_a / fs_b).
+  add_strided_entries<strided_cfg<f, radix_list<16, 16>, 256, 16, 2, NT>, SE_TIN | SE_FS_A | SE_FS_B | SE_FS_ONLY>(v, 4);   // 256
+  add_strided_entries<strided_cfg<f, radix_list<8, 8, 8>, 512, 16, 2, NT>, SE_TIN | SE_FS_A | SE_FS_B | SE_FS_ONLY>(v, 4);  // 512
   return v;
 }
 }  // namespace

@@ -321,24 +321,32 @@ strided_kernel with_rows(strided_kernel k) {
   return k;
 }
 
-template <typename Cfg>
+/// (PF: the software-pipelined kernel's tiled-input form)
+template <typename Cfg, bool PF = false>
 hipError_t launch_strided_tin(hipStream_t stream, unsigned grid, const strided_args& args, int backward) {
   constexpr size_t lds = strided_lds_bytes<Cfg>();
-  if (backward) {
-    hipLaunchKernelGGL((stockham_strided_kernel<Cfg, true, false, 0, true>), dim3(grid), dim3(Cfg::WG), lds, stream, args);
+  const dim3 g(grid), b(Cfg::WG);
+  if constexpr (PF) {
+    if (backward) return pfa_launch(&stockham_strided_prefetch_kernel<Cfg, true, 0, 0, true>, g, b, lds, stream, args);
+    return pfa_launch(&stockham_strided_prefetch_kernel<Cfg, false, 0, 0, true>, g, b, lds, stream, args);
   } else {
-    hipLaunchKernelGGL((stockham_strided_kernel<Cfg, false, false, 0, true>), dim3(grid), dim3(Cfg::WG), lds, stream, args);
+    if (backward) return pfa_launch(&stockham_strided_kernel<Cfg, true, 0, 0, true>, g, b, lds, stream, args);
+    return pfa_launch(&stockham_strided_kernel<Cfg, false, 0, 0, true>, g, b, lds, stream, args);
   }
-  return hipGetLastError();
 }
 
 /// add the tiled-input form (four-step stage B reading a group-major intermediate) to an entry
-template <typename Cfg>
+template <typename Cfg, bool PF = false>
 strided_kernel with_tin(strided_kernel k) {
   static_assert(tin_supported<Cfg>(), "see tin_supported()");
-  k.fn_tin[0] = reinterpret_cast<const void*>(&stockham_strided_kernel<Cfg, false, false, 0, true>);
-  k.fn_tin[1] = reinterpret_cast<const void*>(&stockham_strided_kernel<Cfg, true, false, 0, true>);
-  k.launch_tin = &launch_strided_tin<Cfg>;
+  if constexpr (PF) {
+    k.fn_tin[0] = reinterpret_cast<const void*>(&stockham_strided_prefetch_kernel<Cfg, false, 0, 0, true>);
+    k.fn_tin[1] = reinterpret_cast<const void*>(&stockham_strided_prefetch_kernel<Cfg, true, 0, 0, true>);
+  } else {
+    k.fn_tin[0] = reinterpret_cast<const void*>(&stockham_strided_kernel<Cfg, false, 0, 0, true>);
+    k.fn_tin[1] = reinterpret_cast<const void*>(&stockham_strided_kernel<Cfg, true, 0, 0, true>);
+  }
+  k.launch_tin = &launch_strided_tin<Cfg, PF>;
   return k;
 }
 
@@ -368,15 +376,20 @@ strided_kernel make_strided_entry_prefetch(int groups_per_wg = 4) {
 }
 
 /// flags of add_strided_entries
-enum : unsigned { SE_ROWS = 1, SE_TIN = 2, SE_WIDE = 4, SE_ROWISH = 8, SE_PREFETCH = 16 };
+/// SE_FS_A / SE_FS_B: the entry of its length for the four-step stage A / stage B (strided_kernel::fs_a / fs_b)
+enum : unsigned { SE_ROWS = 1, SE_TIN = 2, SE_WIDE = 4, SE_ROWISH = 8, SE_PREFETCH = 16, SE_FS_A = 32, SE_FS_B = 64, SE_FS_ONLY = 128 };
 
 template <typename Cfg, unsigned F>
 strided_kernel make_strided_entry_flags(int groups_per_wg) {
   strided_kernel k = (F & SE_PREFETCH) ? make_strided_entry_prefetch<Cfg>(groups_per_wg) : make_strided_entry<Cfg>(groups_per_wg);
   if constexpr ((F & SE_ROWS) != 0) k = with_rows<Cfg>(k);
-  if constexpr ((F & SE_TIN) != 0) k = with_tin<Cfg>(k);
+  if constexpr ((F & SE_TIN) != 0) k = with_tin<Cfg, (F & SE_PREFETCH) != 0>(k);
   k.wide = (F & SE_WIDE) != 0;
   k.rowish = (F & SE_ROWISH) != 0;
+  k.fs_a = (F & SE_FS_A) != 0;
+  k.fs_b = (F & SE_FS_B) != 0;
+  k.fs_only = (F & SE_FS_ONLY) != 0;
+  static_assert((F & SE_FS_B) == 0 || (F & SE_TIN) != 0, "a four-step stage-B entry needs its tiled-input form");
   return k;
 }
 
@@ -457,15 +470,16 @@ strided_kernel make_strided_twin(const strided_kernel& base, int policy) {
       k.fn_row[1] = reinterpret_cast<const void*>(&stockham_strided_row_kernel<Cfg, true, true, false>);
       k.launch_row = &launch_strided_row_in<Cfg>;
     }
-    if constexpr ((F & SE_TIN) != 0) k = with_tin<Cfg>(k);
+    if constexpr ((F & SE_TIN) != 0) k = with_tin<Cfg, PF>(k);
   }
   return k;
 }
 
 /// the entry for Cfg (cache policy nt) and its writer / reader twins
 template <typename Cfg, unsigned F = 0>
-void add_strided_entries(std::vector<strided_kernel>& v, int groups_per_wg = 1) {
-  const strided_kernel base = make_strided_entry_flags<Cfg, F>(groups_per_wg);
+void add_strided_entries(std::vector<strided_kernel>& v, int groups_per_wg = 1, int fs_groups_per_wg = 0) {
+  strided_kernel base = make_strided_entry_flags<Cfg, F>(groups_per_wg);
+  base.fs_groups_per_wg = fs_groups_per_wg;
   v.push_back(base);
   v.push_back(make_strided_twin<with_aux_t<Cfg, PFA_AUX_WRITER>, F>(base, 1));
   v.push_back(make_strided_twin<with_aux_t<Cfg, PFA_AUX_READER>, F>(base, 2));

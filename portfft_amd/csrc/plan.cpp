@@ -58,6 +58,7 @@ struct stage {
   int store_modifier = 0;
   int row_mode = 0;  // 0: both sides addressed by the passes, 1: row-shaped input staged, 2: row-shaped output staged
   int tiled_in = 0;  // 1: the kernel's tiled-input form (strided_kernel::launch_tin)
+  int gpw = 0;       // > 0: groups per work-group of this stage instead of the kernel's own rule (four-step pairs)
   int in_buf = BUF_IN, out_buf = BUF_OUT;
   long long count = 0;  // number of FFTs
   unsigned grid = 1;
@@ -420,14 +421,23 @@ struct plan_t {
 
   /// column_both: the stage is column-shaped on both sides -> the wide-group entry of the length, when there is one
   /// row_side: one side of the stage is row-shaped -> the row-friendly entry of the length, when there is one
+  /// fs_stage: 1 / 2 = the length's entry for the four-step stage A / B when there is one (strided_kernel::fs_a / fs_b);
+  /// entries that exist only for such pairs are invisible to every other request
   const strided_kernel* find_strided(long long n, bool column_both = false, bool row_side = false,
-                                     long long inner_count = -1, int policy = 0, bool store_modifier = false) const {
+                                     long long inner_count = -1, int policy = 0, bool store_modifier = false,
+                                     int fs_stage = 0) const {
     int count = 0;
     const strided_kernel* k =
         desc.precision == PFFT_PRECISION_F64 ? strided_kernels_f64(&count) : strided_kernels_f32(&count);
     const strided_kernel* found = nullptr;
+    for (int i = 0; i < count && fs_stage != 0; ++i) {
+      if (k[i].n != n || k[i].lds_bytes > max_lds || k[i].policy != policy) continue;
+      if ((fs_stage == 1 && k[i].fs_a != 0) || (fs_stage == 2 && k[i].fs_b != 0)) return &k[i];
+    }
+    if (fs_stage != 0) return nullptr;
     for (int i = 0; i < count; ++i) {
       if (k[i].n != n || k[i].lds_bytes > max_lds || k[i].policy != policy) continue;
+      if (k[i].fs_only != 0) continue;
       if (k[i].wide == 0 && k[i].rowish == 0 && found == nullptr) found = &k[i];
       // wide groups only pay when the stage has that many adjacent columns (surplus lanes would be masked)
       if (k[i].wide != 0 && column_both && (inner_count < 0 || inner_count >= k[i].fpw)) return &k[i];
@@ -600,7 +610,7 @@ struct plan_t {
 
   stage make_strided_stage(const strided_kernel* k, long long count, long long inner_count, int in_buf,
                            const addressing& ia, int out_buf, const addressing& oa, double scale, int backward,
-                           int store_modifier = 0) {
+                           int store_modifier = 0, bool allow_row = true) {
     stage s;
     s.strided = k;
     s.store_modifier = store_modifier;
@@ -640,6 +650,7 @@ struct plan_t {
     int want_row = 0;
     if (ia.stride == 1 && ia.dist_inner != 1 && oa.dist_inner == 1 && (k->n <= 512 || k->rowish != 0)) want_row = 1;
     if (oa.stride == 1 && oa.dist_inner != 1 && ia.dist_inner == 1) want_row = 2;
+    if (!allow_row) want_row = 0;  // four-step pair: stage B reads the group-major intermediate (tiled-input form)
     const bool mixed = desc.complex_storage == PFFT_SPLIT_COMPLEX && (in_buf == BUF_SCRATCH) != (out_buf == BUF_SCRATCH);
     if (k->launch == nullptr && want_row != 0 && !user_split && !mixed) {  // runtime-compiled entry: build the row form
       std::string why;
@@ -712,8 +723,8 @@ struct plan_t {
       const void* fn = s.row_mode != 0 ? k->fn_row[(s.row_mode - 1) * 2 + s.backward]
                                        : (s.tiled_in != 0 ? k->fn_tin[s.backward] : k->fn[s.backward * 2 + (s.store_modifier ? 1 : 0)]);
       if (fn == nullptr) return;
-      s.grid = persistent_grid(fn, nullptr, k->wg, s.row_mode != 0 ? k->lds_bytes_row : k->lds_bytes, groups,
-                               k->groups_per_wg);
+      const size_t lds = s.row_mode != 0 ? k->lds_bytes_row : std::max(k->lds_bytes, s.lds_bytes);
+      s.grid = persistent_grid(fn, nullptr, k->wg, lds, groups, s.gpw > 0 ? s.gpw : k->groups_per_wg);
     } else if (s.rows2d != nullptr) {
       const rows2d_kernel* k = s.rows2d;
       const bool split = desc.complex_storage == PFFT_SPLIT_COMPLEX;
@@ -1119,6 +1130,21 @@ struct plan_t {
                                                 : (user_io ? get_strided_mixed(n1, n2, 2) : nullptr);
     const strided_kernel* kb = interleaved_user ? get_strided(n2, n1, false, false, false, true, cached ? 2 : 0)  // rows in
                                                 : (user_io ? get_strided_mixed(n2, n1, 3) : nullptr);
+    // Four-step pair: entries tuned as stage A / stage B of a group-major intermediate with equal group widths
+    // (strided_kernel::fs_a / fs_b; PFFT_NO_FS_PAIRS=1 keeps the default entries of the two lengths)
+    bool fs_pair = false;
+    if (interleaved_user && getenv("PFFT_NO_FS_PAIRS") == nullptr && getenv("PFFT_NO_TILED_SCRATCH") == nullptr &&
+        getenv("PFFT_NO_TILED_LANES") == nullptr && getenv("PFFT_NO_PRECOMPILED") == nullptr) {
+      const strided_kernel* fa = find_strided(n1, false, false, -1, cached ? 1 : 0, true, 1);
+      const strided_kernel* fb = find_strided(n2, false, false, -1, cached ? 2 : 0, false, 2);
+      if (fa != nullptr && fb != nullptr && fb->launch_tin != nullptr && fa->fpw == fb->fpw &&
+          (fa->fpw & (fa->fpw - 1)) == 0 && n2 % fa->fpw == 0 && (n2 / fb->radices[0]) % fa->fpw == 0 &&
+          static_cast<unsigned long long>(n) * elem_bytes() < 0xFFFFFFF0ull && store_tables_fit(fa, n)) {
+        ka = fa;
+        kb = fb;
+        fs_pair = true;
+      }
+    }
     const char* dbg = getenv("PFFT_DEBUG_GLOBAL");  // debugging aid: "ga" / "gb" force the generic kernel for a stage
     const bool force_generic_a = dbg != nullptr && std::strstr(dbg, "ga") != nullptr;
     const bool force_generic_b = dbg != nullptr && std::strstr(dbg, "gb") != nullptr;
@@ -1128,6 +1154,7 @@ struct plan_t {
       // the kernels' BWD form on both
       sa = make_strided_stage(ka, count * n2, n2, in_buf, a_in, BUF_SCRATCH, a_out, 1.0, backward, 1);
       attach_store_tables(sa, n);
+      if (fs_pair && ka->fs_groups_per_wg > 0) sa.gpw = ka->fs_groups_per_wg;
     } else {
       sa = make_generic_stage(n1, count * n2, n2, in_buf, a_in, BUF_SCRATCH, a_out, 1.0, backward, backward);
       int shift = 0;  // the generic kernel reads two global tables (hi/lo split of the exponent)
@@ -1150,7 +1177,8 @@ struct plan_t {
     addressing b_out{oa.offset, n1, 1, n};
     stage sb;
     if (!force_generic_b && strided_fits(kb, n1, BUF_SCRATCH, b_in, out_buf, b_out)) {
-      sb = make_strided_stage(kb, count * n1, n1, BUF_SCRATCH, b_in, out_buf, b_out, scale, backward);
+      sb = make_strided_stage(kb, count * n1, n1, BUF_SCRATCH, b_in, out_buf, b_out, scale, backward, 0, !fs_pair);
+      if (fs_pair && kb->fs_groups_per_wg > 0) sb.gpw = kb->fs_groups_per_wg;
     } else {
       sb = make_generic_stage(n2, count * n1, n1, BUF_SCRATCH, b_in, out_buf, b_out, scale, backward, backward);
     }
@@ -1208,9 +1236,9 @@ struct plan_t {
         }
       }
     }
-    if (chunk < count) {
-      regrid_for_chunk(out.back(), chunk * n2);
-      regrid_for_chunk(sb, chunk * n1);
+    if (chunk < count || fs_pair) {  // (a pair's stages may carry their own grid rule / the tiled-input form)
+      regrid_for_chunk(out.back(), std::min(chunk, count) * n2);
+      regrid_for_chunk(sb, std::min(chunk, count) * n1);
     }
     out.push_back(sb);
     record(PFFT_TIER_GLOBAL, {static_cast<int>(n1), static_cast<int>(n2)}, sb.generic ? GENERIC_WG : kb->wg,

@@ -56,17 +56,19 @@ constexpr int strided_pitch() {
 }
 
 /// LDS copy of the store-modifier tables (strided_args::stw_tab): behind the images and the TWL tables.
-template <typename Cfg>
+/// (HALF: the half-exchange kernel of stockham_strided_hx.hpp, whose image holds one scalar per element)
+template <typename Cfg, bool HALF = false>
 PFA_DEV cx<typename Cfg::T>* stw_lds_tables() {
   extern __shared__ __attribute__((aligned(16))) char pfa_smem_strided[];
-  constexpr size_t own = Cfg::NP > 1 ? size_t(Cfg::N) * Cfg::FPW + Cfg::TWL_ELEMS : 0;
+  constexpr size_t image = HALF ? size_t(Cfg::N) * Cfg::FPW / 2 : size_t(Cfg::N) * Cfg::FPW;
+  constexpr size_t own = Cfg::NP > 1 ? image + Cfg::TWL_ELEMS : 0;
   return reinterpret_cast<cx<typename Cfg::T>*>(pfa_smem_strided) + own;
 }
 
 /// W_M^m as the product of one entry per level
-template <typename Cfg>
+template <typename Cfg, bool HALF = false>
 PFA_DEV cx<typename Cfg::T> stw_from_lds(const strided_args& a, unsigned long long m) {
-  const cx<typename Cfg::T>* tab = stw_lds_tables<Cfg>();
+  const cx<typename Cfg::T>* tab = stw_lds_tables<Cfg, HALF>();
   const unsigned sh = static_cast<unsigned>(a.stw_lshift);
   const unsigned mask = (1u << sh) - 1u;
   cx<typename Cfg::T> w = tab[static_cast<unsigned>(m) & mask];
@@ -77,10 +79,10 @@ PFA_DEV cx<typename Cfg::T> stw_from_lds(const strided_args& a, unsigned long lo
 }
 
 /// once per work-group lifetime (STW kernels): the tables into LDS
-template <typename Cfg, int STW>
+template <typename Cfg, int STW, bool HALF = false>
 PFA_DEV void strided_copy_stw(const strided_args& a) {
   if constexpr (STW == 1) {
-    cx<typename Cfg::T>* dst = stw_lds_tables<Cfg>();
+    cx<typename Cfg::T>* dst = stw_lds_tables<Cfg, HALF>();
     const cx<typename Cfg::T>* src = static_cast<const cx<typename Cfg::T>*>(a.stw_tab);
     const int n = a.stw_levels << a.stw_lshift;
     for (int i = threadIdx.x; i < n; i += Cfg::WG) dst[i] = src[i];
@@ -90,7 +92,7 @@ PFA_DEV void strided_copy_stw(const strided_args& a) {
 
 /// The HBM side of a last pass: butterfly outputs v[u] = element (base + u * Ns) of FFT f go to memory, conjugated
 /// for the backward transform, scaled, and -- STW -- multiplied by the store modifier W_M^{k*c}.
-template <typename Cfg, bool BWD, int STW, int R, int Ns, typename IO>
+template <typename Cfg, bool BWD, int STW, int R, int Ns, typename IO, bool HALF = false>
 PFA_DEV void strided_store_butterfly(const IO& io, const strided_args& a, unsigned f, unsigned base, bool live,
                                      long long c0, cx<typename Cfg::T> (&v)[R]) {
   using T = typename Cfg::T;
@@ -120,7 +122,7 @@ PFA_DEV void strided_store_butterfly(const IO& io, const strided_args& a, unsign
         const cx<T>* hi = static_cast<const cx<T>*>(a.stw_hi);
         return cmul(lo[m & ((1ull << a.stw_shift) - 1)], hi[m >> a.stw_shift]);
       } else {
-        return stw_from_lds<Cfg>(a, m);
+        return stw_from_lds<Cfg, HALF>(a, m);
       }
     };
     const cx<T> w0 = root(m0);
@@ -285,7 +287,17 @@ PFA_DEV void strided_passes(const IO& io, const strided_args& a, unsigned f, uns
   }
 }
 
+/// TIN lane mapping of pass 0 (see strided_pass): lanes element-fastest inside the FPW x FPW input tiles
+template <typename Cfg>
+PFA_DEV void tin_lanes(unsigned* f, unsigned* tid, bool* live, long long nlive) {
+  const unsigned lane = threadIdx.x;
+  *f = (lane / Cfg::FPW) % Cfg::FPW;
+  *tid = (lane / (Cfg::FPW * Cfg::FPW)) * Cfg::FPW + lane % Cfg::FPW;
+  *live = static_cast<long long>(*f) < nlive;
+}
+
 /// Pass 0 of the strided kernel split in two (loads / butterfly + scatter) for the prefetching variant.
+/// (f, tid, live) are the TIN lane mapping (tin_lanes) when the kernel reads tiled input.
 template <typename Cfg, bool BWD, typename IO>
 PFA_DEV void strided_pass0_load(const IO& io, const strided_args& a, unsigned f, unsigned tid, bool live,
                                 cx<typename Cfg::T> (&v)[Cfg::bpt(0)][Cfg::Seq::r[0]]) {
@@ -311,7 +323,7 @@ PFA_DEV void strided_pass0_load(const IO& io, const strided_args& a, unsigned f,
   });
 }
 
-template <typename Cfg>
+template <typename Cfg, bool TIN = false>
 PFA_DEV void strided_pass0_compute(cx<typename Cfg::T> (&v)[Cfg::bpt(0)][Cfg::Seq::r[0]], unsigned f, unsigned tid,
                                    cx<typename Cfg::T>* lds) {
   constexpr int R = Cfg::Seq::r[0];
@@ -322,7 +334,8 @@ PFA_DEV void strided_pass0_compute(cx<typename Cfg::T> (&v)[Cfg::bpt(0)][Cfg::Se
     const unsigned j = tid + i * Cfg::TPF;
     if (!ragged || j < NB) {
       dft<R>(v[i]);
-      cx<typename Cfg::T>* p = lds + (j * R) * Cfg::FPW + f;
+      // TIN: element e = j * R + u of FFT f goes to slot f ^ (j % FPW) (strided_pass)
+      cx<typename Cfg::T>* p = lds + (j * R) * Cfg::FPW + (TIN ? (f ^ (j % Cfg::FPW)) : f);
       sfor<0, R>([&](auto u_) PFA_LAMBDA {
         constexpr int u = decltype(u_)::value;
         p[u * Cfg::FPW] = v[i][u];
@@ -396,11 +409,13 @@ template <typename Cfg>
 PFA_DEV void strided_copy_twiddles(cx<typename Cfg::T>* lds, const cx<typename Cfg::T>* __restrict__ tw);
 
 /// Software-pipelined strided kernel: the loads of the work-group's next group are in flight during the LDS passes
-/// of the current one (see stockham_wg_prefetch_kernel).
-template <typename Cfg, bool BWD, int STW, int SPLIT = 0>
+/// of the current one (see stockham_wg_prefetch_kernel).  TIN: tiled input read with the lanes element-fastest inside
+/// the tiles (strided_pass), for the four-step stage B behind a group-major stage A.
+template <typename Cfg, bool BWD, int STW, int SPLIT = 0, bool TIN = false>
 __global__ __launch_bounds__(Cfg::WG, Cfg::OCC) void stockham_strided_prefetch_kernel(const strided_args a) {
   using T = typename Cfg::T;
   static_assert(Cfg::NP >= 2, "the strided tier needs at least two passes (LDS exchange)");
+  static_assert(!TIN || tin_supported<Cfg>(), "TIN: see tin_supported()");
   extern __shared__ __attribute__((aligned(16))) char pfa_smem_strided[];
   cx<T>* lds = reinterpret_cast<cx<T>*>(pfa_smem_strided);
   const unsigned f = threadIdx.x % Cfg::FPW;
@@ -414,24 +429,31 @@ __global__ __launch_bounds__(Cfg::WG, Cfg::OCC) void stockham_strided_prefetch_k
   cx<T> cur[Cfg::bpt(0)][Cfg::Seq::r[0]];
   cx<T> nxt[Cfg::bpt(0)][Cfg::Seq::r[0]];
   bool live, live_n = false;
-  long long c0, c0_n = 0;
-  auto io = strided_group<Cfg, SPLIT>(a, g, f, &live, &c0);
+  long long c0, c0_n = 0, nlive = 0, nlive_n = 0;
+  auto io = strided_group<Cfg, SPLIT>(a, g, f, &live, &c0, &nlive);
   auto io_n = io;
-  strided_pass0_load<Cfg, BWD>(io, a, f, tid, live, cur);
+  // pass 0 runs on the TIN lane mapping (f0, tid0), the later passes on (f, tid)
+  unsigned f0 = f, tid0 = tid;
+  bool live0 = live;
+  if constexpr (TIN) tin_lanes<Cfg>(&f0, &tid0, &live0, nlive);
+  strided_pass0_load<Cfg, BWD>(io, a, f0, tid0, live0, cur);
   for (; g < ngroups; g += gridDim.x) {
-    strided_pass0_compute<Cfg>(cur, f, tid, lds);
+    strided_pass0_compute<Cfg, TIN>(cur, f0, tid0, lds);
     const long long gn = g + gridDim.x;
     if (gn < ngroups) {
-      io_n = strided_group<Cfg, SPLIT>(a, gn, f, &live_n, &c0_n);
-      strided_pass0_load<Cfg, BWD>(io_n, a, f, tid, live_n, nxt);
+      io_n = strided_group<Cfg, SPLIT>(a, gn, f, &live_n, &c0_n, &nlive_n);
+      bool live0_n = live_n;
+      if constexpr (TIN) tin_lanes<Cfg>(&f0, &tid0, &live0_n, nlive_n);
+      strided_pass0_load<Cfg, BWD>(io_n, a, f0, tid0, live0_n, nxt);
     }
-    strided_passes<Cfg, BWD, STW, 1>(io, a, f, tid, live, c0, lds, tw);
+    strided_passes<Cfg, BWD, STW, 1, decltype(io), false, false, TIN>(io, a, f, tid, live, c0, lds, tw, nlive);
     sfor<0, Cfg::bpt(0)>([&](auto i_) PFA_LAMBDA {
       sfor<0, Cfg::Seq::r[0]>([&](auto t_) PFA_LAMBDA { cur[decltype(i_)::value][decltype(t_)::value] = nxt[decltype(i_)::value][decltype(t_)::value]; });
     });
     io = io_n;
     live = live_n;
     c0 = c0_n;
+    nlive = nlive_n;
   }
 }
 

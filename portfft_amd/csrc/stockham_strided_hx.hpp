@@ -25,9 +25,10 @@ constexpr bool hx_supported() {
   return true;
 }
 
-/// LDS bytes: one scalar image, then the TWL twiddle copy
+/// LDS bytes: one scalar image, then the TWL twiddle copy (the launch adds the store-modifier tables of STW == 1)
 template <typename Cfg>
 constexpr size_t strided_hx_lds_bytes() {
+  static_assert((Cfg::N * Cfg::FPW) % 2 == 0, "the scalar image must end on a complex element");
   return size_t(Cfg::N) * Cfg::FPW * sizeof(typename Cfg::T) + size_t(Cfg::TWL_ELEMS) * sizeof(cx<typename Cfg::T>);
 }
 
@@ -97,7 +98,7 @@ PFA_DEV void hx_exchange(cx<typename Cfg::T> (&v)[Cfg::bpt(P)][Cfg::Seq::r[P]],
   });
 }
 
-template <typename Cfg, bool BWD, bool STW, int P, typename IO>
+template <typename Cfg, bool BWD, int STW, int P, typename IO>
 PFA_DEV void hx_passes(cx<typename Cfg::T> (&v)[Cfg::bpt(P)][Cfg::Seq::r[P]], const IO& io, const strided_args& a,
                        unsigned f, unsigned tid, bool live, long long c0, typename Cfg::T* img,
                        const cx<typename Cfg::T>* twl, const cx<typename Cfg::T>* __restrict__ tw) {
@@ -110,7 +111,7 @@ PFA_DEV void hx_passes(cx<typename Cfg::T> (&v)[Cfg::bpt(P)][Cfg::Seq::r[P]], co
       constexpr int i = decltype(i_)::value;
       const unsigned j = tid + i * Cfg::TPF;
       const unsigned base = (j / Ns) * (Ns * R) + j % Ns;
-      strided_store_butterfly<Cfg, BWD, (STW ? 2 : 0), R, Ns>(io, a, f, base, live, c0, v[i]);  // global tables
+      strided_store_butterfly<Cfg, BWD, STW, R, Ns, IO, true>(io, a, f, base, live, c0, v[i]);
     });
   } else {
     cx<T> n[Cfg::bpt(P + 1)][Seq::r[P + 1]];
@@ -119,7 +120,7 @@ PFA_DEV void hx_passes(cx<typename Cfg::T> (&v)[Cfg::bpt(P)][Cfg::Seq::r[P]], co
   }
 }
 
-template <typename Cfg, bool BWD, bool STW>
+template <typename Cfg, bool BWD, int STW>
 __global__ __launch_bounds__(Cfg::WG, Cfg::OCC) void stockham_strided_hx_kernel(const strided_args a) {
   using T = typename Cfg::T;
   static_assert(hx_supported<Cfg>(), "half-exchange kernel: every pass must divide evenly over the lanes");
@@ -134,6 +135,7 @@ __global__ __launch_bounds__(Cfg::WG, Cfg::OCC) void stockham_strided_hx_kernel(
     for (int i = threadIdx.x; i < Cfg::TWL_ELEMS; i += Cfg::WG) twl[i] = tw[i];
     __syncthreads();
   }
+  strided_copy_stw<Cfg, STW, true>(a);
   for (long long g = blockIdx.x; g < ngroups; g += gridDim.x) {
     bool live;
     long long c0;

@@ -38,7 +38,6 @@ void add(const char* name) {
   if constexpr (KIND == 1) fn = (const void*)&stockham_strided_prefetch_kernel<Cfg, false, STW>;
   else if constexpr (KIND == 2) fn = (const void*)&stockham_strided_hx_kernel<Cfg, false, STW>;
   else fn = (const void*)&stockham_strided_kernel<Cfg, false, STW>;
-  static_assert(!(KIND == 2 && STW), "the half-exchange experiment has no store-modifier form");
   constexpr size_t lds = (KIND == 2 ? strided_hx_lds_bytes<Cfg>() : strided_lds_bytes<Cfg>()) + (STW ? 3 * 128 * sizeof(cx<T>) : 0);
   CK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   g_variants.push_back({std::string(name) + (STW ? " +stw" : ""), Cfg::FPW, Cfg::WG, lds, fn, [d_tw](unsigned grid) {
@@ -87,6 +86,27 @@ int main() {
   add<wg_cfg<d, radix_list<16, 8, 8>, 512, 8, 0, 0, TW_GLOBAL, 2, ((2 + 1) << 8) | 18, 0, 1>, 0, true>("loads nt|sc1 stores nt");
   add<wg_cfg<d, radix_list<16, 8, 8>, 512, 8, 0, 0, TW_GLOBAL, 2, ((2 + 1) << 8) | 3, 0, 1>, 0, true>("loads nt|sc0 stores nt");
   add<wg_cfg<d, radix_list<16, 8, 8>, 512, 8, 0, 0, TW_GLOBAL, 2, ((18 + 1) << 8) | 2, 0, 1>, 0, true>("loads nt stores nt|sc1");
+#elif TUNE_CASE == 5
+  // fp32 N = 2^20 four-step stages (n = 1024 columns, 128-byte segments): stage A = strided in / tiled out + stw,
+  // stage B = tiled in / strided out.  Production: 16.8.8 on 1024 lanes (stw stages), 32.32 prefetch (column/column)
+  using T = f; g_stride = 1024; g_inner = 1024; g_dist_outer = 1 << 20; g_total = 256 * 1024;
+  add<strided_cfg<f, radix_list<16, 8, 8>, 1024, 16, 4, NT>, 0>("f32 16.8.8 wg1024 fpw16 (production stw)");
+  add<strided_cfg<f, radix_list<16, 8, 8>, 1024, 16, 4, NT>, 0, true>("f32 16.8.8 wg1024 fpw16 (production stw)");
+  add<strided_cfg<f, radix_list<32, 32>, 512, 16, 2, NT>, 1>("PF f32 32.32 wg512 fpw16 (production c/c)");
+  add<strided_cfg<f, radix_list<32, 32>, 512, 16, 2, NT>, 1, true>("PF f32 32.32 wg512 fpw16");
+  add<strided_cfg<f, radix_list<16, 8, 8>, 1024, 16, 4, NT>, 1>("PF f32 16.8.8 wg1024 fpw16");
+  add<strided_cfg<f, radix_list<16, 8, 8>, 1024, 16, 4, NT>, 1, true>("PF f32 16.8.8 wg1024 fpw16");
+  add<strided_cfg<f, radix_list<16, 8, 8>, 512, 16, 4, NT>, 2>("HX f32 16.8.8 wg512(32pt) fpw16 2/CU");
+  add<strided_cfg<f, radix_list<16, 8, 8>, 512, 16, 4, NT>, 2, true>("HX f32 16.8.8 wg512(32pt) fpw16 2/CU");
+  add<strided_cfg<f, radix_list<16, 8, 8>, 1024, 16, 8, NT>, 2>("HX f32 16.8.8 wg1024(16pt) fpw16 2/CU");
+  add<strided_cfg<f, radix_list<16, 8, 8>, 1024, 16, 8, NT>, 2, true>("HX f32 16.8.8 wg1024(16pt) fpw16 2/CU");
+  add<strided_cfg<f, radix_list<32, 32>, 512, 16, 4, NT>, 2>("HX f32 32.32 wg512(32pt) fpw16 2/CU");
+  add<strided_cfg<f, radix_list<32, 32>, 512, 16, 4, NT>, 2, true>("HX f32 32.32 wg512(32pt) fpw16 2/CU");
+  add<strided_cfg<f, radix_list<16, 8, 8>, 1024, 32, 4, NT>, 2>("HX f32 16.8.8 wg1024(32pt) fpw32 1/CU");
+  add<strided_cfg<f, radix_list<16, 8, 8>, 1024, 32, 4, NT>, 2, true>("HX f32 16.8.8 wg1024(32pt) fpw32 1/CU");
+  add<strided_cfg<f, radix_list<32, 32>, 1024, 32, 4, NT>, 2>("HX f32 32.32 wg1024(32pt) fpw32 1/CU");
+  add<strided_cfg<f, radix_list<32, 32>, 1024, 32, 4, NT>, 2, true>("HX f32 32.32 wg1024(32pt) fpw32 1/CU");
+  add<strided_cfg<f, radix_list<8, 16, 8>, 512, 16, 4, NT>, 2, true>("HX f32 8.16.8 wg512(32pt) fpw16 2/CU");
 #elif TUNE_CASE == 3
   using T = d; g_stride = 1024; g_inner = 1024; g_dist_outer = 1 << 20; g_total = 128 * 1024;
   add<wg_cfg<d, radix_list<16, 8, 8>, 512, 8, 0, 0, TW_GLOBAL, 2, NT, 0, 1>, 0>("f64 16.8.8 wg512 fpw8 TWL1 (production)");
