@@ -56,19 +56,20 @@ constexpr int strided_pitch() {
 }
 
 /// LDS copy of the store-modifier tables (strided_args::stw_tab): behind the images and the TWL tables.
-/// (HALF: the half-exchange kernel of stockham_strided_hx.hpp, whose image holds one scalar per element)
-template <typename Cfg, bool HALF = false>
+/// (IMGDIV: the kernel's image holds 1 / IMGDIV of the group -- 2 for the half-exchange kernel of
+/// stockham_strided_hx.hpp, the first radix for the experiment of tools/probes/stockham_strided_sfr.hpp)
+template <typename Cfg, int IMGDIV = 1>
 PFA_DEV cx<typename Cfg::T>* stw_lds_tables() {
   extern __shared__ __attribute__((aligned(16))) char pfa_smem_strided[];
-  constexpr size_t image = HALF ? size_t(Cfg::N) * Cfg::FPW / 2 : size_t(Cfg::N) * Cfg::FPW;
+  constexpr size_t image = size_t(Cfg::N) * Cfg::FPW / IMGDIV;
   constexpr size_t own = Cfg::NP > 1 ? image + Cfg::TWL_ELEMS : 0;
   return reinterpret_cast<cx<typename Cfg::T>*>(pfa_smem_strided) + own;
 }
 
 /// W_M^m as the product of one entry per level
-template <typename Cfg, bool HALF = false>
+template <typename Cfg, int IMGDIV = 1>
 PFA_DEV cx<typename Cfg::T> stw_from_lds(const strided_args& a, unsigned long long m) {
-  const cx<typename Cfg::T>* tab = stw_lds_tables<Cfg, HALF>();
+  const cx<typename Cfg::T>* tab = stw_lds_tables<Cfg, IMGDIV>();
   const unsigned sh = static_cast<unsigned>(a.stw_lshift);
   const unsigned mask = (1u << sh) - 1u;
   cx<typename Cfg::T> w = tab[static_cast<unsigned>(m) & mask];
@@ -79,10 +80,10 @@ PFA_DEV cx<typename Cfg::T> stw_from_lds(const strided_args& a, unsigned long lo
 }
 
 /// once per work-group lifetime (STW kernels): the tables into LDS
-template <typename Cfg, int STW, bool HALF = false>
+template <typename Cfg, int STW, int IMGDIV = 1>
 PFA_DEV void strided_copy_stw(const strided_args& a) {
   if constexpr (STW == 1) {
-    cx<typename Cfg::T>* dst = stw_lds_tables<Cfg, HALF>();
+    cx<typename Cfg::T>* dst = stw_lds_tables<Cfg, IMGDIV>();
     const cx<typename Cfg::T>* src = static_cast<const cx<typename Cfg::T>*>(a.stw_tab);
     const int n = a.stw_levels << a.stw_lshift;
     for (int i = threadIdx.x; i < n; i += Cfg::WG) dst[i] = src[i];
@@ -92,7 +93,7 @@ PFA_DEV void strided_copy_stw(const strided_args& a) {
 
 /// The HBM side of a last pass: butterfly outputs v[u] = element (base + u * Ns) of FFT f go to memory, conjugated
 /// for the backward transform, scaled, and -- STW -- multiplied by the store modifier W_M^{k*c}.
-template <typename Cfg, bool BWD, int STW, int R, int Ns, typename IO, bool HALF = false>
+template <typename Cfg, bool BWD, int STW, int R, int Ns, typename IO, int IMGDIV = 1>
 PFA_DEV void strided_store_butterfly(const IO& io, const strided_args& a, unsigned f, unsigned base, bool live,
                                      long long c0, cx<typename Cfg::T> (&v)[R]) {
   using T = typename Cfg::T;
@@ -122,7 +123,7 @@ PFA_DEV void strided_store_butterfly(const IO& io, const strided_args& a, unsign
         const cx<T>* hi = static_cast<const cx<T>*>(a.stw_hi);
         return cmul(lo[m & ((1ull << a.stw_shift) - 1)], hi[m >> a.stw_shift]);
       } else {
-        return stw_from_lds<Cfg, HALF>(a, m);
+        return stw_from_lds<Cfg, IMGDIV>(a, m);
       }
     };
     const cx<T> w0 = root(m0);
@@ -366,6 +367,9 @@ PFA_DEV strided_io<typename Cfg::T, Cfg::AUX, SPLIT> strided_group(const strided
   const long long t0 = o * a.inner + c0;
   const long long nlive = (a.inner - c0 < a.total - t0) ? a.inner - c0 : a.total - t0;
   *live = static_cast<long long>(f) < nlive;
+#ifdef PFA_TUNE_DEAD_LANES  // tuners only: every lane masked -- no HBM traffic, the kernel's arithmetic / LDS time alone
+  *live = false;
+#endif
   *c0_out = c0;
   if (nlive_out != nullptr) *nlive_out = nlive;
   // group-major sides: group number (g - o * per_outer) of outer index o starts at that multiple of gdist

@@ -111,7 +111,7 @@ PFA_DEV void hx_passes(cx<typename Cfg::T> (&v)[Cfg::bpt(P)][Cfg::Seq::r[P]], co
       constexpr int i = decltype(i_)::value;
       const unsigned j = tid + i * Cfg::TPF;
       const unsigned base = (j / Ns) * (Ns * R) + j % Ns;
-      strided_store_butterfly<Cfg, BWD, STW, R, Ns, IO, true>(io, a, f, base, live, c0, v[i]);
+      strided_store_butterfly<Cfg, BWD, STW, R, Ns, IO, 2>(io, a, f, base, live, c0, v[i]);
     });
   } else {
     cx<T> n[Cfg::bpt(P + 1)][Seq::r[P + 1]];
@@ -135,7 +135,7 @@ __global__ __launch_bounds__(Cfg::WG, Cfg::OCC) void stockham_strided_hx_kernel(
     for (int i = threadIdx.x; i < Cfg::TWL_ELEMS; i += Cfg::WG) twl[i] = tw[i];
     __syncthreads();
   }
-  strided_copy_stw<Cfg, STW, true>(a);
+  strided_copy_stw<Cfg, STW, 2>(a);
   for (long long g = blockIdx.x; g < ngroups; g += gridDim.x) {
     bool live;
     long long c0;

@@ -17,6 +17,7 @@
 #include <string>
 #include <vector>
 #include "../portfft_amd/csrc/stockham_strided_hx.hpp"
+#include "probes/stockham_strided_sfr.hpp"
 #include "../portfft_amd/csrc/kernels.hpp"
 using namespace pfa;
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s line %d\n", hipGetErrorString(e_), __LINE__); exit(1);} } while (0)
@@ -66,7 +67,7 @@ __global__ void fill_uniform(T* p, size_t n, unsigned seed) {
   }
 }
 
-enum kind_t { K_PLAIN = 0, K_PREFETCH = 1, K_HX = 2, K_ROW_IN = 3, K_TIN = 4, K_NOSTW = 5 /* timing only: stage A without its store modifier */, K_PF_TIN = 6 };
+enum kind_t { K_PLAIN = 0, K_PREFETCH = 1, K_HX = 2, K_ROW_IN = 3, K_TIN = 4, K_NOSTW = 5 /* timing only: stage A without its store modifier */, K_PF_TIN = 6, K_SFR = 7 };
 struct variant {
   std::string name;
   int kind, fpw, wg, gpw;
@@ -82,17 +83,19 @@ static int g_stw_levels, g_stw_shift;
 static void* g_stw_tab;
 
 template <typename Cfg, int KIND, bool STAGE_A>
-void add(const char* name, bool tiled, int gpw) {
+void add(const char* name, bool tiled, int gpw, size_t extra_lds = 0) {
   constexpr int STW = (STAGE_A && KIND != K_NOSTW) ? 1 : 0;
   const void* fn;
   size_t lds;
   if constexpr (KIND == K_PREFETCH) { fn = (const void*)&stockham_strided_prefetch_kernel<Cfg, false, STW>; lds = strided_lds_bytes<Cfg>(); }
   else if constexpr (KIND == K_PF_TIN) { fn = (const void*)&stockham_strided_prefetch_kernel<Cfg, false, STW, 0, true>; lds = strided_lds_bytes<Cfg>(); }
+  else if constexpr (KIND == K_SFR) { fn = (const void*)&stockham_strided_sfr_kernel<Cfg, false, STW>; lds = strided_sfr_lds_bytes<Cfg>(); }
   else if constexpr (KIND == K_HX) { fn = (const void*)&stockham_strided_hx_kernel<Cfg, false, STW>; lds = strided_hx_lds_bytes<Cfg>(); }
   else if constexpr (KIND == K_ROW_IN) { fn = (const void*)&stockham_strided_row_kernel<Cfg, false, true, false>; lds = strided_row_lds_bytes<Cfg>(); }
   else if constexpr (KIND == K_TIN) { fn = (const void*)&stockham_strided_kernel<Cfg, false, STW, 0, true>; lds = strided_lds_bytes<Cfg>(); }
   else { fn = (const void*)&stockham_strided_kernel<Cfg, false, STW>; lds = strided_lds_bytes<Cfg>(); }
   if (STAGE_A) lds += ((size_t)g_stw_levels << g_stw_shift) * sizeof(cx<T>);
+  lds += extra_lds;  // (occupancy experiments: unused LDS that costs resident work-groups)
   CK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   variant v;
   v.name = name; v.kind = KIND; v.fpw = Cfg::FPW; v.wg = Cfg::WG; v.gpw = gpw; v.tiled = tiled; v.lds = lds; v.fn = fn;
@@ -101,6 +104,7 @@ void add(const char* name, bool tiled, int gpw) {
   v.launch = [lds](unsigned grid, const strided_args& a) {
     if constexpr (KIND == K_PREFETCH) hipLaunchKernelGGL((stockham_strided_prefetch_kernel<Cfg, false, STW>), dim3(grid), dim3(Cfg::WG), lds, 0, a);
     else if constexpr (KIND == K_PF_TIN) hipLaunchKernelGGL((stockham_strided_prefetch_kernel<Cfg, false, STW, 0, true>), dim3(grid), dim3(Cfg::WG), lds, 0, a);
+    else if constexpr (KIND == K_SFR) hipLaunchKernelGGL((stockham_strided_sfr_kernel<Cfg, false, STW>), dim3(grid), dim3(Cfg::WG), lds, 0, a);
     else if constexpr (KIND == K_HX) hipLaunchKernelGGL((stockham_strided_hx_kernel<Cfg, false, STW>), dim3(grid), dim3(Cfg::WG), lds, 0, a);
     else if constexpr (KIND == K_ROW_IN) hipLaunchKernelGGL((stockham_strided_row_kernel<Cfg, false, true, false>), dim3(grid), dim3(Cfg::WG), lds, 0, a);
     else if constexpr (KIND == K_TIN) hipLaunchKernelGGL((stockham_strided_kernel<Cfg, false, STW, 0, true>), dim3(grid), dim3(Cfg::WG), lds, 0, a);
@@ -108,8 +112,8 @@ void add(const char* name, bool tiled, int gpw) {
   };
   (STAGE_A ? g_a : g_b).push_back(v);
 }
-template <typename Cfg, int KIND> void addA(const char* name, bool tiled, int gpw) { add<Cfg, KIND, true>(name, tiled, gpw); }
-template <typename Cfg, int KIND> void addB(const char* name, bool tiled, int gpw) { add<Cfg, KIND, false>(name, tiled, gpw); }
+template <typename Cfg, int KIND> void addA(const char* name, bool tiled, int gpw, size_t x = 0) { add<Cfg, KIND, true>(name, tiled, gpw, x); }
+template <typename Cfg, int KIND> void addB(const char* name, bool tiled, int gpw, size_t x = 0) { add<Cfg, KIND, false>(name, tiled, gpw, x); }
 
 static int g_cus = 256;
 static unsigned grid_of(const variant& v, long long groups) {  // plan.cpp persistent_grid
@@ -225,6 +229,9 @@ int main() {
   addA<strided_cfg<f, radix_list<16, 8, 8>, 512, 16, 4, W>, K_HX>("A HX 16.8.8 wg512(32pt) fpw16 tiled 2/CU", true, 4);
   addB<strided_cfg<f, radix_list<16, 8, 8>, 512, 16, 4, RD>, K_HX>("B HX 16.8.8 wg512(32pt) fpw16 tiled 2/CU", true, 4);
   addB<strided_cfg<f, radix_list<32, 32>, 512, 16, 4, RD>, K_HX>("B HX 32.32 wg512(32pt) fpw16 tiled 2/CU", true, 4);
+  addA<sfr_cfg<f, radix_list<2, 8, 8, 8>, 512, 16, 4, W>, K_SFR>("A SFR 2.8.8.8 wg512 fpw16 tiled 2/CU", true, 4);
+  addA<sfr_cfg<f, radix_list<2, 8, 8, 8>, 512, 16, 4, W>, K_SFR>("A SFR 2.8.8.8 wg512 fpw16 tiled 2/CU gpw2", true, 2);
+  addB<sfr_cfg<f, radix_list<2, 8, 8, 8>, 512, 16, 4, RD>, K_SFR>("B SFR 2.8.8.8 wg512 fpw16 tiled 2/CU", true, 4);
   addA<strided_cfg<f, radix_list<16, 8, 8>, 1024, 16, 4, W>, K_NOSTW>("A 16.8.8 wg1024 fpw16 tiled WITHOUT stw (timing only)", true, 4);
   addA<strided_cfg<f, radix_list<32, 32>, 512, 16, 2, W>, K_NOSTW>("A 32.32 wg512 fpw16 tiled WITHOUT stw (timing only)", true, 4);
   addA<strided_cfg<f, radix_list<32, 32>, 512, 16, 2, W>, K_PLAIN>("A 32.32 wg512 fpw16 tiled", true, 4);
@@ -254,6 +261,10 @@ int main() {
   addB<strided_cfg<f, radix_list<8, 8, 8>, 512, 16, 2, RD>, K_TIN>("B 8.8.8 wg512 fpw16 tiled TIN 2/CU gpw8", true, 8);
   addA<strided_cfg<f, radix_list<8, 8, 8>, 256, 16, 1, W>, K_PLAIN>("A 8.8.8 wg256(32pt) fpw16 tiled 2/CU", true, 4);
   addB<strided_cfg<f, radix_list<8, 8, 8>, 256, 16, 1, RD>, K_TIN>("B 8.8.8 wg256(32pt) fpw16 tiled TIN 2/CU", true, 4);
+  addA<strided_cfg<f, radix_list<8, 8, 8>, 512, 16, 2, W>, K_PLAIN>("A 8.8.8 wg512 fpw16 tiled FORCED 1/CU (+16 KiB LDS)", true, 4, 16 << 10);
+  addB<strided_cfg<f, radix_list<8, 8, 8>, 512, 16, 2, RD>, K_TIN>("B 8.8.8 wg512 fpw16 tiled TIN FORCED 1/CU (+16 KiB)", true, 4, 16 << 10);
+  addA<sfr_cfg<f, radix_list<2, 16, 16>, 512, 32, 4, W>, K_SFR>("A SFR 2.16.16 wg512 fpw32 tiled 2/CU", true, 2);
+  addB<sfr_cfg<f, radix_list<2, 16, 16>, 512, 32, 4, RD>, K_SFR>("B SFR 2.16.16 wg512 fpw32 tiled 2/CU", true, 2);
   addA<strided_cfg<f, radix_list<16, 32>, 512, 32, 2, W>, K_PLAIN>("A 16.32 wg512 fpw32 tiled", true, 2);
   addB<strided_cfg<f, radix_list<32, 16>, 512, 32, 2, RD>, K_PLAIN>("B 32.16 wg512 fpw32 tiled", true, 2);
 #elif TUNE_CASE == 16
@@ -280,6 +291,10 @@ int main() {
   addB<strided_cfg<f, radix_list<16, 16, 8>, 1024, 8, 4, RD>, K_PF_TIN>("B PF+TIN 16.16.8 wg1024 fpw8 tiled", true, 1);
   addA<strided_cfg<f, radix_list<16, 16, 8>, 1024, 8, 4, W>, K_PLAIN>("A 16.16.8 wg1024 fpw8 tiled gpw4", true, 4);
   addB<strided_cfg<f, radix_list<16, 16, 8>, 1024, 8, 4, RD>, K_TIN>("B 16.16.8 wg1024 fpw8 tiled TIN gpw4", true, 4);
+  addA<sfr_cfg<f, radix_list<2, 16, 8, 8>, 1024, 16, 4, W>, K_SFR>("A SFR 2.16.8.8 wg1024 fpw16 tiled 1/CU", true, 4);
+  addB<sfr_cfg<f, radix_list<2, 16, 8, 8>, 1024, 16, 4, RD>, K_SFR>("B SFR 2.16.8.8 wg1024 fpw16 tiled 1/CU", true, 4);
+  addA<sfr_cfg<f, radix_list<4, 8, 8, 8>, 1024, 16, 4, W>, K_SFR>("A SFR 4.8.8.8 wg1024 fpw16 tiled", true, 4);
+  addB<sfr_cfg<f, radix_list<4, 8, 8, 8>, 1024, 16, 4, RD>, K_SFR>("B SFR 4.8.8.8 wg1024 fpw16 tiled", true, 4);
   addA<strided_cfg<f, radix_list<16, 16, 8>, 1024, 16, 4, W>, K_HX>("A HX 16.16.8 wg1024(32pt) fpw16 tiled", true, 1);
   addB<strided_cfg<f, radix_list<16, 16, 8>, 1024, 16, 4, RD>, K_HX>("B HX 16.16.8 wg1024(32pt) fpw16 tiled", true, 1);
 #elif TUNE_CASE == 120
@@ -288,6 +303,9 @@ int main() {
   addB<strided_cfg<d, radix_list<16, 8, 8>, 512, 8, 2, RD>, K_PLAIN>("B 16.8.8 wg512 fpw8 tiled", true, 4);
   addA<strided_cfg<d, radix_list<16, 8, 8>, 512, 8, 2, W>, K_PREFETCH>("A PF 16.8.8 wg512 fpw8 tiled", true, 4);
   addB<strided_cfg<d, radix_list<16, 8, 8>, 512, 8, 2, RD>, K_PREFETCH>("B PF 16.8.8 wg512 fpw8 tiled", true, 4);
+  addA<sfr_cfg<d, radix_list<2, 8, 8, 8>, 512, 8, 4, W>, K_SFR>("A SFR 2.8.8.8 wg512 fpw8 tiled 2/CU", true, 4);
+  addA<sfr_cfg<d, radix_list<2, 8, 8, 8>, 512, 8, 4, W>, K_SFR>("A SFR 2.8.8.8 wg512 fpw8 tiled 2/CU gpw2", true, 2);
+  addB<sfr_cfg<d, radix_list<2, 8, 8, 8>, 512, 8, 4, RD>, K_SFR>("B SFR 2.8.8.8 wg512 fpw8 tiled 2/CU", true, 4);
   addB<strided_cfg<d, radix_list<16, 8, 8>, 512, 8, 2, RD>, K_PF_TIN>("B PF+TIN 16.8.8 wg512 fpw8 tiled", true, 4);
   addA<wg_cfg<d, radix_list<16, 8, 8>, 256, 8, 0, 0, TW_GLOBAL, 2, W, 0, 0>, K_HX>("A HX 16.8.8 wg256(32pt) fpw8 TWL0 tiled 2/CU", true, 4);
   addA<strided_cfg<d, radix_list<16, 8, 8>, 256, 8, 2, W>, K_HX>("A HX 16.8.8 wg256(32pt) fpw8 tiled 2/CU", true, 4);
