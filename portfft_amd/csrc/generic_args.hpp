@@ -43,6 +43,13 @@ inline unsigned long long generic_magic(unsigned d) { return ((1ull << 40) / d) 
 /// radices the generic kernel can run; the planner factorises lengths into these (plan.cpp: choose_radices)
 #define PFA_GENERIC_RADICES(X) \
   X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16) X(17) X(19) X(23) X(29) X(31)
+/// ... and the primes only the "big radix" instantiation of the kernel carries (generic_fft_kernel<T, true>): a
+/// wave64 build of the reference takes any prime factor up to its sub-group size as one cross-lane DFT
+/// (/root/reference/src/portfft/common/subgroup.hpp:226-253, CMakeLists.txt:54 PORTFFT_SUBGROUP_SIZES); here such a
+/// factor is one in-register butterfly of the symmetric half-length form.  Kept out of the ordinary instantiation:
+/// a radix-61 butterfly holds 61 complex values per lane, and the kernel's register count is that of its largest case.
+#define PFA_GENERIC_RADICES_BIG(X) X(37) X(41) X(43) X(47) X(53) X(59) X(61)
+constexpr int GENERIC_MAX_SMALL_RADIX = 31;
 
 
 }  // namespace pfa

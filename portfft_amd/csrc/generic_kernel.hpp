@@ -43,7 +43,8 @@ PFA_DEV void generic_butterfly(const cx<T>* __restrict__ a, cx<T>* __restrict__ 
   });
 }
 
-template <typename T>
+/// BIG: the instantiation that also carries the prime radices 37 ... 61 (generic_args.hpp)
+template <typename T, bool BIG = false>
 __global__ __launch_bounds__(GENERIC_WG) void generic_fft_kernel(const generic_args p) {
   extern __shared__ __attribute__((aligned(16))) char pfa_smem_generic[];
   cx<T>* A = reinterpret_cast<cx<T>*>(pfa_smem_generic);
@@ -112,6 +113,18 @@ __global__ __launch_bounds__(GENERIC_WG) void generic_fft_kernel(const generic_a
           PFA_GENERIC_RADICES(PFA_CASE)
 #undef PFA_CASE
           default:
+            if constexpr (BIG) {
+              switch (R) {
+#define PFA_CASE(r)                                      \
+  case r:                                                \
+    generic_butterfly<r>(a, b, j, nb, ns, mns, twp); \
+    break;
+                PFA_GENERIC_RADICES_BIG(PFA_CASE)
+#undef PFA_CASE
+                default:
+                  break;
+              }
+            }
             break;
         }
       }

@@ -143,6 +143,6 @@ const spec_kernel* spec_kernels_f64(int* count);
 
 hipError_t launch_generic_f32(hipStream_t stream, unsigned grid, size_t lds_bytes, const generic_args& args);
 hipError_t launch_generic_f64(hipStream_t stream, unsigned grid, size_t lds_bytes, const generic_args& args);
-const void* generic_kernel_symbol(int precision);
+const void* generic_kernel_symbol(int precision, bool big_radix = false);
 
 }  // namespace pfa

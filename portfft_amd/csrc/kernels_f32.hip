@@ -57,7 +57,13 @@ const spec_kernel* spec_kernels_f32(int* count) {
 }
 
 hipError_t launch_generic_f32(hipStream_t stream, unsigned grid, size_t lds_bytes, const generic_args& args) {
-  hipLaunchKernelGGL(generic_fft_kernel<float>, dim3(grid), dim3(GENERIC_WG), lds_bytes, stream, args);
+  bool big = false;
+  for (int i = 0; i < args.n_passes; ++i) big = big || args.radix[i] > GENERIC_MAX_SMALL_RADIX;
+  if (big) {
+    hipLaunchKernelGGL((generic_fft_kernel<float, true>), dim3(grid), dim3(GENERIC_WG), lds_bytes, stream, args);
+  } else {
+    hipLaunchKernelGGL((generic_fft_kernel<float, false>), dim3(grid), dim3(GENERIC_WG), lds_bytes, stream, args);
+  }
   return hipGetLastError();
 }
 

@@ -42,13 +42,23 @@ const spec_kernel* spec_kernels_f64(int* count) {
 }
 
 hipError_t launch_generic_f64(hipStream_t stream, unsigned grid, size_t lds_bytes, const generic_args& args) {
-  hipLaunchKernelGGL(generic_fft_kernel<double>, dim3(grid), dim3(GENERIC_WG), lds_bytes, stream, args);
+  bool big = false;
+  for (int i = 0; i < args.n_passes; ++i) big = big || args.radix[i] > GENERIC_MAX_SMALL_RADIX;
+  if (big) {
+    hipLaunchKernelGGL((generic_fft_kernel<double, true>), dim3(grid), dim3(GENERIC_WG), lds_bytes, stream, args);
+  } else {
+    hipLaunchKernelGGL((generic_fft_kernel<double, false>), dim3(grid), dim3(GENERIC_WG), lds_bytes, stream, args);
+  }
   return hipGetLastError();
 }
 
-const void* generic_kernel_symbol(int precision) {
-  return precision == PFFT_PRECISION_F64 ? reinterpret_cast<const void*>(&generic_fft_kernel<double>)
-                                         : reinterpret_cast<const void*>(&generic_fft_kernel<float>);
+const void* generic_kernel_symbol(int precision, bool big) {
+  if (big) {
+    return precision == PFFT_PRECISION_F64 ? reinterpret_cast<const void*>(&generic_fft_kernel<double, true>)
+                                           : reinterpret_cast<const void*>(&generic_fft_kernel<float, true>);
+  }
+  return precision == PFFT_PRECISION_F64 ? reinterpret_cast<const void*>(&generic_fft_kernel<double, false>)
+                                         : reinterpret_cast<const void*>(&generic_fft_kernel<float, false>);
 }
 
 }  // namespace pfa

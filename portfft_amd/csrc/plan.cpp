@@ -126,6 +126,7 @@ bool generic_radix_ok(int r) {
   switch (r) {
 #define PFA_OK(x) case x:
     PFA_GENERIC_RADICES(PFA_OK)
+    PFA_GENERIC_RADICES_BIG(PFA_OK)
 #undef PFA_OK
     return true;
     default:
@@ -148,7 +149,9 @@ std::vector<int> choose_radices(long long n) {
       }
     }
     if (best == 0) {
-      for (int c : {17, 19, 23, 29, 31}) {
+      // prime factors up to the wavefront size: what a wave64 build of the reference takes as one sub-group DFT
+      // (/root/reference/src/portfft/common/subgroup.hpp:226-253)
+      for (int c : {17, 19, 23, 29, 31, 37, 41, 43, 47, 53, 59, 61}) {
         if (rem % c == 0) best = c;
       }
     }
@@ -885,7 +888,9 @@ struct plan_t {
     }
     g.in_f_fast = (fpw > 1 && ia.dist_inner < ia.stride) ? 1 : 0;
     g.out_f_fast = (fpw > 1 && oa.dist_inner < oa.stride) ? 1 : 0;
-    const void* fn = generic_kernel_symbol(desc.precision);
+    bool big_radix = false;  // a prime radix 37 ... 61: the kernel's "big radix" instantiation (generic_args.hpp)
+    for (int p = 0; p < g.n_passes; ++p) big_radix = big_radix || g.radix[p] > GENERIC_MAX_SMALL_RADIX;
+    const void* fn = generic_kernel_symbol(desc.precision, big_radix);
     if (s.lds_bytes > 48 * 1024) {
       hip_check(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(max_lds)),
                 "hipFuncSetAttribute");

@@ -18,8 +18,9 @@ static int fails = 0;
     }                                  \
   } while (0)
 
+/// prime factors up to the wavefront size (jit.cpp: jit_max_prime)
 static bool smooth31(long long n) {
-  for (int p = 2; p <= 31; ++p) {
+  for (int p = 2; p <= 61; ++p) {
     while (n % p == 0) n /= p;
   }
   return n == 1;
@@ -43,7 +44,8 @@ int main(int argc, char** argv) {
       long long prod = 1;
       for (int r : p.radices) {
         prod *= r;
-        EXPECT(r >= 2 && r <= 32, "n=%lld radix %d", n, r);
+        EXPECT(r >= 2 && r <= 61 && (r <= 32 || (r % 2 != 0 && r % 3 != 0 && r % 5 != 0 && r % 7 != 0)),
+               "n=%lld radix %d", n, r);
       }
       EXPECT(prod == n, "n=%lld product %lld", n, prod);
       EXPECT(p.radices.size() <= 6, "n=%lld passes", n);
@@ -59,7 +61,7 @@ int main(int argc, char** argv) {
       if (pfa::choose_strided_params(prec, n, 1000, max_lds, &q)) {
         long long pq = 1;
         for (int r : q.radices) pq *= r;
-        EXPECT(pq == n && (q.radices.size() >= 2 || n <= 32), "strided n=%lld", n);
+        EXPECT(pq == n && (q.radices.size() >= 2 || n <= 61), "strided n=%lld", n);  // one lane per FFT up to the largest radix
         EXPECT(q.wg >= 64 && q.wg <= 1024 && q.wg % q.fpw == 0, "strided n=%lld wg=%d fpw=%d", n, q.wg, q.fpw);
         EXPECT(static_cast<size_t>(n) * q.fpw * es <= 128 * 1024, "strided n=%lld lds", n);
       }
@@ -116,7 +118,7 @@ int main(int argc, char** argv) {
   {
     struct { int prec; std::vector<long long> dims; bool ok; } shapes[] = {
         {0, {64, 64}, true}, {1, {16, 16, 16}, true}, {0, {30, 50}, true}, {0, {128, 128}, true},
-        {1, {128, 128}, false}, {0, {37, 8}, false},  {0, {4, 1, 8}, true}, {0, {256, 128}, false}};
+        {1, {128, 128}, false}, {0, {67, 8}, false},  {0, {4, 1, 8}, true}, {0, {256, 128}, false}};
     for (auto& sh : shapes) {
       pfa::nd_kernel nk;
       const bool ok = pfa::choose_nd_params(sh.prec, sh.dims, max_lds, &nk);

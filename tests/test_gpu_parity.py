@@ -273,9 +273,44 @@ def test_maximum_sizes():
             got, _ = G.transform_packed(d, pf.direction.FORWARD, x)
             _check(got, y, n, dtype, ("max sizes", prec, n))
     with pytest.raises(pf.unsupported_configuration):
-        G.make_descriptor([37 * 64]).commit()  # prime factor beyond the supported radices
+        G.make_descriptor([67 * 64]).commit()  # prime factor beyond the wavefront size (test_wave64_prime_factors)
     with pytest.raises(pf.unsupported_configuration):
         G.make_descriptor([1 << 28]).commit()  # longer than (LDS/2 elements)^2
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("prec", ["f32", "f64"])
+def test_wave64_prime_factors(prec, oracle):
+    """Prime factors 37 ... 61: a wave64 build of the reference (CMakeLists.txt:54 PORTFFT_SUBGROUP_SIZES,
+    common/subgroup.hpp:226-253 factorize_sg / fits_in_sg: any factor up to the sub-group size is one cross-lane DFT)
+    accepts them; here they are in-register butterflies of the generic tier.  Against NumPy, and against the oracle
+    planned with sub-group size 64, forward and backward, both placements, packed and batch-interleaved, a four-step
+    length and an N-D shape."""
+    import gpu_utils as G
+    pf = _pf()
+    dtype = np.complex64 if prec == "f32" else np.complex128
+    for n in (37, 41, 43, 47, 53, 59, 61, 74, 37 * 64, 41 * 64, 61 * 16, 43 * 47, 3 * 53 * 5, 59 * 59, 61 * 61 * 8):
+        for batch in (1, 5):
+            x, y = H.gen_fourier_data(batch, [n], dtype, seed=n)
+            for place in (0, 1):
+                d = G.make_descriptor([n], prec, batch=batch, placement=place)
+                got, _ = G.transform_packed(d, pf.direction.FORWARD, x)
+                _check(got, y, n, dtype, ("wave64 primes fwd", prec, n, batch, place))
+                back, _ = G.transform_packed(d, pf.direction.BACKWARD, y)
+                _check(back, x.astype(np.complex128) * n, n, dtype, ("wave64 primes bwd", prec, n, batch, place))
+    for n in (37, 74, 41 * 64, 61 * 16):
+        x, _ = H.gen_fourier_data(3, [n], dtype, seed=7)
+        got, _ = G.transform_packed(G.make_descriptor([n], prec, batch=3), pf.direction.FORWARD, x)
+        ref = oracle.compute(oracle.make_desc([n], prec, batch=3), F, x.ravel(), sg=64).reshape(x.shape)
+        _check(got, ref, n, dtype, ("wave64 primes vs oracle(sg=64)", prec, n))
+    # batch-interleaved and N-D
+    x, y = H.gen_fourier_data(33, [37 * 8], dtype, seed=3)
+    d = _layout_desc(G, 37 * 8, prec, 33, 1, "BI", "BI", F, 0)
+    got, _ = G.transform_packed(d, pf.direction.FORWARD, x)
+    _check(got, y, 37 * 8, dtype, ("wave64 primes BI", prec))
+    x, y = H.gen_fourier_data(2, [41, 53], dtype, seed=4)
+    got, _ = G.transform_packed(G.make_descriptor([41, 53], prec, batch=2), pf.direction.FORWARD, x)
+    _check(got.reshape(2, -1), y.reshape(2, -1), 41 * 53, dtype, ("wave64 primes 2-D", prec))
 
 
 def test_offsets():
