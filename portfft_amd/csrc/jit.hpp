@@ -121,7 +121,11 @@ hipError_t jit_launch_strided_split(const strided_kernel* k, hipStream_t stream,
                                     const strided_args& args, int backward);
 /// Make the row-staged form (stockham_strided_row_kernel; fp32, interleaved, no store modifier) of a
 /// runtime-compiled strided entry available: row_out 0 = row-shaped input, 1 = row-shaped output.
-bool jit_strided_ensure_row(const strided_kernel* k, int row_out, size_t max_lds, std::string* why);
+/// split_mode 3 (row_out 0): the row-staged input form of the mixed stage B (interleaved scratch -> split planes),
+/// launched with jit_launch_strided_row_mixed
+bool jit_strided_ensure_row(const strided_kernel* k, int row_out, size_t max_lds, std::string* why, int split_mode = 0);
+hipError_t jit_launch_strided_row_mixed(const strided_kernel* k, hipStream_t stream, unsigned grid,
+                                        const strided_args& args, int backward);
 hipError_t jit_launch_strided_row(const strided_kernel* k, hipStream_t stream, unsigned grid, const strided_args& args,
                                   int backward, int row_out);
 hipError_t jit_launch_strided_mixed(const strided_kernel* k, hipStream_t stream, unsigned grid,

@@ -74,6 +74,8 @@ struct strided_kernel {
   hipFunction_t mfn_mixed[4];
   /// row-staged forms of runtime-compiled entries: mfn_row[row_out * 2 + backward] (lds_bytes_row as above)
   hipFunction_t mfn_row[4];
+  /// ... and the row-staged input form of the mixed stage B (interleaved scratch rows -> split planes): [backward]
+  hipFunction_t mfn_row_mixed[2];
   /// tiled-input form (strided_pass TIN): the four-step stage B behind a group-major stage A of the same group
   /// width; fn_tin[backward]; null when not instantiated
   const void* fn_tin[2];

@@ -662,6 +662,18 @@ struct plan_t {
         s.lds_bytes = k->lds_bytes_row;
       }
     }
+    // mixed stage B (interleaved scratch rows -> the user's planes): always row-staged when the image fits -- its
+    // f-fastest form reads 8 bytes per lane from FPW different rows, and there is no tiled-input form to fall back on
+    // (power-of-two rows only: fp32 N = 65536 1.88 -> 0.91 ms per GiB, 2^20 1.61 -> 1.28; with 8000-byte rows
+    //  -- N = 10^6 -- the f-fastest form spreads over the channels by itself and the staged form loses, 1.84 -> 2.21)
+    if (k->launch == nullptr && mixed && in_buf == BUF_SCRATCH && ia.stride == 1 && ia.dist_inner != 1 &&
+        oa.dist_inner == 1 && (k->n & (k->n - 1)) == 0 && getenv("PFFT_NO_MIXED_ROWS") == nullptr) {
+      std::string why;
+      if (jit_strided_ensure_row(k, 0, max_lds, &why, 3)) {
+        s.row_mode = 1;
+        s.lds_bytes = k->lds_bytes_row;
+      }
+    }
     if (k->launch_row != nullptr && !user_split && k->lds_bytes_row <= max_lds &&
         (want_row == 0 || k->fn_row[(want_row - 1) * 2 + backward] != nullptr)) {  // pre-compiled entries
       s.row_mode = want_row;
@@ -696,7 +708,8 @@ struct plan_t {
     }
     const long long groups = strided_groups(count, a.inner, k->fpw);
     if (k->launch == nullptr && s.row_mode != 0) {
-      s.grid = persistent_grid(nullptr, k->mfn_row[(s.row_mode - 1) * 2 + backward], k->wg, k->lds_bytes_row, groups, 1);
+      s.grid = persistent_grid(nullptr, mixed ? k->mfn_row_mixed[backward] : k->mfn_row[(s.row_mode - 1) * 2 + backward],
+                               k->wg, k->lds_bytes_row, groups, 1);
     } else if (k->launch == nullptr) {  // runtime-compiled: whichever variant this stage will launch
       const bool split_storage = desc.complex_storage == PFFT_SPLIT_COMPLEX;
       hipFunction_t f = user_split ? k->mfn_split[backward] : k->mfn[backward * 2];
@@ -1518,7 +1531,9 @@ struct plan_t {
         a.in_im = in_user ? base_im(s.in_buf) + io : nullptr;
         a.out = const_cast<char*>(base_re(s.out_buf, false)) + oo;
         a.out_im = in_user ? nullptr : const_cast<char*>(base_im(s.out_buf)) + oo;
-        hip_check(jit_launch_strided_mixed(s.strided, stream, grid, a, s.backward, in_user ? 2 : 3), "kernel launch");
+        hip_check(s.row_mode == 1 && !in_user ? jit_launch_strided_row_mixed(s.strided, stream, grid, a, s.backward)
+                                              : jit_launch_strided_mixed(s.strided, stream, grid, a, s.backward, in_user ? 2 : 3),
+                  "kernel launch");
         return;
       }
       if (split && s.in_buf != BUF_SCRATCH) {  // both sides are user buffers

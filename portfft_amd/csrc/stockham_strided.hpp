@@ -463,10 +463,14 @@ __global__ __launch_bounds__(Cfg::WG, Cfg::OCC) void stockham_strided_prefetch_k
 
 /// Strided kernel with a row-shaped side copied through LDS (see strided_pitch).  Interleaved storage, no store
 /// modifier.  ROW_IN: in_stride must be 1 (FFT f starts at f * in_fdist); ROW_OUT: out_stride must be 1.
-template <typename Cfg, bool BWD, bool ROW_IN, bool ROW_OUT>
+/// SPLIT 3 (with ROW_IN): the four-step stage B of SPLIT_COMPLEX data -- interleaved rows of the scratch in, the user's
+/// two planes out (column-shaped stores of the last pass).  Addressed f-fastest that stage read 8 bytes per lane from
+/// FPW different rows (fp32 N = 65536 x 2Ki: 1339 us per GiB); staged it reads whole lines.
+template <typename Cfg, bool BWD, bool ROW_IN, bool ROW_OUT, int SPLIT = 0>
 __global__ __launch_bounds__(Cfg::WG, Cfg::OCC) void stockham_strided_row_kernel(const strided_args a) {
   using T = typename Cfg::T;
   static_assert(Cfg::NP >= 2 && (ROW_IN || ROW_OUT));
+  static_assert(SPLIT == 0 || (SPLIT == 3 && ROW_IN && !ROW_OUT), "row-staged forms: interleaved, or scratch -> planes");
   extern __shared__ __attribute__((aligned(16))) char pfa_smem_strided[];
   cx<T>* lds = reinterpret_cast<cx<T>*>(pfa_smem_strided);
   constexpr int PITCH = strided_pitch<Cfg, true>();
@@ -481,7 +485,7 @@ __global__ __launch_bounds__(Cfg::WG, Cfg::OCC) void stockham_strided_row_kernel
     bool live;
     long long c0;
     long long left;
-    const auto io = strided_group<Cfg, 0>(a, g, f, &live, &c0, &left);
+    const auto io = strided_group<Cfg, SPLIT>(a, g, f, &live, &c0, &left);
     if constexpr (ROW_IN) {
       sfor<0, EPT>([&](auto k_) PFA_LAMBDA {
         constexpr int k = decltype(k_)::value;
