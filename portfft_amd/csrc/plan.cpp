@@ -483,9 +483,9 @@ struct plan_t {
   }
 
   /// four-step stages on SPLIT_COMPLEX data: split user side, interleaved scratch side (runtime-specialised only)
-  const strided_kernel* get_strided_mixed(long long n, long long inner_count, int split_mode) {
+  const strided_kernel* get_strided_mixed(long long n, long long inner_count, int split_mode, int policy = 0) {
     std::string why;
-    return jit_strided_kernel(desc.precision, n, inner_count, split_mode == 2, split_mode, max_lds, &why);
+    return jit_strided_kernel(desc.precision, n, inner_count, split_mode == 2, split_mode, max_lds, &why, false, policy);
   }
 
   /// PFFT_JIT_VERBOSE: say why a configuration stayed on the slower tier
@@ -1119,7 +1119,11 @@ struct plan_t {
     // several chunks of one-work-group-per-CU kernels (C3: fp64 1024-point stages, 130 KiB of LDS) loses ~1 % to the
     // tails of the extra launches, so those two cases keep round 1's plan.
     const size_t all_bytes = per_transform * static_cast<size_t>(count);
-    bool cached = interleaved_io && cache_chunk_bytes() >= per_transform && all_bytes >= cache_chunk_bytes() / 2;
+    // (SPLIT_COMPLEX user data: the mixed-storage stage kernels carry the same writer / reader policies; PFFT_SPLIT_CACHED=0
+    //  keeps them streamed and unchunked as in round 2)
+    const bool split_cached = getenv("PFFT_SPLIT_CACHED") == nullptr || std::atoi(getenv("PFFT_SPLIT_CACHED")) != 0;
+    bool cached = (interleaved_io || split_cached) && cache_chunk_bytes() >= per_transform &&
+                  all_bytes >= cache_chunk_bytes() / 2;
     if (cached && all_bytes > cache_chunk_bytes()) {
       const strided_kernel* pa = find_strided(n1);
       const strided_kernel* pb = find_strided(n2);
@@ -1145,9 +1149,9 @@ struct plan_t {
     const bool interleaved_user = desc.complex_storage == PFFT_INTERLEAVED_COMPLEX;
     const bool user_io = in_buf != BUF_SCRATCH && out_buf != BUF_SCRATCH;
     const strided_kernel* ka = interleaved_user ? get_strided(n1, n2, true, false, false, false, cached ? 1 : 0)
-                                                : (user_io ? get_strided_mixed(n1, n2, 2) : nullptr);
+                                                : (user_io ? get_strided_mixed(n1, n2, 2, cached ? 1 : 0) : nullptr);
     const strided_kernel* kb = interleaved_user ? get_strided(n2, n1, false, false, false, true, cached ? 2 : 0)  // rows in
-                                                : (user_io ? get_strided_mixed(n2, n1, 3) : nullptr);
+                                                : (user_io ? get_strided_mixed(n2, n1, 3, cached ? 2 : 0) : nullptr);
     // Four-step pair: entries tuned as stage A / stage B of a group-major intermediate with equal group widths
     // (strided_kernel::fs_a / fs_b; PFFT_NO_FS_PAIRS=1 keeps the default entries of the two lengths)
     bool fs_pair = false;
