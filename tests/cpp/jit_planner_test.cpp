@@ -31,10 +31,10 @@ int main(int argc, char** argv) {
   long long planned[2] = {0, 0};
   for (int prec = 0; prec < 2; ++prec) {
     const int es = prec ? 16 : 8;
-    for (long long n = 2; n <= 20000; ++n) {
+    for (long long n = 2; n <= 21000; ++n) {
       pfa::wg_params p;
       const bool ok = pfa::choose_spec_params(prec, n, max_lds, &p);
-      if (!smooth31(n) || static_cast<size_t>(n) * es > 128 * 1024) {
+      if (!smooth31(n) || static_cast<size_t>(n) * es > max_lds) {
         EXPECT(!ok, "n=%lld prec=%d should not be planned", n, prec);
         continue;
       }

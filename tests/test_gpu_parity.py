@@ -265,8 +265,10 @@ def test_maximum_sizes():
     a 7-smooth length near the top of the generic tier, and a long prime-factor-31 length"""
     import gpu_utils as G
     pf = _pf()
-    for prec, dtype, sizes in (("f32", np.complex64, [1 << 22, 1 << 24, 10080, 31 * 31 * 31 * 8, 9 * 5 * 7 * 11 * 13 * 16]),
-                               ("f64", np.complex128, [1 << 22, 5040, 31 * 29 * 23 * 4])):
+    # (16807 = 7^5, 19683 = 3^9, 20480, fp64 10125 / 10240: the longest single-work-group transforms -- the whole LDS of a CU)
+    for prec, dtype, sizes in (("f32", np.complex64, [1 << 22, 1 << 24, 10080, 31 * 31 * 31 * 8, 9 * 5 * 7 * 11 * 13 * 16,
+                                                      16807, 18000, 19683, 20480]),
+                               ("f64", np.complex128, [1 << 22, 5040, 31 * 29 * 23 * 4, 9604, 10125, 10240])):
         for n in sizes:
             x, y = H.gen_fourier_data(1, [n], dtype, seed=5)
             d = G.make_descriptor([n], prec)
