@@ -46,6 +46,14 @@ WORKLOADS = {
     "ref256": ([256], 512 * 1024, "f32", "reference bench set medium_small_1d: fp32 N=256 batch=512Ki", 1),
     "ref4096": ([4096], 32 * 1024, "f32", "reference bench set medium_large_1d: fp32 N=4096 batch=32Ki", 1),
     "ref65536": ([65536], 2048, "f32", "reference bench set large_1d: fp32 N=65536 batch=2Ki", 2),
+    # the reference's GLOBAL-tier sizes (test/unit_test/instantiate_fft_tests.hpp:147-151) and the fp32 four-step sizes
+    # beyond them, 1 GiB per buffer
+    "g32_15": ([32768], 4096, "f32", "fp32 four-step N=32768 batch=4Ki (reference GlobalTest size)", 2),
+    "g32_17": ([131072], 1024, "f32", "fp32 four-step N=131072 batch=1Ki (reference GlobalTest size)", 2),
+    "g32_18": ([1 << 18], 512, "f32", "fp32 four-step N=2^18 batch=512", 2),
+    "g32_20": ([1 << 20], 128, "f32", "fp32 four-step N=2^20 batch=128", 2),
+    "g32_22": ([1 << 22], 32, "f32", "fp32 four-step N=2^22 batch=32", 2),
+    "g64_16": ([65536], 1024, "f64", "fp64 four-step N=65536 batch=1Ki (reference GlobalTest size)", 2),
 }
 
 
@@ -176,7 +184,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--config", default="c2", choices=sorted(WORKLOADS),
                     help="c2 (default, the headline line); c3 / c5: the other single-GPU configs of BASELINE.json; "
-                         "ref16 / ref256 / ref4096 / ref65536: the reference's own bench set")
+                         "ref16 / ref256 / ref4096 / ref65536: the reference's own bench set; g32_* / g64_16: four-step "
+                         "(GLOBAL tier) sizes")
     ap.add_argument("--manual", metavar="KEY=VALUE,...",
                     help="any descriptor, in the grammar of the reference's bench_manual_float / bench_manual_double "
                          "(register_manual_bench.hpp), e.g. d=cpx,n=1024x1024,b=64,s=split,p=ip; overrides --config")

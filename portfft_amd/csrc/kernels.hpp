@@ -137,6 +137,14 @@ inline int aux_of_policy(int policy) {
   return policy == 2 ? PFA_AUX_READER : PFA_AUX_NT;
 }
 
+/// Completion event of the submission being enqueued (pfft_execute*_ex with event_out): plan_t::execute arms it in
+/// front of its LAST launch, the launch helpers (kernels_impl.hpp, jit.cpp) take it and hand it to
+/// hipExtLaunchKernel / hipExtModuleLaunchKernel as the dispatch's stop event -- no separate hipEventRecord packet
+/// behind a small transform (tools/latency.py).  Thread-local; whoever armed it records the event the ordinary way
+/// when no launch helper took it.
+void arm_stop_event(hipEvent_t ev);
+hipEvent_t take_stop_event();  // the armed event (and disarms), or nullptr
+
 const strided_kernel* strided_kernels_f32(int* count);
 const strided_kernel* strided_kernels_f64(int* count);
 

@@ -13,6 +13,38 @@
 #include "stockham_wg.hpp"
 #include "stockham_xlane.hpp"
 
+#include <tuple>
+#include <utility>
+
+namespace pfa {
+
+/// Every launch of a pre-compiled kernel: the ordinary launch, or -- when the submission's completion event is armed
+/// (kernels.hpp: arm_stop_event) -- hipExtLaunchKernel with that event as the dispatch's stop event.  The arguments
+/// are converted to the kernel's formal parameter types before they are packed.
+template <typename... KArgs, typename... Args, size_t... I>
+inline hipError_t launch_with_stop_event(void (*kernel)(KArgs...), dim3 g, dim3 b, size_t lds, hipStream_t stream,
+                                         hipEvent_t stop, std::index_sequence<I...>, Args&&... args) {
+  std::tuple<KArgs...> formal(static_cast<KArgs>(args)...);
+  void* p[] = {static_cast<void*>(&std::get<I>(formal))...};
+  return hipExtLaunchKernel(reinterpret_cast<const void*>(kernel), g, b, p, lds, stream, nullptr, stop, 0);
+}
+template <typename... KArgs, typename... Args>
+inline void launch_kernel(void (*kernel)(KArgs...), dim3 g, dim3 b, size_t lds, hipStream_t stream, Args&&... args) {
+  static_assert(sizeof...(KArgs) == sizeof...(Args), "kernel argument count");
+  if (hipEvent_t stop = take_stop_event()) {
+    (void)launch_with_stop_event(kernel, g, b, lds, stream, stop, std::index_sequence_for<KArgs...>{},
+                                 std::forward<Args>(args)...);
+    return;
+  }
+  kernel<<<g, b, lds, stream>>>(static_cast<KArgs>(args)...);
+}
+}  // namespace pfa
+// (hip_runtime.h defines hipLaunchKernelGGL as a macro; inside this library's device translation units every use of it
+//  goes through pfa::launch_kernel)
+#undef hipLaunchKernelGGL
+#define hipLaunchKernelGGL(kernel, grid, block, lds, stream, ...) \
+  ::pfa::launch_kernel(kernel, grid, block, lds, stream, __VA_ARGS__)
+
 namespace pfa {
 
 /// the same configuration with another cache policy (AUX)
@@ -170,7 +202,7 @@ inline hipError_t pfa_launch(K kernel, dim3 g, dim3 b, size_t lds, hipStream_t s
   if (args.any_order != 0) {
     A copy = args;
     void* p[] = {&copy};
-    return hipExtLaunchKernel(reinterpret_cast<const void*>(kernel), g, b, p, lds, stream, nullptr, nullptr,
+    return hipExtLaunchKernel(reinterpret_cast<const void*>(kernel), g, b, p, lds, stream, nullptr, take_stop_event(),
                               hipExtAnyOrderLaunch);
   }
   hipLaunchKernelGGL(kernel, g, b, lds, stream, args);

@@ -27,6 +27,16 @@
 namespace pfa {
 
 namespace {
+thread_local hipEvent_t g_armed_stop_event = nullptr;
+}
+void arm_stop_event(hipEvent_t ev) { g_armed_stop_event = ev; }
+hipEvent_t take_stop_event() {
+  hipEvent_t ev = g_armed_stop_event;
+  g_armed_stop_event = nullptr;
+  return ev;
+}
+
+namespace {
 
 void hip_check(hipError_t e, const char* what) {
   if (e != hipSuccess) fail(PFFT_HIP_ERROR, what, ": ", hipGetErrorString(e));
@@ -1692,16 +1702,37 @@ struct plan_t {
     hip_check(hipStreamWaitEvent(stream, chunk_events[2 * n_chunks - 1], 0), "hipStreamWaitEvent");
   }
 
-  void execute(int direction, const void* in_re, const void* in_im, void* out_re, void* out_im) {
+  /// `completion`: the submission's completion event.  Returns true when it rode on the last launch as that dispatch's
+  /// stop event (kernels.hpp: arm_stop_event); otherwise the caller records it behind the launches.
+  bool execute(int direction, const void* in_re, const void* in_im, void* out_re, void* out_im,
+               hipEvent_t completion = nullptr) {
     if (direction != PFFT_FORWARD && direction != PFFT_BACKWARD) {
       fail(PFFT_INVALID_CONFIGURATION, "Invalid direction ", direction);
     }
     if (in_re == nullptr || out_re == nullptr) fail(PFFT_INVALID_CONFIGURATION, "null data pointer");
     device_guard dg(device);  // launches go to the device the plan was committed on, whatever is current
     const std::vector<stage>& st = stages[direction];
+    bool rode = false;
+    if (completion != nullptr && !st.empty() && st.back().chunk_group < 0 && stop_event_on_launch()) {
+      hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
+      if (hipStreamIsCapturing(stream, &capturing) != hipSuccess || capturing != hipStreamCaptureStatusNone) {
+        completion = nullptr;  // a captured execute records its event as a node of its own
+      }
+    } else {
+      completion = nullptr;
+    }
     for (size_t i = 0; i < st.size();) {
       if (st[i].chunk_group < 0) {
-        run_stage(st[i], in_re, in_im, out_re, out_im);
+        if (completion != nullptr && i + 1 == st.size()) {
+          arm_stop_event(completion);
+          struct disarm {  // also when the launch throws
+            bool* rode;
+            ~disarm() { *rode = take_stop_event() == nullptr; }
+          } guard{&rode};
+          run_stage(st[i], in_re, in_im, out_re, out_im);
+        } else {
+          run_stage(st[i], in_re, in_im, out_re, out_im);
+        }
         ++i;
         continue;
       }
@@ -1720,6 +1751,16 @@ struct plan_t {
       }
       i = j;
     }
+    return rode;
+  }
+
+  /// PFFT_STOP_EVENT_ON_LAUNCH=0: always record completion events with hipEventRecord (A/B, tools/latency.py)
+  static bool stop_event_on_launch() {
+    static const bool on = [] {
+      const char* e = getenv("PFFT_STOP_EVENT_ON_LAUNCH");
+      return e == nullptr || std::atoi(e) != 0;
+    }();
+    return on;
   }
 };
 
@@ -1784,17 +1825,27 @@ void execute_with_events(pfft_plan_t* plan, int32_t n_deps, void* const* deps, v
     const hipError_t e = hipStreamWaitEvent(p.stream, static_cast<hipEvent_t>(deps[i]), 0);
     if (e != hipSuccess) pfa::fail(PFFT_HIP_ERROR, "hipStreamWaitEvent: ", hipGetErrorString(e));
   }
-  run();
-  if (event_out != nullptr) {
-    *event_out = nullptr;
-    hipEvent_t ev = events().get(p.device);
+  if (event_out == nullptr) {
+    (void)run(nullptr);
+    return;
+  }
+  *event_out = nullptr;
+  hipEvent_t ev = events().get(p.device);
+  bool rode = false;
+  try {
+    rode = run(ev);  // true: the event is the stop event of the last dispatch, no packet of its own
+  } catch (...) {
+    (void)events().put(ev);
+    throw;
+  }
+  if (!rode) {
     const hipError_t e = hipEventRecord(ev, p.stream);
     if (e != hipSuccess) {
       (void)events().put(ev);
       pfa::fail(PFFT_HIP_ERROR, "hipEventRecord: ", hipGetErrorString(e));
     }
-    *event_out = ev;
   }
+  *event_out = ev;
 }
 }  // namespace
 
@@ -1855,7 +1906,7 @@ pfft_status pfft_execute_ex(pfft_plan_t* plan, int32_t direction, const void* in
                 "To use interleaved data layout, the descriptor.complex_storage must be INTERLEAVED_COMPLEX");
     }
     execute_with_events(plan, n_deps, deps, event_out,
-                        [&] { plan->impl->execute(direction, in, nullptr, out, nullptr); });
+                        [&](hipEvent_t ev) { return plan->impl->execute(direction, in, nullptr, out, nullptr, ev); });
   });
 }
 
@@ -1870,7 +1921,9 @@ pfft_status pfft_execute_split_ex(pfft_plan_t* plan, int32_t direction, const vo
     }
     if (in_imag == nullptr || out_imag == nullptr) pfa::fail(PFFT_INVALID_CONFIGURATION, "null imaginary pointer");
     execute_with_events(plan, n_deps, deps, event_out,
-                        [&] { plan->impl->execute(direction, in_real, in_imag, out_real, out_imag); });
+                        [&](hipEvent_t ev) {
+                          return plan->impl->execute(direction, in_real, in_imag, out_real, out_imag, ev);
+                        });
   });
 }
 
