@@ -4,6 +4,7 @@ error behaviour follow the reference so that tests read like the reference's own
 Reference: /root/reference/src/portfft/descriptor.hpp:43-271, committed_descriptor.hpp:58-310, enums.hpp:25-56,
 common/exceptions.hpp:32-77.
 """
+import copy as _copy
 import ctypes as C
 import enum
 
@@ -251,23 +252,35 @@ class committed_descriptor:
 
     def __init__(self, desc, queue=None, _clone_of=None):
         self._plan = C.c_void_p()
-        self.params = desc
         if _clone_of is not None:
+            # a copy shares the parent's snapshot: nothing is re-derived from a descriptor the user may have changed
             _check(lib.pfft_plan_clone(_clone_of._plan, C.byref(self._plan)))
-        else:
-            c = desc._c()
-            _check(lib.pfft_plan_create(C.byref(c), C.c_void_p(_stream_handle(queue)), C.byref(self._plan)))
+            for name in ("params", "_device", "_torch", "_split", "_counts", "_scalar", "_real_dtype", "_cplx_dtype"):
+                if hasattr(_clone_of, name):
+                    setattr(self, name, getattr(_clone_of, name))
+            self._no_deps = (C.c_void_p * 1)()
+            return
+        # the committed descriptor is a snapshot (the reference copies `params` at commit): the user's descriptor can be
+        # modified and committed again without touching this plan
+        self.params = _copy.deepcopy(desc)
+        desc = self.params
+        c = desc._c()
+        _check(lib.pfft_plan_create(C.byref(c), C.c_void_p(_stream_handle(queue)), C.byref(self._plan)))
         self._device = None
         self._torch = None
         try:
             import torch
             self._torch = torch
             if torch.cuda.is_available():
-                self._device = torch.cuda.current_device()
+                # the plan lives on the device of its queue: a torch stream knows its device, anything else was
+                # committed on the current one
+                dev = getattr(queue, "device", None)
+                self._device = dev.index if dev is not None and getattr(dev, "index", None) is not None \
+                    else torch.cuda.current_device()
         except ImportError:
             pass
-        # the committed descriptor is a snapshot (the reference copies `params` at commit): element counts, storage and
-        # the dtypes a buffer may have are fixed here, so that a compute call costs a few attribute reads
+        # element counts, storage and the dtypes a buffer may have are fixed here, so that a compute call costs a few
+        # attribute reads
         self._split = desc.complex_storage == complex_storage.SPLIT_COMPLEX
         self._counts = {int(d): (desc.get_input_count(d), desc.get_output_count(d))
                         for d in (direction.FORWARD, direction.BACKWARD)}

@@ -1147,12 +1147,6 @@ struct plan_t {
     long long chunk = static_cast<long long>((cached ? cache_chunk_bytes() : global_chunk_bytes()) / per_transform);
     chunk = std::max<long long>(1, std::min<long long>(chunk, count));
     const int group_id = n_chunk_groups++;
-    const size_t need = static_cast<size_t>(chunk) * per_transform;
-    scratch_bytes = std::max(scratch_bytes, need);
-    if (chunk < count && chunk_overlap_enabled()) {  // consecutive chunks overlap: two halves of the scratch alternate
-      overlap_scratch_half = std::max(overlap_scratch_half, need);
-      scratch_bytes = std::max(scratch_bytes, 2 * overlap_scratch_half);
-    }
     // stage A: for every batch b and column c: length-n1 FFT over rows (stride n2), x W_n^{k1*c}, same layout out
     addressing a_in{ia.offset, n2, 1, n};
     addressing a_out{0, n2, 1, n};
@@ -1175,6 +1169,23 @@ struct plan_t {
         ka = fa;
         kb = fb;
         fs_pair = true;
+      }
+    }
+    // Scratch: one chunk -- or two halves that alternate when consecutive chunks overlap (the first launch of chunk
+    // c + 1 without the in-order barrier).  Only a pre-compiled interleaved stage A can launch that way (pfa_launch);
+    // plans on mixed-storage, runtime-compiled or generic stages keep ONE buffer, and a plan whose chunk is the scratch
+    // cap itself halves the chunk instead of doubling the allocation.
+    {
+      const bool any_order_capable = chunk < count && chunk_overlap_enabled() && interleaved_user && ka != nullptr &&
+                                     ka->launch != nullptr && kb != nullptr;
+      if (any_order_capable && !cached && 2 * static_cast<size_t>(chunk) * per_transform > global_chunk_bytes()) {
+        chunk = std::max<long long>(1, chunk / 2);
+      }
+      const size_t need = static_cast<size_t>(chunk) * per_transform;
+      scratch_bytes = std::max(scratch_bytes, need);
+      if (any_order_capable) {
+        overlap_scratch_half = std::max(overlap_scratch_half, need);
+        scratch_bytes = std::max(scratch_bytes, 2 * overlap_scratch_half);
       }
     }
     const char* dbg = getenv("PFFT_DEBUG_GLOBAL");  // debugging aid: "ga" / "gb" force the generic kernel for a stage
@@ -1475,8 +1486,19 @@ struct plan_t {
 
   /// intermediate of the two-pass 2-D plan when the caller's buffers alias: allocated at commit for IN_PLACE
   /// descriptors, on first use when an OUT_OF_PLACE plan is executed with in == out
+  /// (the lazy path is serialised, refuses to allocate inside a stream capture -- hipMalloc is not capturable: run the
+  ///  aliasing execute once before capturing, or commit the descriptor IN_PLACE)
   void ensure_alias_scratch() {
     if (alias_scratch != nullptr) return;
+    static std::mutex m;
+    std::lock_guard<std::mutex> lock(m);
+    if (alias_scratch != nullptr) return;
+    hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(stream, &capturing) == hipSuccess && capturing != hipStreamCaptureStatusNone) {
+      fail(PFFT_INVALID_CONFIGURATION,
+           "an OUT_OF_PLACE plan executed with aliasing buffers needs an intermediate that cannot be allocated during "
+           "stream capture: execute it once before capturing, or commit the descriptor IN_PLACE");
+    }
     if (alias_scratch_bytes == 0) alias_scratch_bytes = two_pass_chunk_bytes;
     hip_check(hipMalloc(&alias_scratch, alias_scratch_bytes), "hipMalloc(2-D intermediate)");
   }
@@ -1506,7 +1528,8 @@ struct plan_t {
       return split ? static_cast<const char*>(out_im) : static_cast<const char*>(out_re) + sb;
     };
     auto step_of = [&](int buf) { return (buf == BUF_SCRATCH || !split) ? 2 : 1; };
-    const bool aliased = s.alias_scratch != 0 && in_re == out_re;
+    // (split storage: either pair of planes aliasing means the pass cannot write its output over its input)
+    const bool aliased = s.alias_scratch != 0 && (in_re == out_re || (split && in_im != nullptr && in_im == out_im));
     if (aliased) ensure_alias_scratch();
     if (s.rows2d != nullptr) {
       rows2d_args a = s.ra;
@@ -1740,7 +1763,7 @@ struct plan_t {
       while (j < st.size() && st[j].chunk_group == st[i].chunk_group) ++j;
       const long long batches = st[i].count / st[i].ffts_per_batch;
       const long long chunk_batches = std::max<long long>(1, st[i].chunk_batches);
-      if (overlappable(st, i, j, batches > chunk_batches, in_re == out_re)) {
+      if (overlappable(st, i, j, batches > chunk_batches, in_re == out_re || (in_im != nullptr && in_im == out_im))) {
         run_chunks_overlapped(st[i], st[i + 1], batches, chunk_batches, in_re, in_im, out_re, out_im);
         i = j;
         continue;
