@@ -315,3 +315,75 @@ def test_cache_sized_chunks_and_policy_twins():
     g.replay()
     torch.cuda.synchronize()
     assert torch.equal(out, y), "graph replay of a chunked plan"
+
+
+def test_four_step_stage_pairs_and_split_storage():
+    """The four-step (GLOBAL) tier after round 3: registered stage pairs (group-major intermediate, tiled-input stage B,
+    software-pipelined forms), lengths whose two factors have no pair (fall back to the default entries), cache-sized
+    chunks with a ragged last chunk, SPLIT_COMPLEX data through the mixed-storage stages (stage B row-staged through LDS
+    for power-of-two rows, writer / reader policies).  Against NumPy on sampled transforms, round trip through the
+    backward plan, and against the same descriptor planned without the pairs (PFFT_NO_FS_PAIRS=1) / with the split plans
+    streamed (PFFT_SPLIT_CACHED=0, PFFT_NO_MIXED_ROWS=1): same results within the tolerance."""
+    G, pf, torch = _mods()
+
+    def commit(lengths, prec, batch, storage, env=None):
+        old = {k: os.environ.get(k) for k in (env or {})}
+        os.environ.update(env or {})
+        try:
+            return G.make_descriptor(lengths, prec, batch=batch, storage=storage).commit()
+        finally:
+            for k, v in old.items():
+                if v is None:
+                    del os.environ[k]
+                else:
+                    os.environ[k] = v
+
+    def forward(plan, x, split):
+        if split:
+            re, im = x.real.contiguous(), x.imag.contiguous()
+            ore, oim = torch.empty_like(re), torch.empty_like(im)
+            plan.compute_forward(re, im, ore, oim).wait()
+            return torch.complex(ore, oim)
+        y = torch.empty_like(x)
+        plan.compute_forward(x, y).wait()
+        return y
+
+    def backward(plan, y, split):
+        if split:
+            re, im = y.real.contiguous(), y.imag.contiguous()
+            ore, oim = torch.empty_like(re), torch.empty_like(im)
+            plan.compute_backward(re, im, ore, oim).wait()
+            return torch.complex(ore, oim)
+        z = torch.empty_like(y)
+        plan.compute_backward(y, z).wait()
+        return z
+
+    cases = [  # (n, prec, batch, storage)
+        (1 << 15, "f32", 5, 0), (1 << 16, "f32", 5, 0), (1 << 17, "f32", 3, 0), (1 << 18, "f32", 3, 0),
+        (1 << 19, "f32", 3, 0), (1 << 20, "f32", 2, 0), (1 << 21, "f32", 2, 0), (1 << 22, "f32", 2, 0),
+        (1 << 16, "f64", 3, 0), (1 << 20, "f64", 2, 0),
+        (1 << 16, "f32", 600, 0), (1 << 18, "f32", 150, 0), (1 << 20, "f64", 21, 0),   # chunked, ragged last chunk
+        (1 << 16, "f32", 5, 1), (1 << 20, "f32", 2, 1), (1 << 18, "f64", 3, 1), (1000000, "f32", 2, 1),
+        (1 << 16, "f32", 600, 1), (1 << 20, "f32", 40, 1),                              # split, chunked
+    ]
+    for n, prec, batch, storage in cases:
+        cdt = torch.complex64 if prec == "f32" else torch.complex128
+        tol = H.REL_L2_TOL[np.dtype(np.complex64 if prec == "f32" else np.complex128)]
+        g = torch.Generator(device="cuda").manual_seed(n % 1000 + batch)
+        x = torch.empty(batch * n, dtype=cdt, device="cuda")
+        torch.view_as_real(x).uniform_(-1, 1, generator=g)
+        split = storage == 1
+        plan = commit([n], prec, batch, storage)
+        y = forward(plan, x, split)
+        for b in sorted({0, batch // 2, batch - 1}):
+            ref = np.fft.fft(x.view(batch, n)[b].cpu().numpy().astype(np.complex128))
+            assert H.rel_l2(y.view(batch, n)[b].cpu().numpy(), ref) <= tol, (n, prec, batch, storage, b)
+        z = backward(plan, y, split)
+        err = float(((z / n - x).abs().double().pow(2).sum() / x.abs().double().pow(2).sum()).sqrt())
+        assert err <= tol, (n, prec, batch, storage, "round trip", err)
+        env = {"PFFT_NO_FS_PAIRS": "1"} if not split else {"PFFT_SPLIT_CACHED": "0", "PFFT_NO_MIXED_ROWS": "1"}
+        y0 = forward(commit([n], prec, batch, storage, env), x, split)
+        diff = float(((y - y0).abs().double().pow(2).sum() / y0.abs().double().pow(2).sum()).sqrt())
+        assert diff <= tol, (n, prec, batch, storage, "vs the round-2 plan", diff)
+        del x, y, z, y0, plan
+        torch.cuda.empty_cache()
