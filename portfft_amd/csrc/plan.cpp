@@ -1372,9 +1372,20 @@ struct plan_t {
         std::vector<stage> tail;
         pfft_dim_info_t di{};
         tail_policy = cached ? 2 : 0;
+        // the attempt is planned into temporaries: when it is rejected below, whatever plan_1d reserved for it (scratch
+        // of a two-stage column plan, chunk groups) is given back (its small twiddle tables stay uploaded
+        // until the plan goes away)
+        const size_t saved_scratch = scratch_bytes, saved_half = overlap_scratch_half;
+        const int saved_groups = n_chunk_groups;
         const int tier = plan_1d(tail, m, nmat * cols, cols, BUF_OUT, a, BUF_OUT, a, false, scale, backward, &di);
         tail_policy = 0;
-        if (tier == PFFT_TIER_WORKGROUP && tail.size() == 1 && tail[0].strided != nullptr) {
+        const bool accepted = tier == PFFT_TIER_WORKGROUP && tail.size() == 1 && tail[0].strided != nullptr;
+        if (!accepted) {
+          scratch_bytes = saved_scratch;
+          overlap_scratch_half = saved_half;
+          n_chunk_groups = saved_groups;
+        }
+        if (accepted) {
           st.push_back(make_rows2d_stage(rk, nmat, n0, static_cast<long long>(vin.offset),
                                          static_cast<long long>(vout.offset), backward));
           tail[0].alias_scratch = 2;

@@ -1,4 +1,4 @@
-"""Random descriptors against NumPy: rank, lengths (31-smooth), batch, layout (packed / batch-interleaved / unpacked rows /
+"""Random descriptors against NumPy: rank, lengths (61-smooth), batch, layout (packed / batch-interleaved / unpacked rows /
 strided), storage, placement, offsets, scales, precision, direction.  usage: fuzz.py [seed] [iterations] [big2d]
 With `big2d` the shapes are 2-D / 3-D with a long last dimension (256...2048): the two-pass 2-D plan
 (stockham_rows2d.hpp) and its fall-backs."""
@@ -10,7 +10,7 @@ import helpers as H
 import gpu_utils as G
 import portfft_amd as pf
 
-PRIMES = [2, 2, 2, 2, 3, 3, 5, 5, 7, 11, 13, 17, 19, 23, 29, 31]
+PRIMES = [2, 2, 2, 2, 2, 2, 3, 3, 3, 5, 5, 7, 7, 11, 13, 17, 19, 23, 29, 31, 37, 41, 43, 47, 53, 59, 61]
 
 def smooth(rng, lo, hi):
     lo = min(lo, hi)
