@@ -68,14 +68,14 @@ PFA_DEV cx<typename Cfg::T>* stw_lds_tables() {
 
 /// W_M^m as the product of one entry per level
 template <typename Cfg, int IMGDIV = 1>
-PFA_DEV cx<typename Cfg::T> stw_from_lds(const strided_args& a, unsigned long long m) {
+PFA_DEV cx<typename Cfg::T> stw_from_lds(const strided_args& a, unsigned m) {
   const cx<typename Cfg::T>* tab = stw_lds_tables<Cfg, IMGDIV>();
   const unsigned sh = static_cast<unsigned>(a.stw_lshift);
   const unsigned mask = (1u << sh) - 1u;
-  cx<typename Cfg::T> w = tab[static_cast<unsigned>(m) & mask];
-  if (a.stw_levels > 1) w = cmul(w, tab[(1u << sh) + (static_cast<unsigned>(m >> sh) & mask)]);
-  if (a.stw_levels > 2) w = cmul(w, tab[(2u << sh) + (static_cast<unsigned>(m >> (2 * sh)) & mask)]);
-  if (a.stw_levels > 3) w = cmul(w, tab[(3u << sh) + (static_cast<unsigned>(m >> (3 * sh)) & mask)]);
+  cx<typename Cfg::T> w = tab[m & mask];
+  if (a.stw_levels > 1) w = cmul(w, tab[(1u << sh) + ((m >> sh) & mask)]);
+  if (a.stw_levels > 2) w = cmul(w, tab[(2u << sh) + ((m >> (2 * sh)) & mask)]);
+  if (a.stw_levels > 3) w = cmul(w, tab[(3u << sh) + ((m >> (3 * sh)) & mask)]);
   return w;
 }
 
@@ -108,20 +108,21 @@ PFA_DEV void strided_store_butterfly(const IO& io, const strided_args& a, unsign
   // come from the hi/lo tables, the other powers are one multiply away from those
   [[maybe_unused]] cx<T> stw[R];
   if constexpr (STW != 0) {
-    unsigned long long stw_c = static_cast<unsigned long long>(c0 + f);
-    if (a.stw_cdiv > 1) stw_c /= static_cast<unsigned long long>(a.stw_cdiv);
-    const unsigned long long m0 = static_cast<unsigned long long>(base) * stw_c;
-    const unsigned long long ms = static_cast<unsigned long long>(Ns) * stw_c;
+    // exponents in 32 bits: k * c < n1 * n2 = M <= 2^28 for every k of the stage and every column c
+    unsigned stw_c = static_cast<unsigned>(c0 + f);
+    if (a.stw_cdiv > 1) stw_c = static_cast<unsigned>(static_cast<unsigned long long>(c0 + f) / static_cast<unsigned long long>(a.stw_cdiv));
+    const unsigned m0 = base * stw_c;
+    const unsigned ms = static_cast<unsigned>(Ns) * stw_c;
     // W^m: STW == 1 from the small multi-level tables in LDS (strided_copy_stw) -- two L2-resident tables read with
     // scattered 16-byte gathers cost the pre-compiled stage kernels 4.5 % (C3 stage A) to 15 % (fp32 n = 1024) --,
     // STW == 2 from those two global tables (hi/lo split of the exponent): kernels that are bound by their
     // arithmetic and LDS traffic, not by the vector memory path (runtime-planned odd radices with several
     // work-groups per CU: fp32 N = 30000 stage A 144 us with gathers, 185 us with three-level LDS tables)
-    auto root = [&](unsigned long long m) PFA_LAMBDA -> cx<T> {
+    auto root = [&](unsigned m) PFA_LAMBDA -> cx<T> {
       if constexpr (STW == 2) {
         const cx<T>* lo = static_cast<const cx<T>*>(a.stw_lo);
         const cx<T>* hi = static_cast<const cx<T>*>(a.stw_hi);
-        return cmul(lo[m & ((1ull << a.stw_shift) - 1)], hi[m >> a.stw_shift]);
+        return cmul(lo[m & ((1u << a.stw_shift) - 1u)], hi[m >> a.stw_shift]);
       } else {
         return stw_from_lds<Cfg, IMGDIV>(a, m);
       }
@@ -138,7 +139,7 @@ PFA_DEV void strided_store_butterfly(const IO& io, const strided_args& a, unsign
       constexpr int k = decltype(k_)::value;
       cx<T> anchor = w0;
       if constexpr (k > 0) {
-        const unsigned long long mu = ms * static_cast<unsigned long long>(4 * k);
+        const unsigned mu = ms * static_cast<unsigned>(4 * k);
         anchor = cmul(w0, root(mu));
       }
       stw[4 * k] = anchor;
