@@ -61,17 +61,20 @@ def pmc_traffic(config):
     """HBM bytes per execute from the committed rocprofv3 PMC passes of the same command (FETCH_SIZE x2 on gfx950 +
     WRITE_SIZE, separate passes: tools/summarize_pmc.py -> profiles/r*_pmc_traffic*.json); None when no summary is
     committed for this config.  PMC counters cannot be collected from inside this process, so the figure is reported
-    with its provenance."""
+    with its provenance -- and with the planner's record of the launches it was measured on (`bench_kernel_label`,
+    written next to the counters by tools/final_profiles_r3.sh): a plan that has since changed its kernels shows up as
+    `traffic_matches_plan: false` in the line."""
     names = ["r*_pmc_traffic.json"] if config == "c2" else []
     names.append("r*_pmc_traffic_%s.json" % config)
     files = sorted(f for n in names for f in glob.glob(os.path.join(ROOT, "profiles", n)))
     for path in reversed(files):
         try:
             with open(path) as f:
-                return float(json.load(f)["traffic_bytes_per_launch"]), os.path.relpath(path, ROOT)
+                d = json.load(f)
+            return float(d["traffic_bytes_per_launch"]), os.path.relpath(path, ROOT), d.get("bench_kernel_label")
         except (OSError, ValueError, KeyError):
             continue
-    return None, None
+    return None, None, None
 
 
 def _numpy_slice_worker(args):
@@ -365,7 +368,8 @@ def main():
         gflops = flops_per_step / (elapsed / args.steps) / 1e9
         alg_bytes = 2.0 * n * batch_per_gpu * esz  # per execute: every element read once + written once
         achieved = alg_bytes / (avg_kernel_ms * 1e-3) / 1e9
-        traffic, traffic_src = pmc_traffic(args.config)
+        traffic, traffic_src, traffic_label = pmc_traffic(args.config)
+        live_label = kernel_label(plan, lengths)
         result = {
             "metric": METRIC if args.config == "c2" else "GFLOP/s (5Nlog2N) + achieved-HBM%% (%s)" % args.config,
             "value": round(gflops, 1),
@@ -389,7 +393,8 @@ def main():
                        "parity_rel_l2_vs_numpy": worst},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
-                         "kernel": kernel_label(plan, lengths), "hbm_passes_per_execute": launches,
+                         "traffic_matches_plan": None if traffic_label is None else traffic_label == live_label,
+                         "kernel": live_label, "hbm_passes_per_execute": launches,
                          "launches_per_execute": int(plan.info().launches[0]),
                          "kernel_ms": round(avg_kernel_ms, 5),
                          "copy_probe": None if copy_ms is None else {

@@ -19,6 +19,18 @@ python3 tools/summarize_pmc.py $out/pmc_c2 $out/r3_pmc_traffic.json --config c2 
 python3 tools/summarize_pmc.py $out/pmc_c3 $out/r3_pmc_traffic_c3.json --config c3 --kernels stockham_strided --alg-bytes 4294967296 --launches-per-execute 8 --label "C3 fp64 N=2^20 x 128: four-step, 8 chunks of 256 MiB (stage A writer policy, stage B software-pipelined tiled-input reader); FETCH_SIZE counts Infinity-Cache hits" > $out/pmc_c3.sum 2>&1
 python3 tools/summarize_pmc.py $out/pmc_c5 $out/r3_pmc_traffic_c5.json --config c5 --kernels stockham_rows2d,stockham_strided --alg-bytes 4294967296 --launches-per-execute 8 --label "C5 fp32 1024x1024 x 256: two-pass 2-D plan, 8 chunks of 256 MiB" > $out/pmc_c5.sum 2>&1
 python3 tools/summarize_pmc.py $out/pmc_ref65536 $out/r3_pmc_traffic_ref65536.json --config ref65536 --kernels stockham_strided --alg-bytes 2147483648 --launches-per-execute 4 --label "fp32 N=65536 x 2048: four-step, 4 chunks of 256 MiB" > $out/pmc_ref65536.sum 2>&1
+# the planner's record of the launches the counters were taken on goes into the traffic files (bench.py compares it
+# with its live plan: roofline.traffic_matches_plan)
+for c in c2 c3 c5 ref65536; do
+  t=$out/r3_pmc_traffic_$c.json; [ $c = c2 ] && t=$out/r3_pmc_traffic.json
+  python3 - $out/r3_bench_$c.json $t <<'PY'
+import json, sys
+b = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+t = json.load(open(sys.argv[2]))
+t["bench_kernel_label"] = b["roofline"]["kernel"]
+json.dump(t, open(sys.argv[2], "w"), indent=1)
+PY
+done
 # the bench lines again, now that the traffic files exist (their roofline.traffic then agrees with the PMC summaries)
 mkdir -p profiles_tmp && cp $out/r3_pmc_traffic*.json profiles/ 2>/dev/null
 for c in c2 c3 c5 ref65536; do
