@@ -387,3 +387,25 @@ def test_four_step_stage_pairs_and_split_storage():
         assert diff <= tol, (n, prec, batch, storage, "vs the round-2 plan", diff)
         del x, y, z, y0, plan
         torch.cuda.empty_cache()
+
+
+def test_committed_descriptor_is_a_snapshot():
+    """The reference copies `params` at commit (committed_descriptor_impl.hpp:716-725): changing the user's descriptor
+    afterwards -- the common `d.number_of_transforms = ...; d.commit()` pattern -- must not change what an existing plan
+    or its copies validate and run."""
+    G, pf, torch = _mods()
+    d = G.make_descriptor([256], "f32", batch=4)
+    plan = d.commit()
+    d.number_of_transforms = 64                      # the user's object moves on ...
+    d.complex_storage = pf.complex_storage.SPLIT_COMPLEX
+    big = d.commit()
+    assert plan.params.number_of_transforms == 4 and big.params.number_of_transforms == 64
+    x = torch.empty(4 * 256, dtype=torch.complex64, device="cuda")
+    torch.view_as_real(x).uniform_(-1, 1)
+    y, y2 = torch.empty_like(x), torch.empty_like(x)
+    plan.compute_forward(x, y).wait()                # ... the first plan still takes 4 interleaved transforms
+    plan.copy().compute_forward(x, y2).wait()        # and so does its copy (re-derived nothing from `d`)
+    ref = np.fft.fft(x.view(4, 256).cpu().numpy().astype(np.complex128), axis=1)
+    assert H.rel_l2(y.view(4, 256).cpu().numpy(), ref) <= 2e-6 and torch.equal(y, y2)
+    with pytest.raises(pf.invalid_configuration):    # too small for the 64-transform split plan
+        big.compute_forward(x.real.contiguous(), x.imag.contiguous(), y.real.contiguous(), y.imag.contiguous())

@@ -301,6 +301,12 @@ int main() {
   addA<strided_cfg<d, radix_list<16, 8, 8>, 512, 8, 2, W>, K_PLAIN>("A 16.8.8 wg512 fpw8 tiled (production)", true, 4);
   addB<strided_cfg<d, radix_list<16, 8, 8>, 512, 8, 2, RD>, K_TIN>("B 16.8.8 wg512 fpw8 tiled TIN (production)", true, 4);
   addB<strided_cfg<d, radix_list<16, 8, 8>, 512, 8, 2, RD>, K_PLAIN>("B 16.8.8 wg512 fpw8 tiled", true, 4);
+  addA<strided_cfg<d, radix_list<16, 8, 8>, 512, 8, 2, W>, K_PLAIN>("A 16.8.8 wg512 fpw8 tiled gpw2", true, 2);
+  addA<strided_cfg<d, radix_list<16, 8, 8>, 512, 8, 2, W>, K_PLAIN>("A 16.8.8 wg512 fpw8 tiled gpw8", true, 8);
+  addA<strided_cfg<d, radix_list<16, 8, 8>, 512, 8, 2, W>, K_PLAIN>("A 16.8.8 wg512 fpw8 tiled gpw16 (= 1x resident)", true, 16);
+  addA<strided_cfg<d, radix_list<16, 8, 8>, 512, 8, 2, W>, K_NOSTW>("A 16.8.8 wg512 fpw8 tiled WITHOUT stw (timing only)", true, 4);
+  addB<strided_cfg<d, radix_list<16, 8, 8>, 512, 8, 2, RD>, K_PF_TIN>("B PF+TIN 16.8.8 wg512 fpw8 tiled gpw2", true, 2);
+  addB<strided_cfg<d, radix_list<16, 8, 8>, 512, 8, 2, RD>, K_PF_TIN>("B PF+TIN 16.8.8 wg512 fpw8 tiled gpw8", true, 8);
   addA<strided_cfg<d, radix_list<16, 8, 8>, 512, 8, 2, W>, K_PREFETCH>("A PF 16.8.8 wg512 fpw8 tiled", true, 4);
   addB<strided_cfg<d, radix_list<16, 8, 8>, 512, 8, 2, RD>, K_PREFETCH>("B PF 16.8.8 wg512 fpw8 tiled", true, 4);
   addA<sfr_cfg<d, radix_list<2, 8, 8, 8>, 512, 8, 4, W>, K_SFR>("A SFR 2.8.8.8 wg512 fpw8 tiled 2/CU", true, 4);
