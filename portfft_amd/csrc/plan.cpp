@@ -1572,6 +1572,19 @@ struct plan_t {
       a.total = count;
       const long long groups = strided_groups(count, a.inner, s.strided->fpw);
       unsigned grid = static_cast<unsigned>(std::min<long long>(s.grid, std::max<long long>(groups, 1)));
+      // column-shaped input in segments narrower than a 128-byte line (fp32 n = 2048 stages: 8 columns; the planes of
+      // SPLIT_COMPLEX data at 16 fp32 / 8 fp64 columns): neighbouring groups on one XCD (strided_args::pair_xcd).
+      // Only the plain strided kernel forms honour it; the grid becomes a multiple of 16.
+      {
+        const bool in_user_split = split && s.in_buf != BUF_SCRATCH;
+        const size_t seg = static_cast<size_t>(s.strided->fpw) * (in_user_split ? sb : elem_bytes());
+        const bool column_in = a.in_fdist == 1 && a.in_gdist == 0 && a.in_stride > 1;
+        if (column_in && seg < 128 && s.row_mode == 0 && s.tiled_in == 0 && s.strided->fpw > 1 && grid >= 32 &&
+            groups >= 32 && pair_xcd_enabled()) {
+          a.pair_xcd = 1;
+          grid &= ~15u;
+        }
+      }
       if (split && (s.in_buf == BUF_SCRATCH) != (s.out_buf == BUF_SCRATCH)) {  // mixed storage (four-step stages)
         const bool in_user = s.in_buf != BUF_SCRATCH;
         const size_t iu = in_user ? sb : elem_bytes(), ou = in_user ? elem_bytes() : sb;
@@ -1788,6 +1801,15 @@ struct plan_t {
       i = j;
     }
     return rode;
+  }
+
+  /// PFFT_PAIR_XCD=0: never pair narrow-segment groups on one XCD (A/B)
+  static bool pair_xcd_enabled() {
+    static const bool on = [] {
+      const char* e = getenv("PFFT_PAIR_XCD");
+      return e == nullptr || std::atoi(e) != 0;
+    }();
+    return on;
   }
 
   /// PFFT_STOP_EVENT_ON_LAUNCH=0: always record completion events with hipEventRecord (A/B, tools/latency.py)

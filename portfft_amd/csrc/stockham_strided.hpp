@@ -577,7 +577,17 @@ __global__ __launch_bounds__(Cfg::WG, Cfg::OCC) void stockham_strided_kernel(con
   strided_copy_stw<Cfg, STW>(a);
   // (a two-tier grid like the headline kernel's was measured here: neutral on C3 / ref65536, 1.2 % slower on C5, and
   //  the extra loop state alone cost the fp64 n = 256 row-in / column-out shape 15 % -- plain grid-stride loop)
-  for (long long g = blockIdx.x; g < ngroups; g += gridDim.x) {
+  // Groups whose input segments are narrower than a 128-byte line share every line with their neighbour group.  Blocks b
+  // and b + 8 run on the same XCD and are dispatched back to back (MI355X_MICROARCH.md, "workgroup dispatch"), so they
+  // take groups 2k and 2k + 1: the two halves of a line are then fetched by one XCD at about the same time -- 64-byte
+  // segments read at 4.1-4.2 instead of 3.5-3.7 TB/s as a plain copy (tools/probes/seg64_pairing.hip; stores do not
+  // gain).  The permutation is a bijection on every aligned run of 16 blocks; the host rounds the grid to 16.
+  const bool pair = a.pair_xcd != 0 && (gridDim.x & 15u) == 0u;
+  long long g0 = blockIdx.x;
+  if (pair) g0 = (g0 & ~15ll) + 2 * (g0 & 7) + ((g0 >> 3) & 1);
+  const long long gend = pair ? ((ngroups + 15) & ~15ll) : ngroups;
+  for (long long g = g0; g < gend; g += gridDim.x) {
+    if (g >= ngroups) continue;  // (uniform: the ragged last run of a paired grid)
     bool live;
     long long c0;
     long long nlive;

@@ -47,6 +47,9 @@ struct strided_args {
   long long outer_lo;
   long long in_dist_outer_hi, out_dist_outer_hi;
   int any_order;  // host side only: launch without the in-order barrier (pfa_launch)
+  /// 1: blocks b and b + 8 (one XCD, dispatched back to back) take neighbouring groups -- stages whose input segments
+  /// are narrower than a 128-byte line (stockham_strided_kernel); the grid is then a multiple of 16
+  int pair_xcd;
 };
 
 
