@@ -37,6 +37,11 @@ for c in c2 c3 c5 ref65536; do
   if [ $c = c2 ]; then python bench.py > $out/r3_bench_c2.json 2> $out/c2.err; else python bench.py --config $c --no-cpu-baseline > $out/r3_bench_$c.json 2> $out/$c.err; fi
 done
 rmdir profiles_tmp 2>/dev/null
+# multi-rank plumbing on one device: the RCCL branch at world size 1, and 8 ranks (gloo fall-back: RCCL refuses several
+# ranks per device)
+export HSA_ENABLE_IPC_MODE_LEGACY=0
+PFFT_BENCH_FORCE_DIST=1 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 1 --steps 20 --warmup 3 --no-cpu-baseline > $out/r3_bench_rccl_world1.json 2> $out/rccl_w1.err
+PFFT_BENCH_ONE_DEVICE=1 python bench.py --gpus 8 --steps 10 --warmup 2 --no-cpu-baseline > $out/r3_bench_8rank_one_device.json 2> $out/8rank.err
 tools/survey.sh $out/survey > $out/survey.log 2>&1
 for f in $out/r3_bench_*.json; do python3 -c "
 import json,sys

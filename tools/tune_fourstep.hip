@@ -28,6 +28,12 @@ using namespace pfa;
 #if TUNE_CASE == 120
 using T = double;
 constexpr long long N1 = 1024, N2 = 1024, BATCH = 64;
+#elif TUNE_CASE == 116
+using T = double;
+constexpr long long N1 = 256, N2 = 256, BATCH = 1024;
+#elif TUNE_CASE == 118
+using T = double;
+constexpr long long N1 = 512, N2 = 512, BATCH = 256;
 #elif TUNE_CASE == 18
 using T = float;
 constexpr long long N1 = 512, N2 = 512, BATCH = 512;
@@ -297,6 +303,29 @@ int main() {
   addB<sfr_cfg<f, radix_list<4, 8, 8, 8>, 1024, 16, 4, RD>, K_SFR>("B SFR 4.8.8.8 wg1024 fpw16 tiled", true, 4);
   addA<strided_cfg<f, radix_list<16, 16, 8>, 1024, 16, 4, W>, K_HX>("A HX 16.16.8 wg1024(32pt) fpw16 tiled", true, 1);
   addB<strided_cfg<f, radix_list<16, 16, 8>, 1024, 16, 4, RD>, K_HX>("B HX 16.16.8 wg1024(32pt) fpw16 tiled", true, 1);
+#elif TUNE_CASE == 116
+  addA<strided_cfg<d, radix_list<16, 16>, 128, 8, 2, W>, K_PLAIN>("A 16.16 wg128 fpw8 tiled (production)", true, 2);
+  addB<strided_cfg<d, radix_list<16, 16>, 128, 8, 2, RD>, K_TIN>("B 16.16 wg128 fpw8 tiled TIN (production)", true, 2);
+  addB<strided_cfg<d, radix_list<16, 16>, 128, 8, 2, RD>, K_PF_TIN>("B PF+TIN 16.16 wg128 fpw8 tiled", true, 2);
+  addB<strided_cfg<d, radix_list<16, 16>, 128, 8, 2, RD>, K_PF_TIN>("B PF+TIN 16.16 wg128 fpw8 tiled gpw4", true, 4);
+  addA<strided_cfg<d, radix_list<16, 16>, 128, 8, 2, W>, K_PLAIN>("A 16.16 wg128 fpw8 tiled gpw4", true, 4);
+  addA<strided_cfg<d, radix_list<16, 16>, 128, 8, 2, W>, K_PLAIN>("A 16.16 wg128 fpw8 tiled gpw8", true, 8);
+  addA<strided_cfg<d, radix_list<16, 16>, 128, 8, 2, W>, K_PREFETCH>("A PF 16.16 wg128 fpw8 tiled", true, 4);
+  addA<strided_cfg<d, radix_list<16, 16>, 256, 8, 2, W>, K_PLAIN>("A 16.16 wg256(8pt) fpw8 tiled", true, 4);
+  addB<strided_cfg<d, radix_list<16, 16>, 128, 8, 2, RD>, K_TIN>("B 16.16 wg128 fpw8 tiled TIN gpw4", true, 4);
+  addB<strided_cfg<d, radix_list<16, 16>, 128, 8, 2, RD>, K_TIN>("B 16.16 wg128 fpw8 tiled TIN gpw8", true, 8);
+  addA<strided_cfg<d, radix_list<16, 16>, 128, 8, 2, W>, K_NOSTW>("A 16.16 wg128 fpw8 tiled WITHOUT stw (timing only)", true, 2);
+#elif TUNE_CASE == 118
+  addA<strided_cfg<d, radix_list<8, 8, 8>, 512, 8, 2, W>, K_PLAIN>("A 8.8.8 wg512 fpw8 tiled (production)", true, 4);
+  addB<strided_cfg<d, radix_list<8, 8, 8>, 512, 8, 2, RD>, K_TIN>("B 8.8.8 wg512 fpw8 tiled TIN (production)", true, 4);
+  addB<strided_cfg<d, radix_list<8, 8, 8>, 512, 8, 2, RD>, K_PF_TIN>("B PF+TIN 8.8.8 wg512 fpw8 tiled", true, 4);
+  addA<strided_cfg<d, radix_list<8, 8, 8>, 512, 8, 2, W>, K_PREFETCH>("A PF 8.8.8 wg512 fpw8 tiled", true, 4);
+  addA<strided_cfg<d, radix_list<8, 8, 8>, 256, 8, 2, W>, K_PLAIN>("A 8.8.8 wg256(16pt) fpw8 tiled", true, 4);
+  addB<strided_cfg<d, radix_list<8, 8, 8>, 256, 8, 2, RD>, K_TIN>("B 8.8.8 wg256(16pt) fpw8 tiled TIN", true, 4);
+  addA<strided_cfg<d, radix_list<16, 32>, 256, 8, 2, W>, K_PLAIN>("A 16.32 wg256 fpw8 tiled", true, 4);
+  addB<strided_cfg<d, radix_list<32, 16>, 256, 8, 2, RD>, K_PLAIN>("B 32.16 wg256 fpw8 tiled", true, 4);
+  addA<strided_cfg<d, radix_list<8, 8, 8>, 512, 8, 2, W>, K_PLAIN>("A 8.8.8 wg512 fpw8 tiled gpw8", true, 8);
+  addA<strided_cfg<d, radix_list<8, 8, 8>, 512, 8, 2, W>, K_NOSTW>("A 8.8.8 wg512 fpw8 tiled WITHOUT stw (timing only)", true, 4);
 #elif TUNE_CASE == 120
   addA<strided_cfg<d, radix_list<16, 8, 8>, 512, 8, 2, W>, K_PLAIN>("A 16.8.8 wg512 fpw8 tiled (production)", true, 4);
   addB<strided_cfg<d, radix_list<16, 8, 8>, 512, 8, 2, RD>, K_TIN>("B 16.8.8 wg512 fpw8 tiled TIN (production)", true, 4);
