@@ -98,6 +98,10 @@ struct strided_kernel {
   /// such a pair (0: groups_per_wg).
   int fs_a, fs_b, fs_groups_per_wg;
   int fs_only;  // 1: the entry exists only for such pairs (never the default entry of its length)
+  /// 1 (fs_b entries): as stage B of a pair this entry carries the inter-stage twiddles on its LOADS (its tiled-input
+  /// form multiplies the inputs of pass 0: strided_pass0_compute LTW) and stage A runs without the store modifier --
+  /// fp64 n = 1024 (C3): stage A 120 -> 108 us per chunk, stage B 90 -> 91-94 (tools/tune_fourstep.hip case 120)
+  int fs_ltw;
 };
 
 /// First pass of the two-pass 2-D plan (stockham_rows2d.hpp): whole row FFTs of length n + the first radix-rc

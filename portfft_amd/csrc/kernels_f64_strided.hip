@@ -17,10 +17,12 @@ std::vector<strided_kernel> build() {
   // N=2^18 1.500 -> 1.451 ms; N=65536 (n=256) prefers two, N=2^22 (n=2048) one
   add_strided_entries<strided_cfg<d, radix_list<16, 16>, 128, 8, 2, NT>, SE_TIN>(v, 2);     // 256
   add_strided_entries<strided_cfg<d, radix_list<8, 8, 8>, 512, 8, 2, NT>, SE_TIN>(v, 4);    // 512
-  add_strided_entries<strided_cfg<d, radix_list<16, 8, 8>, 512, 8, 2, NT>, SE_TIN | SE_FS_A>(v, 4);   // 1024
+  add_strided_entries<strided_cfg<d, radix_list<16, 8, 8>, 512, 8, 2, NT>, SE_TIN | SE_FS_A | SE_FS_B | SE_PLAIN_WRITER>(v, 4);   // 1024
   // four-step stage B of n2 = 1024 (C3): the software-pipelined kernel in its tiled-input form -- 86-92 us per 256 MiB
   // chunk against 95-96 (tools/tune_fourstep.hip case 120); stage A keeps the entry above (pipelined: equal)
-  add_strided_entries<strided_cfg<d, radix_list<16, 8, 8>, 512, 8, 2, NT>, SE_PREFETCH | SE_TIN | SE_FS_B | SE_FS_ONLY>(v, 4);
+  // ... and it carries the inter-stage twiddles on its loads (SE_LTW): the modifier is 53 % more VALU instructions on
+  // stage A, which has no slack, and is hidden behind stage B's memory time -- A 120 -> 108 us, B 90 -> 91-94
+  add_strided_entries<strided_cfg<d, radix_list<16, 8, 8>, 512, 8, 2, NT>, SE_PREFETCH | SE_TIN | SE_FS_B | SE_FS_ONLY | SE_LTW>(v, 4);
   add_strided_entries<strided_cfg<d, radix_list<16, 16, 8>, 512, 4, 2, NT>, SE_TIN>(v);  // 2048
   // 16 columns per group (256-byte segments) for stages that are column-shaped on both sides (batch-interleaved
   // layouts, N-D outer dimensions): BI N=256 4.7 -> 5.4 TB/s, N=512 4.4 -> 5.0.  The four-step stages keep the

@@ -353,32 +353,34 @@ strided_kernel with_rows(strided_kernel k) {
   return k;
 }
 
-/// (PF: the software-pipelined kernel's tiled-input form)
-template <typename Cfg, bool PF = false>
+/// (PF: the software-pipelined kernel's tiled-input form; LTW: ... carrying the inter-stage twiddles on its loads, tables
+/// in LDS behind the kernel's own)
+template <typename Cfg, bool PF = false, int LTW = 0>
 hipError_t launch_strided_tin(hipStream_t stream, unsigned grid, const strided_args& args, int backward) {
-  constexpr size_t lds = strided_lds_bytes<Cfg>();
+  const size_t lds = strided_lds_bytes<Cfg>() + stw_lds_bytes<Cfg>(args, LTW);
   const dim3 g(grid), b(Cfg::WG);
   if constexpr (PF) {
-    if (backward) return pfa_launch(&stockham_strided_prefetch_kernel<Cfg, true, 0, 0, true>, g, b, lds, stream, args);
-    return pfa_launch(&stockham_strided_prefetch_kernel<Cfg, false, 0, 0, true>, g, b, lds, stream, args);
+    if (backward) return pfa_launch(&stockham_strided_prefetch_kernel<Cfg, true, 0, 0, true, LTW>, g, b, lds, stream, args);
+    return pfa_launch(&stockham_strided_prefetch_kernel<Cfg, false, 0, 0, true, LTW>, g, b, lds, stream, args);
   } else {
+    static_assert(LTW == 0, "the load-side modifier exists in the software-pipelined kernel only");
     if (backward) return pfa_launch(&stockham_strided_kernel<Cfg, true, 0, 0, true>, g, b, lds, stream, args);
     return pfa_launch(&stockham_strided_kernel<Cfg, false, 0, 0, true>, g, b, lds, stream, args);
   }
 }
 
 /// add the tiled-input form (four-step stage B reading a group-major intermediate) to an entry
-template <typename Cfg, bool PF = false>
+template <typename Cfg, bool PF = false, int LTW = 0>
 strided_kernel with_tin(strided_kernel k) {
   static_assert(tin_supported<Cfg>(), "see tin_supported()");
   if constexpr (PF) {
-    k.fn_tin[0] = reinterpret_cast<const void*>(&stockham_strided_prefetch_kernel<Cfg, false, 0, 0, true>);
-    k.fn_tin[1] = reinterpret_cast<const void*>(&stockham_strided_prefetch_kernel<Cfg, true, 0, 0, true>);
+    k.fn_tin[0] = reinterpret_cast<const void*>(&stockham_strided_prefetch_kernel<Cfg, false, 0, 0, true, LTW>);
+    k.fn_tin[1] = reinterpret_cast<const void*>(&stockham_strided_prefetch_kernel<Cfg, true, 0, 0, true, LTW>);
   } else {
     k.fn_tin[0] = reinterpret_cast<const void*>(&stockham_strided_kernel<Cfg, false, 0, 0, true>);
     k.fn_tin[1] = reinterpret_cast<const void*>(&stockham_strided_kernel<Cfg, true, 0, 0, true>);
   }
-  k.launch_tin = &launch_strided_tin<Cfg, PF>;
+  k.launch_tin = &launch_strided_tin<Cfg, PF, LTW>;
   return k;
 }
 
@@ -409,13 +411,16 @@ strided_kernel make_strided_entry_prefetch(int groups_per_wg = 4) {
 
 /// flags of add_strided_entries
 /// SE_FS_A / SE_FS_B: the entry of its length for the four-step stage A / stage B (strided_kernel::fs_a / fs_b)
-enum : unsigned { SE_ROWS = 1, SE_TIN = 2, SE_WIDE = 4, SE_ROWISH = 8, SE_PREFETCH = 16, SE_FS_A = 32, SE_FS_B = 64, SE_FS_ONLY = 128 };
+enum : unsigned { SE_ROWS = 1, SE_TIN = 2, SE_WIDE = 4, SE_ROWISH = 8, SE_PREFETCH = 16, SE_FS_A = 32, SE_FS_B = 64, SE_FS_ONLY = 128,
+                SE_LTW = 256 /* fs_b entry carrying the modifier on its loads (strided_kernel::fs_ltw) */,
+                SE_PLAIN_WRITER = 512 /* the writer twin also carries the forms without store modifier (stage A of an SE_LTW pair) */ };
 
 template <typename Cfg, unsigned F>
 strided_kernel make_strided_entry_flags(int groups_per_wg) {
   strided_kernel k = (F & SE_PREFETCH) ? make_strided_entry_prefetch<Cfg>(groups_per_wg) : make_strided_entry<Cfg>(groups_per_wg);
   if constexpr ((F & SE_ROWS) != 0) k = with_rows<Cfg>(k);
-  if constexpr ((F & SE_TIN) != 0) k = with_tin<Cfg, (F & SE_PREFETCH) != 0>(k);
+  if constexpr ((F & SE_TIN) != 0) k = with_tin<Cfg, (F & SE_PREFETCH) != 0, (F & SE_LTW) != 0 ? 1 : 0>(k);
+  k.fs_ltw = (F & SE_LTW) != 0;
   k.wide = (F & SE_WIDE) != 0;
   k.rowish = (F & SE_ROWISH) != 0;
   k.fs_a = (F & SE_FS_A) != 0;
@@ -488,6 +493,12 @@ strided_kernel make_strided_twin(const strided_kernel& base, int policy) {
       k.fn[3] = reinterpret_cast<const void*>(&stockham_strided_kernel<Cfg, true, true>);
     }
     k.launch = &launch_strided_writer<Cfg, PF>;
+    if constexpr ((F & SE_PLAIN_WRITER) != 0) {  // stage A of a pair whose stage B carries the modifier: no store modifier
+      static_assert(!PF, "plain writer forms: the non-pipelined kernel");
+      k.fn[0] = reinterpret_cast<const void*>(&stockham_strided_kernel<Cfg, false, false>);
+      k.fn[2] = reinterpret_cast<const void*>(&stockham_strided_kernel<Cfg, true, false>);
+      k.launch = &launch_strided<Cfg>;
+    }
   } else {
     if constexpr (PF) {
       k.fn[0] = reinterpret_cast<const void*>(&stockham_strided_prefetch_kernel<Cfg, false, false>);
@@ -502,7 +513,7 @@ strided_kernel make_strided_twin(const strided_kernel& base, int policy) {
       k.fn_row[1] = reinterpret_cast<const void*>(&stockham_strided_row_kernel<Cfg, true, true, false>);
       k.launch_row = &launch_strided_row_in<Cfg>;
     }
-    if constexpr ((F & SE_TIN) != 0) k = with_tin<Cfg, PF>(k);
+    if constexpr ((F & SE_TIN) != 0) k = with_tin<Cfg, PF, (F & SE_LTW) != 0 ? 1 : 0>(k);
   }
   return k;
 }

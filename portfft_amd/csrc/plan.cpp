@@ -360,10 +360,12 @@ struct plan_t {
   /// Store-modifier tables of a strided stage: L tables of 2^shift entries, table l = W_M^(i << (l * shift)), so that
   /// W_M^m is the product of one entry per table (stockham_strided.hpp: stw_from_lds).  The kernel copies them behind
   /// its own LDS once per work-group (round 1: two L2-resident tables read with scattered gathers).
-  void attach_store_tables(stage& s, long long M) {
+  /// on_loads: the tables of a stage B that carries the modifier on its loads (strided_kernel::fs_ltw; pre-compiled
+  /// tiled-input form, tables in LDS): the stage keeps store_modifier == 0, its fn_tin forms get the larger LDS limit.
+  void attach_store_tables(stage& s, long long M, bool on_loads = false) {
     const strided_kernel* k = s.strided;
-    s.store_modifier = 1;
-    if (k->stw_mode != 1) {  // this kernel's store-modifier forms read two global tables (strided_kernel::stw_mode)
+    s.store_modifier = on_loads ? 0 : 1;
+    if (k->stw_mode != 1 && !on_loads) {  // this kernel's store-modifier forms read two global tables (strided_kernel::stw_mode)
       int sh = 0;
       while ((1ll << (2 * sh)) < M) ++sh;
       upload_store_twiddles(M, sh, &s.sa.stw_lo, &s.sa.stw_hi);
@@ -396,8 +398,18 @@ struct plan_t {
     s.sa.stw_tab = slot;
     s.sa.stw_levels = levels;
     s.sa.stw_lshift = shift;
-    s.store_modifier = 1;
     const size_t total = k->lds_bytes + extra;
+    if (on_loads) {
+      for (int d = 0; d < 2; ++d) {
+        if (k->fn_tin[d] != nullptr && total > 48 * 1024) {
+          hip_check(hipFuncSetAttribute(k->fn_tin[d], hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(total)),
+                    "hipFuncSetAttribute");
+        }
+      }
+      s.lds_bytes = total;
+      return;
+    }
+    s.store_modifier = 1;
     if (k->launch != nullptr) {  // pre-compiled: the store-modifier forms get the larger dynamic LDS limit
       for (int d = 0; d < 2; ++d) {
         if (k->fn[d * 2 + 1] != nullptr && total > 48 * 1024) {
@@ -443,9 +455,16 @@ struct plan_t {
     const strided_kernel* k =
         desc.precision == PFFT_PRECISION_F64 ? strided_kernels_f64(&count) : strided_kernels_f32(&count);
     const strided_kernel* found = nullptr;
-    for (int i = 0; i < count && fs_stage != 0; ++i) {
-      if (k[i].n != n || k[i].lds_bytes > max_lds || k[i].policy != policy) continue;
-      if ((fs_stage == 1 && k[i].fs_a != 0) || (fs_stage == 2 && k[i].fs_b != 0)) return &k[i];
+    // (stage B: an entry that carries the modifier on its loads first -- PFFT_NO_LTW=1 hides those entries, their
+    //  tiled-input form cannot run without the tables)
+    const bool ltw_ok = getenv("PFFT_NO_LTW") == nullptr;
+    for (int pass = 0; pass < 2 && fs_stage != 0; ++pass) {
+      for (int i = 0; i < count; ++i) {
+        if (k[i].n != n || k[i].lds_bytes > max_lds || k[i].policy != policy) continue;
+        if (k[i].fs_ltw != 0 && (!ltw_ok || pass == 1)) continue;
+        if (pass == 0 && fs_stage == 2 && k[i].fs_ltw == 0) continue;
+        if ((fs_stage == 1 && k[i].fs_a != 0) || (fs_stage == 2 && k[i].fs_b != 0)) return &k[i];
+      }
     }
     if (fs_stage != 0) return nullptr;
     // (the narrow pair entries are for stages with one contiguous side: with both sides strided -- batch-interleaved
@@ -1173,6 +1192,11 @@ struct plan_t {
         fs_pair = true;
       }
     }
+    // the pair's stage B may carry the inter-stage twiddles on its loads; stage A then has no store modifier
+    // (PFFT_NO_LTW=1: the modifier stays on stage A's stores)
+    bool ltw = fs_pair && kb->fs_ltw != 0 && kb->stw_mode == 1 && store_tables_fit(kb, n) && ka->fn[0] != nullptr &&
+               getenv("PFFT_NO_LTW") == nullptr && getenv("PFFT_DEBUG_GLOBAL") == nullptr &&
+               strided_fits(ka, n2, in_buf, addressing{ia.offset, n2, 1, n}, BUF_SCRATCH, addressing{0, n2, 1, n});
     // Scratch: one chunk -- or two halves that alternate when consecutive chunks overlap (the first launch of chunk
     // c + 1 without the in-order barrier).  Only a pre-compiled interleaved stage A can launch that way (pfa_launch);
     // plans on mixed-storage, runtime-compiled or generic stages keep ONE buffer, and a plan whose chunk is the scratch
@@ -1197,10 +1221,11 @@ struct plan_t {
     if (!force_generic_a && strided_fits(ka, n2, in_buf, a_in, BUF_SCRATCH, a_out) && store_tables_fit(ka, n)) {
       // conjugating on load and store in both stages is the identity in between, so the backward transform can use
       // the kernels' BWD form on both
-      sa = make_strided_stage(ka, count * n2, n2, in_buf, a_in, BUF_SCRATCH, a_out, 1.0, backward, 1);
-      attach_store_tables(sa, n);
+      sa = make_strided_stage(ka, count * n2, n2, in_buf, a_in, BUF_SCRATCH, a_out, 1.0, backward, ltw ? 0 : 1);
+      if (!ltw) attach_store_tables(sa, n);
       if (fs_pair && ka->fs_groups_per_wg > 0) sa.gpw = ka->fs_groups_per_wg;
     } else {
+      ltw = false;  // (cannot happen for a registered pair; the generic stage A always carries the modifier itself)
       sa = make_generic_stage(n1, count * n2, n2, in_buf, a_in, BUF_SCRATCH, a_out, 1.0, backward, backward);
       int shift = 0;  // the generic kernel reads two global tables (hi/lo split of the exponent)
       while ((1ll << (2 * shift)) < n) ++shift;
@@ -1279,6 +1304,10 @@ struct plan_t {
         if (sb.strided->launch_tin != nullptr && sb.strided->fpw == t && getenv("PFFT_NO_TILED_LANES") == nullptr) {
           sb.tiled_in = 1;
         }
+        if (ltw && sb.tiled_in == 0) {
+          fail(PFFT_INTERNAL_ERROR, "four-step pair: the load-modifier stage B lost its tiled-input form");
+        }
+        if (ltw) attach_store_tables(sb, n, true);
       }
     }
     if (chunk < count || fs_pair) {  // (a pair's stages may carry their own grid rule / the tiled-input form)

@@ -91,6 +91,67 @@ PFA_DEV void strided_copy_stw(const strided_args& a) {
   }
 }
 
+/// v[u] *= W_M^{(base + u * stride) * c}, u < R -- the inter-stage twiddles of the four-step decomposition, for the
+/// butterfly outputs of a stage A's last pass (base = element index, stride = Ns) or for the butterfly inputs of a
+/// stage B's first pass (base = j, stride = N / R: strided_pass0_compute LTW).  W^{base*c}, the step W^{stride*c} and
+/// every fourth power of the step come from the tables, the other powers are one multiply away from those.
+/// Exponents in 32 bits: k * c < n1 * n2 = M <= 2^28 for every element k of a stage and every column c.
+template <typename Cfg, int STW, int R, int IMGDIV = 1>
+PFA_DEV void stw_apply(const strided_args& a, unsigned base, unsigned stride, unsigned stw_c, cx<typename Cfg::T> (&v)[R]) {
+  using T = typename Cfg::T;
+  static_assert(STW != 0, "no modifier requested");
+  const unsigned m0 = base * stw_c;
+  const unsigned ms = stride * stw_c;
+  // W^m: STW == 1 from the small multi-level tables in LDS (strided_copy_stw) -- two L2-resident tables read with
+  // scattered 16-byte gathers cost the pre-compiled stage kernels 4.5 % (C3 stage A) to 15 % (fp32 n = 1024) --,
+  // STW == 2 from those two global tables (hi/lo split of the exponent): kernels that are bound by their
+  // arithmetic and LDS traffic, not by the vector memory path (runtime-planned odd radices with several
+  // work-groups per CU: fp32 N = 30000 stage A 144 us with gathers, 185 us with three-level LDS tables)
+  auto root = [&](unsigned m) PFA_LAMBDA -> cx<T> {
+    if constexpr (STW == 2) {
+      const cx<T>* lo = static_cast<const cx<T>*>(a.stw_lo);
+      const cx<T>* hi = static_cast<const cx<T>*>(a.stw_hi);
+      return cmul(lo[m & ((1u << a.stw_shift) - 1u)], hi[m >> a.stw_shift]);
+    } else {
+      return stw_from_lds<Cfg, IMGDIV>(a, m);
+    }
+  };
+  const cx<T> w0 = root(m0);
+  // stw[u] = W^{(base + u*stride)*c} = w0 * step^u.  Every fourth one is w0 times a table value (anchor), the
+  // three behind it are one multiply away from their anchor -- a chain of squarings of the step would amplify
+  // its rounding by u (radix 32: ~45 ulp in fp32), and folding w0 into the anchors saves R multiplies.
+  cx<T> stw[R];
+  [[maybe_unused]] cx<T> pw[4];
+  if constexpr (R > 1) pw[1] = root(ms);
+  if constexpr (R > 2) pw[2] = cmul(pw[1], pw[1]);
+  if constexpr (R > 3) pw[3] = cmul(pw[2], pw[1]);
+  sfor<0, (R + 3) / 4>([&](auto k_) PFA_LAMBDA {
+    constexpr int k = decltype(k_)::value;
+    cx<T> anchor = w0;
+    if constexpr (k > 0) {
+      const unsigned mu = ms * static_cast<unsigned>(4 * k);
+      anchor = cmul(w0, root(mu));
+    }
+    stw[4 * k] = anchor;
+    sfor<1, 4>([&](auto r_) PFA_LAMBDA {
+      constexpr int r = decltype(r_)::value;
+      if constexpr (4 * k + r < R) stw[4 * k + r] = cmul(anchor, pw[r]);
+    });
+  });
+  sfor<0, R>([&](auto u_) PFA_LAMBDA {
+    constexpr int u = decltype(u_)::value;
+    v[u] = cmul(v[u], stw[u]);
+  });
+}
+
+/// column index of the store / load modifier of FFT f of a group (strided_args::stw_cdiv: 1 for packed data)
+PFA_DEV unsigned stw_column(const strided_args& a, long long c0, unsigned f) {
+  if (a.stw_cdiv > 1) {
+    return static_cast<unsigned>(static_cast<unsigned long long>(c0 + f) / static_cast<unsigned long long>(a.stw_cdiv));
+  }
+  return static_cast<unsigned>(c0 + f);
+}
+
 /// The HBM side of a last pass: butterfly outputs v[u] = element (base + u * Ns) of FFT f go to memory, conjugated
 /// for the backward transform, scaled, and -- STW -- multiplied by the store modifier W_M^{k*c}.
 template <typename Cfg, bool BWD, int STW, int R, int Ns, typename IO, int IMGDIV = 1>
@@ -104,55 +165,10 @@ PFA_DEV void strided_store_butterfly(const IO& io, const strided_args& a, unsign
       live ? (f * a.out_fdist + (base >> osh) * a.out_stride + (base & ((1u << osh) - 1u)) * omul) * ES_OUT
            : 0xFFFFFFF0u;
   const T scale = static_cast<T>(a.scale);
-  // store modifier W_M^{k*c}, k = base + u*Ns: W^{base*c}, the step W^{Ns*c} and every fourth power of the step
-  // come from the hi/lo tables, the other powers are one multiply away from those
-  [[maybe_unused]] cx<T> stw[R];
-  if constexpr (STW != 0) {
-    // exponents in 32 bits: k * c < n1 * n2 = M <= 2^28 for every k of the stage and every column c
-    unsigned stw_c = static_cast<unsigned>(c0 + f);
-    if (a.stw_cdiv > 1) stw_c = static_cast<unsigned>(static_cast<unsigned long long>(c0 + f) / static_cast<unsigned long long>(a.stw_cdiv));
-    const unsigned m0 = base * stw_c;
-    const unsigned ms = static_cast<unsigned>(Ns) * stw_c;
-    // W^m: STW == 1 from the small multi-level tables in LDS (strided_copy_stw) -- two L2-resident tables read with
-    // scattered 16-byte gathers cost the pre-compiled stage kernels 4.5 % (C3 stage A) to 15 % (fp32 n = 1024) --,
-    // STW == 2 from those two global tables (hi/lo split of the exponent): kernels that are bound by their
-    // arithmetic and LDS traffic, not by the vector memory path (runtime-planned odd radices with several
-    // work-groups per CU: fp32 N = 30000 stage A 144 us with gathers, 185 us with three-level LDS tables)
-    auto root = [&](unsigned m) PFA_LAMBDA -> cx<T> {
-      if constexpr (STW == 2) {
-        const cx<T>* lo = static_cast<const cx<T>*>(a.stw_lo);
-        const cx<T>* hi = static_cast<const cx<T>*>(a.stw_hi);
-        return cmul(lo[m & ((1u << a.stw_shift) - 1u)], hi[m >> a.stw_shift]);
-      } else {
-        return stw_from_lds<Cfg, IMGDIV>(a, m);
-      }
-    };
-    const cx<T> w0 = root(m0);
-    // stw[u] = W^{(base + u*Ns)*c} = w0 * step^u.  Every fourth one is w0 times a table value (anchor), the
-    // three behind it are one multiply away from their anchor -- a chain of squarings of the step would amplify
-    // its rounding by u (radix 32: ~45 ulp in fp32), and folding w0 into the anchors saves R multiplies.
-    [[maybe_unused]] cx<T> pw[4];
-    if constexpr (R > 1) pw[1] = root(ms);
-    if constexpr (R > 2) pw[2] = cmul(pw[1], pw[1]);
-    if constexpr (R > 3) pw[3] = cmul(pw[2], pw[1]);
-    sfor<0, (R + 3) / 4>([&](auto k_) PFA_LAMBDA {
-      constexpr int k = decltype(k_)::value;
-      cx<T> anchor = w0;
-      if constexpr (k > 0) {
-        const unsigned mu = ms * static_cast<unsigned>(4 * k);
-        anchor = cmul(w0, root(mu));
-      }
-      stw[4 * k] = anchor;
-      sfor<1, 4>([&](auto r_) PFA_LAMBDA {
-        constexpr int r = decltype(r_)::value;
-        if constexpr (4 * k + r < R) stw[4 * k + r] = cmul(anchor, pw[r]);
-      });
-    });
-  }
+  if constexpr (STW != 0) stw_apply<Cfg, STW, R, IMGDIV>(a, base, static_cast<unsigned>(Ns), stw_column(a, c0, f), v);
   sfor<0, R>([&](auto u_) PFA_LAMBDA {
     constexpr int u = decltype(u_)::value;
     cx<T> y = v[u];
-    if constexpr (STW != 0) y = cmul(y, stw[u]);
     if constexpr (BWD) y.im = -y.im;
     y.re *= scale;
     y.im *= scale;
@@ -325,9 +341,12 @@ PFA_DEV void strided_pass0_load(const IO& io, const strided_args& a, unsigned f,
   });
 }
 
-template <typename Cfg, bool TIN = false>
+/// LTW (1 LDS tables / 2 global tables, as STW): the inter-stage twiddles applied to the INPUTS of the stage -- element
+/// j + t * NB of the FFT with inner index c0 + f is multiplied by W_M^{(j + t*NB) * c} before pass 0 (the four-step
+/// stage B carrying the modifier instead of stage A's stores)
+template <typename Cfg, bool TIN = false, int LTW = 0>
 PFA_DEV void strided_pass0_compute(cx<typename Cfg::T> (&v)[Cfg::bpt(0)][Cfg::Seq::r[0]], unsigned f, unsigned tid,
-                                   cx<typename Cfg::T>* lds) {
+                                   cx<typename Cfg::T>* lds, const strided_args* a = nullptr, long long c0 = 0) {
   constexpr int R = Cfg::Seq::r[0];
   constexpr int NB = Cfg::N / R;
   constexpr bool ragged = (NB % Cfg::TPF) != 0;
@@ -335,6 +354,7 @@ PFA_DEV void strided_pass0_compute(cx<typename Cfg::T> (&v)[Cfg::bpt(0)][Cfg::Se
     constexpr int i = decltype(i_)::value;
     const unsigned j = tid + i * Cfg::TPF;
     if (!ragged || j < NB) {
+      if constexpr (LTW != 0) stw_apply<Cfg, LTW, R>(*a, j, static_cast<unsigned>(NB), stw_column(*a, c0, f), v[i]);
       dft<R>(v[i]);
       // TIN: element e = j * R + u of FFT f goes to slot f ^ (j % FPW) (strided_pass)
       cx<typename Cfg::T>* p = lds + (j * R) * Cfg::FPW + (TIN ? (f ^ (j % Cfg::FPW)) : f);
@@ -416,7 +436,7 @@ PFA_DEV void strided_copy_twiddles(cx<typename Cfg::T>* lds, const cx<typename C
 /// Software-pipelined strided kernel: the loads of the work-group's next group are in flight during the LDS passes
 /// of the current one (see stockham_wg_prefetch_kernel).  TIN: tiled input read with the lanes element-fastest inside
 /// the tiles (strided_pass), for the four-step stage B behind a group-major stage A.
-template <typename Cfg, bool BWD, int STW, int SPLIT = 0, bool TIN = false>
+template <typename Cfg, bool BWD, int STW, int SPLIT = 0, bool TIN = false, int LTW = 0>
 __global__ __launch_bounds__(Cfg::WG, Cfg::OCC) void stockham_strided_prefetch_kernel(const strided_args a) {
   using T = typename Cfg::T;
   static_assert(Cfg::NP >= 2, "the strided tier needs at least two passes (LDS exchange)");
@@ -429,8 +449,9 @@ __global__ __launch_bounds__(Cfg::WG, Cfg::OCC) void stockham_strided_prefetch_k
   const long long ngroups = strided_ngroups<Cfg>(a);
   long long g = blockIdx.x;
   if (g >= ngroups) return;
+  static_assert(STW == 0 || LTW == 0, "the modifier sits on one side of the stage");
   strided_copy_twiddles<Cfg>(lds, tw);
-  strided_copy_stw<Cfg, STW>(a);
+  strided_copy_stw<Cfg, STW != 0 ? STW : LTW>(a);
   cx<T> cur[Cfg::bpt(0)][Cfg::Seq::r[0]];
   cx<T> nxt[Cfg::bpt(0)][Cfg::Seq::r[0]];
   bool live, live_n = false;
@@ -443,7 +464,7 @@ __global__ __launch_bounds__(Cfg::WG, Cfg::OCC) void stockham_strided_prefetch_k
   if constexpr (TIN) tin_lanes<Cfg>(&f0, &tid0, &live0, nlive);
   strided_pass0_load<Cfg, BWD>(io, a, f0, tid0, live0, cur);
   for (; g < ngroups; g += gridDim.x) {
-    strided_pass0_compute<Cfg, TIN>(cur, f0, tid0, lds);
+    strided_pass0_compute<Cfg, TIN, LTW>(cur, f0, tid0, lds, &a, c0);
     const long long gn = g + gridDim.x;
     if (gn < ngroups) {
       io_n = strided_group<Cfg, SPLIT>(a, gn, f, &live_n, &c0_n, &nlive_n);

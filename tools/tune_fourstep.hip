@@ -73,7 +73,7 @@ __global__ void fill_uniform(T* p, size_t n, unsigned seed) {
   }
 }
 
-enum kind_t { K_PLAIN = 0, K_PREFETCH = 1, K_HX = 2, K_ROW_IN = 3, K_TIN = 4, K_NOSTW = 5 /* timing only: stage A without its store modifier */, K_PF_TIN = 6, K_SFR = 7 };
+enum kind_t { K_PLAIN = 0, K_PREFETCH = 1, K_HX = 2, K_ROW_IN = 3, K_TIN = 4, K_NOSTW = 5 /* timing only: stage A without its store modifier */, K_PF_TIN = 6, K_SFR = 7, K_PF_TIN_LTW = 8 /* stage B carrying the modifier on its loads */ };
 struct variant {
   std::string name;
   int kind, fpw, wg, gpw;
@@ -96,6 +96,7 @@ void add(const char* name, bool tiled, int gpw, size_t extra_lds = 0) {
   if constexpr (KIND == K_PREFETCH) { fn = (const void*)&stockham_strided_prefetch_kernel<Cfg, false, STW>; lds = strided_lds_bytes<Cfg>(); }
   else if constexpr (KIND == K_PF_TIN) { fn = (const void*)&stockham_strided_prefetch_kernel<Cfg, false, STW, 0, true>; lds = strided_lds_bytes<Cfg>(); }
   else if constexpr (KIND == K_SFR) { fn = (const void*)&stockham_strided_sfr_kernel<Cfg, false, STW>; lds = strided_sfr_lds_bytes<Cfg>(); }
+  else if constexpr (KIND == K_PF_TIN_LTW) { fn = (const void*)&stockham_strided_prefetch_kernel<Cfg, false, 0, 0, true, 1>; lds = strided_lds_bytes<Cfg>() + ((size_t)g_stw_levels << g_stw_shift) * sizeof(cx<T>); }
   else if constexpr (KIND == K_HX) { fn = (const void*)&stockham_strided_hx_kernel<Cfg, false, STW>; lds = strided_hx_lds_bytes<Cfg>(); }
   else if constexpr (KIND == K_ROW_IN) { fn = (const void*)&stockham_strided_row_kernel<Cfg, false, true, false>; lds = strided_row_lds_bytes<Cfg>(); }
   else if constexpr (KIND == K_TIN) { fn = (const void*)&stockham_strided_kernel<Cfg, false, STW, 0, true>; lds = strided_lds_bytes<Cfg>(); }
@@ -111,6 +112,7 @@ void add(const char* name, bool tiled, int gpw, size_t extra_lds = 0) {
     if constexpr (KIND == K_PREFETCH) hipLaunchKernelGGL((stockham_strided_prefetch_kernel<Cfg, false, STW>), dim3(grid), dim3(Cfg::WG), lds, 0, a);
     else if constexpr (KIND == K_PF_TIN) hipLaunchKernelGGL((stockham_strided_prefetch_kernel<Cfg, false, STW, 0, true>), dim3(grid), dim3(Cfg::WG), lds, 0, a);
     else if constexpr (KIND == K_SFR) hipLaunchKernelGGL((stockham_strided_sfr_kernel<Cfg, false, STW>), dim3(grid), dim3(Cfg::WG), lds, 0, a);
+    else if constexpr (KIND == K_PF_TIN_LTW) hipLaunchKernelGGL((stockham_strided_prefetch_kernel<Cfg, false, 0, 0, true, 1>), dim3(grid), dim3(Cfg::WG), lds, 0, a);
     else if constexpr (KIND == K_HX) hipLaunchKernelGGL((stockham_strided_hx_kernel<Cfg, false, STW>), dim3(grid), dim3(Cfg::WG), lds, 0, a);
     else if constexpr (KIND == K_ROW_IN) hipLaunchKernelGGL((stockham_strided_row_kernel<Cfg, false, true, false>), dim3(grid), dim3(Cfg::WG), lds, 0, a);
     else if constexpr (KIND == K_TIN) hipLaunchKernelGGL((stockham_strided_kernel<Cfg, false, STW, 0, true>), dim3(grid), dim3(Cfg::WG), lds, 0, a);
@@ -144,7 +146,7 @@ static strided_args args_b(const variant& v, const T* scratch, T* out, long long
   strided_args a{};
   a.in = scratch; a.out = out; a.tw = v.tw; a.total = nb * N1; a.inner = N1;
   a.in_dist_outer = N; a.out_dist_outer = N; a.in_stride = 1; a.in_fdist = (unsigned)N2; a.out_stride = (unsigned)N1; a.out_fdist = 1;
-  a.scale = 1.0; a.stw_cdiv = 1;
+  a.scale = 1.0; a.stw_tab = g_stw_tab; a.stw_levels = g_stw_levels; a.stw_lshift = g_stw_shift; a.stw_cdiv = 1;
   if (t_layout > 0) {
     int sh = 0; while ((1 << sh) < t_layout) ++sh;
     a.in_tile_shift = sh; a.in_stride = (unsigned)(N1 * t_layout); a.in_fdist = (unsigned)t_layout;
@@ -247,6 +249,7 @@ int main() {
   addB<strided_cfg<f, radix_list<16, 8, 8>, 1024, 16, 4, RD>, K_PF_TIN>("B PF+TIN 16.8.8 wg1024 fpw16 tiled", true, 4);
   addB<strided_cfg<f, radix_list<16, 8, 8>, 1024, 16, 4, RD>, K_PF_TIN>("B PF+TIN 16.8.8 wg1024 fpw16 tiled gpw8", true, 8);
   addB<strided_cfg<f, radix_list<32, 32>, 512, 16, 2, RD>, K_PF_TIN>("B PF+TIN 32.32 wg512 fpw16 tiled", true, 4);
+  addB<strided_cfg<f, radix_list<32, 32>, 512, 16, 2, RD>, K_PF_TIN_LTW>("B PF+TIN+LTW 32.32 wg512 fpw16 tiled (modifier on loads)", true, 4);
   addB<strided_cfg<f, radix_list<16, 8, 8>, 1024, 16, 4, RD>, K_TIN>("B 16.8.8 wg1024 fpw16 tiled TIN gpw2", true, 2);
   addB<strided_cfg<f, radix_list<16, 8, 8>, 1024, 16, 4, RD>, K_TIN>("B 16.8.8 wg1024 fpw16 tiled TIN gpw8", true, 8);
 #elif TUNE_CASE == 18
@@ -334,6 +337,7 @@ int main() {
   addA<strided_cfg<d, radix_list<16, 8, 8>, 512, 8, 2, W>, K_PLAIN>("A 16.8.8 wg512 fpw8 tiled gpw8", true, 8);
   addA<strided_cfg<d, radix_list<16, 8, 8>, 512, 8, 2, W>, K_PLAIN>("A 16.8.8 wg512 fpw8 tiled gpw16 (= 1x resident)", true, 16);
   addA<strided_cfg<d, radix_list<16, 8, 8>, 512, 8, 2, W>, K_NOSTW>("A 16.8.8 wg512 fpw8 tiled WITHOUT stw (timing only)", true, 4);
+  addB<strided_cfg<d, radix_list<16, 8, 8>, 512, 8, 2, RD>, K_PF_TIN_LTW>("B PF+TIN+LTW 16.8.8 wg512 fpw8 tiled (modifier on loads)", true, 4);
   addB<strided_cfg<d, radix_list<16, 8, 8>, 512, 8, 2, RD>, K_PF_TIN>("B PF+TIN 16.8.8 wg512 fpw8 tiled gpw2", true, 2);
   addB<strided_cfg<d, radix_list<16, 8, 8>, 512, 8, 2, RD>, K_PF_TIN>("B PF+TIN 16.8.8 wg512 fpw8 tiled gpw8", true, 8);
   addA<strided_cfg<d, radix_list<16, 8, 8>, 512, 8, 2, W>, K_PREFETCH>("A PF 16.8.8 wg512 fpw8 tiled", true, 4);
@@ -364,7 +368,7 @@ int main() {
   printf("---- stage-A variants (partner: first stage-B variant with the same layout)\n");
   for (size_t i = 0; i < g_a.size(); ++i) {
     const variant* pb = nullptr;
-    for (auto& p : g_b) if (p.tiled == g_a[i].tiled && (N2 / p.r0) % g_a[i].fpw == 0 && ((p.kind != K_TIN && p.kind != K_PF_TIN) || p.fpw == g_a[i].fpw)) { pb = &p; break; }
+    for (auto& p : g_b) if (p.tiled == g_a[i].tiled && (N2 / p.r0) % g_a[i].fpw == 0 && ((p.kind != K_TIN && p.kind != K_PF_TIN && p.kind != K_PF_TIN_LTW) || p.fpw == g_a[i].fpw)) { pb = &p; break; }
     if (pb == nullptr) { printf("%-52s no partner\n", g_a[i].name.c_str()); continue; }
     CK(hipMemset(out, 0, cmp_count * sizeof(T)));
     const result r = run_pair(g_a[i], *pb, in, scratch, out, reps);
@@ -375,7 +379,7 @@ int main() {
   printf("---- stage-B variants (partner: first tiled / plain stage-A variant with a matching tile)\n");
   for (size_t i = 0; i < g_b.size(); ++i) {
     const variant* pa = nullptr;
-    for (auto& p : g_a) if (p.tiled == g_b[i].tiled && (!p.tiled || ((N2 / g_b[i].r0) % p.fpw == 0 && ((g_b[i].kind != K_TIN && g_b[i].kind != K_PF_TIN) || p.fpw == g_b[i].fpw)))) { pa = &p; break; }
+    for (auto& p : g_a) if (p.tiled == g_b[i].tiled && (!p.tiled || ((N2 / g_b[i].r0) % p.fpw == 0 && ((g_b[i].kind != K_TIN && g_b[i].kind != K_PF_TIN && g_b[i].kind != K_PF_TIN_LTW) || p.fpw == g_b[i].fpw)))) { pa = &p; break; }
     if (pa == nullptr) { printf("%-52s no partner\n", g_b[i].name.c_str()); continue; }
     CK(hipMemset(out, 0, cmp_count * sizeof(T)));
     const result r = run_pair(*pa, g_b[i], in, scratch, out, reps);
@@ -384,5 +388,17 @@ int main() {
            2.0 * 268435456.0 / (r.b_us * 1e-6) * 1e-12, pa->name.c_str(), r.a_us, compare(out, ref, cmp_count));
   }
   (void)partner;
+  // the modifier moved from stage A's stores to stage B's loads: the pair's result against the reference
+  {
+    const variant *pa = nullptr, *pb = nullptr;
+    for (auto& p : g_a) if (p.kind == K_NOSTW && p.tiled) { pa = &p; break; }
+    for (auto& p : g_b) if (p.kind == K_PF_TIN_LTW && pa != nullptr && p.fpw == pa->fpw) { pb = &p; break; }
+    if (pa != nullptr && pb != nullptr) {
+      CK(hipMemset(out, 0, cmp_count * sizeof(T)));
+      const result r = run_pair(*pa, *pb, in, scratch, out, reps);
+      printf("---- modifier on stage B's loads: %s + %s: A %.1f us  B %.1f us per chunk, rel-L2 vs ref %.1e\n", pa->name.c_str(), pb->name.c_str(),
+             r.a_us, r.b_us, compare(out, ref, cmp_count));
+    }
+  }
   return 0;
 }
