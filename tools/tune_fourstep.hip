@@ -73,7 +73,7 @@ __global__ void fill_uniform(T* p, size_t n, unsigned seed) {
   }
 }
 
-enum kind_t { K_PLAIN = 0, K_PREFETCH = 1, K_HX = 2, K_ROW_IN = 3, K_TIN = 4, K_NOSTW = 5 /* timing only: stage A without its store modifier */, K_PF_TIN = 6, K_SFR = 7, K_PF_TIN_LTW = 8 /* stage B carrying the modifier on its loads */ };
+enum kind_t { K_PLAIN = 0, K_PREFETCH = 1, K_HX = 2, K_ROW_IN = 3, K_TIN = 4, K_NOSTW = 5 /* timing only: stage A without its store modifier */, K_PF_TIN = 6, K_SFR = 7, K_PF_TIN_LTW = 8 /* stage B carrying the modifier on its loads */, K_PF_NOSTW = 9 /* timing only */ };
 struct variant {
   std::string name;
   int kind, fpw, wg, gpw;
@@ -90,10 +90,10 @@ static void* g_stw_tab;
 
 template <typename Cfg, int KIND, bool STAGE_A>
 void add(const char* name, bool tiled, int gpw, size_t extra_lds = 0) {
-  constexpr int STW = (STAGE_A && KIND != K_NOSTW) ? 1 : 0;
+  constexpr int STW = (STAGE_A && KIND != K_NOSTW && KIND != K_PF_NOSTW) ? 1 : 0;
   const void* fn;
   size_t lds;
-  if constexpr (KIND == K_PREFETCH) { fn = (const void*)&stockham_strided_prefetch_kernel<Cfg, false, STW>; lds = strided_lds_bytes<Cfg>(); }
+  if constexpr (KIND == K_PREFETCH || KIND == K_PF_NOSTW) { fn = (const void*)&stockham_strided_prefetch_kernel<Cfg, false, STW>; lds = strided_lds_bytes<Cfg>(); }
   else if constexpr (KIND == K_PF_TIN) { fn = (const void*)&stockham_strided_prefetch_kernel<Cfg, false, STW, 0, true>; lds = strided_lds_bytes<Cfg>(); }
   else if constexpr (KIND == K_SFR) { fn = (const void*)&stockham_strided_sfr_kernel<Cfg, false, STW>; lds = strided_sfr_lds_bytes<Cfg>(); }
   else if constexpr (KIND == K_PF_TIN_LTW) { fn = (const void*)&stockham_strided_prefetch_kernel<Cfg, false, 0, 0, true, 1>; lds = strided_lds_bytes<Cfg>() + ((size_t)g_stw_levels << g_stw_shift) * sizeof(cx<T>); }
@@ -109,7 +109,7 @@ void add(const char* name, bool tiled, int gpw, size_t extra_lds = 0) {
   v.tw = make_twiddles<typename Cfg::Seq>();
   v.r0 = Cfg::Seq::r[0]; v.rlast = Cfg::Seq::r[Cfg::NP - 1];
   v.launch = [lds](unsigned grid, const strided_args& a) {
-    if constexpr (KIND == K_PREFETCH) hipLaunchKernelGGL((stockham_strided_prefetch_kernel<Cfg, false, STW>), dim3(grid), dim3(Cfg::WG), lds, 0, a);
+    if constexpr (KIND == K_PREFETCH || KIND == K_PF_NOSTW) hipLaunchKernelGGL((stockham_strided_prefetch_kernel<Cfg, false, STW>), dim3(grid), dim3(Cfg::WG), lds, 0, a);
     else if constexpr (KIND == K_PF_TIN) hipLaunchKernelGGL((stockham_strided_prefetch_kernel<Cfg, false, STW, 0, true>), dim3(grid), dim3(Cfg::WG), lds, 0, a);
     else if constexpr (KIND == K_SFR) hipLaunchKernelGGL((stockham_strided_sfr_kernel<Cfg, false, STW>), dim3(grid), dim3(Cfg::WG), lds, 0, a);
     else if constexpr (KIND == K_PF_TIN_LTW) hipLaunchKernelGGL((stockham_strided_prefetch_kernel<Cfg, false, 0, 0, true, 1>), dim3(grid), dim3(Cfg::WG), lds, 0, a);
@@ -337,6 +337,11 @@ int main() {
   addA<strided_cfg<d, radix_list<16, 8, 8>, 512, 8, 2, W>, K_PLAIN>("A 16.8.8 wg512 fpw8 tiled gpw8", true, 8);
   addA<strided_cfg<d, radix_list<16, 8, 8>, 512, 8, 2, W>, K_PLAIN>("A 16.8.8 wg512 fpw8 tiled gpw16 (= 1x resident)", true, 16);
   addA<strided_cfg<d, radix_list<16, 8, 8>, 512, 8, 2, W>, K_NOSTW>("A 16.8.8 wg512 fpw8 tiled WITHOUT stw (timing only)", true, 4);
+  addA<strided_cfg<d, radix_list<16, 8, 8>, 512, 8, 2, W>, K_PF_NOSTW>("A PF 16.8.8 wg512 fpw8 tiled WITHOUT stw", true, 4);
+  addA<strided_cfg<d, radix_list<16, 8, 8>, 512, 8, 2, W>, K_NOSTW>("A 16.8.8 wg512 fpw8 tiled WITHOUT stw gpw8", true, 8);
+  addA<strided_cfg<d, radix_list<16, 8, 8>, 512, 8, 2, W>, K_NOSTW>("A 16.8.8 wg512 fpw8 tiled WITHOUT stw gpw2", true, 2);
+  addA<strided_cfg<d, radix_list<32, 32>, 256, 8, 1, W>, K_NOSTW>("A 32.32 wg256 fpw8 tiled WITHOUT stw", true, 4);
+  addA<strided_cfg<d, radix_list<16, 8, 8>, 1024, 8, 4, W>, K_NOSTW>("A 16.8.8 wg1024(8pt) fpw8 tiled WITHOUT stw", true, 4);
   addB<strided_cfg<d, radix_list<16, 8, 8>, 512, 8, 2, RD>, K_PF_TIN_LTW>("B PF+TIN+LTW 16.8.8 wg512 fpw8 tiled (modifier on loads)", true, 4);
   addB<strided_cfg<d, radix_list<16, 8, 8>, 512, 8, 2, RD>, K_PF_TIN>("B PF+TIN 16.8.8 wg512 fpw8 tiled gpw2", true, 2);
   addB<strided_cfg<d, radix_list<16, 8, 8>, 512, 8, 2, RD>, K_PF_TIN>("B PF+TIN 16.8.8 wg512 fpw8 tiled gpw8", true, 8);
