@@ -15,8 +15,12 @@ std::vector<strided_kernel> build() {
   // groups per work-group (last argument): tools/perf_gpw.py, random data -- four-step fp64 N=2^20 x 128 (C3) 1.733 ms
   // with one group per work-group, 1.627 ms with four (the tail of a launch of one-work-group-per-CU kernels);
   // N=2^18 1.500 -> 1.451 ms; N=65536 (n=256) prefers two, N=2^22 (n=2048) one
-  add_strided_entries<strided_cfg<d, radix_list<16, 16>, 128, 8, 2, NT>, SE_TIN>(v, 2);     // 256
-  add_strided_entries<strided_cfg<d, radix_list<8, 8, 8>, 512, 8, 2, NT>, SE_TIN>(v, 4);    // 512
+  add_strided_entries<strided_cfg<d, radix_list<16, 16>, 128, 8, 2, NT>, SE_TIN | SE_FS_A | SE_FS_B | SE_PLAIN_WRITER>(v, 2);     // 256
+  add_strided_entries<strided_cfg<d, radix_list<8, 8, 8>, 512, 8, 2, NT>, SE_TIN | SE_FS_A | SE_FS_B | SE_PLAIN_WRITER>(v, 4);    // 512
+  // their stage-B partners: software-pipelined tiled-input forms carrying the inter-stage twiddles on their loads (as
+  // the n = 1024 entry below) -- tools/tune_fourstep.hip cases 116 / 118: A 100-104 -> 95, B 82 -> 83 / A 103 -> 99, B 88 -> 88
+  add_strided_entries<strided_cfg<d, radix_list<16, 16>, 128, 8, 2, NT>, SE_PREFETCH | SE_TIN | SE_FS_B | SE_FS_ONLY | SE_LTW>(v, 2);
+  add_strided_entries<strided_cfg<d, radix_list<8, 8, 8>, 512, 8, 2, NT>, SE_PREFETCH | SE_TIN | SE_FS_B | SE_FS_ONLY | SE_LTW>(v, 4);
   add_strided_entries<strided_cfg<d, radix_list<16, 8, 8>, 512, 8, 2, NT>, SE_TIN | SE_FS_A | SE_FS_B | SE_PLAIN_WRITER>(v, 4);   // 1024
   // four-step stage B of n2 = 1024 (C3): the software-pipelined kernel in its tiled-input form -- 86-92 us per 256 MiB
   // chunk against 95-96 (tools/tune_fourstep.hip case 120); stage A keeps the entry above (pipelined: equal)

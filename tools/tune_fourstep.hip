@@ -311,6 +311,7 @@ int main() {
   addB<strided_cfg<d, radix_list<16, 16>, 128, 8, 2, RD>, K_TIN>("B 16.16 wg128 fpw8 tiled TIN (production)", true, 2);
   addB<strided_cfg<d, radix_list<16, 16>, 128, 8, 2, RD>, K_PF_TIN>("B PF+TIN 16.16 wg128 fpw8 tiled", true, 2);
   addB<strided_cfg<d, radix_list<16, 16>, 128, 8, 2, RD>, K_PF_TIN>("B PF+TIN 16.16 wg128 fpw8 tiled gpw4", true, 4);
+  addB<strided_cfg<d, radix_list<16, 16>, 128, 8, 2, RD>, K_PF_TIN_LTW>("B PF+TIN+LTW 16.16 wg128 fpw8 tiled (modifier on loads)", true, 2);
   addA<strided_cfg<d, radix_list<16, 16>, 128, 8, 2, W>, K_PLAIN>("A 16.16 wg128 fpw8 tiled gpw4", true, 4);
   addA<strided_cfg<d, radix_list<16, 16>, 128, 8, 2, W>, K_PLAIN>("A 16.16 wg128 fpw8 tiled gpw8", true, 8);
   addA<strided_cfg<d, radix_list<16, 16>, 128, 8, 2, W>, K_PREFETCH>("A PF 16.16 wg128 fpw8 tiled", true, 4);
@@ -322,6 +323,7 @@ int main() {
   addA<strided_cfg<d, radix_list<8, 8, 8>, 512, 8, 2, W>, K_PLAIN>("A 8.8.8 wg512 fpw8 tiled (production)", true, 4);
   addB<strided_cfg<d, radix_list<8, 8, 8>, 512, 8, 2, RD>, K_TIN>("B 8.8.8 wg512 fpw8 tiled TIN (production)", true, 4);
   addB<strided_cfg<d, radix_list<8, 8, 8>, 512, 8, 2, RD>, K_PF_TIN>("B PF+TIN 8.8.8 wg512 fpw8 tiled", true, 4);
+  addB<strided_cfg<d, radix_list<8, 8, 8>, 512, 8, 2, RD>, K_PF_TIN_LTW>("B PF+TIN+LTW 8.8.8 wg512 fpw8 tiled (modifier on loads)", true, 4);
   addA<strided_cfg<d, radix_list<8, 8, 8>, 512, 8, 2, W>, K_PREFETCH>("A PF 8.8.8 wg512 fpw8 tiled", true, 4);
   addA<strided_cfg<d, radix_list<8, 8, 8>, 256, 8, 2, W>, K_PLAIN>("A 8.8.8 wg256(16pt) fpw8 tiled", true, 4);
   addB<strided_cfg<d, radix_list<8, 8, 8>, 256, 8, 2, RD>, K_TIN>("B 8.8.8 wg256(16pt) fpw8 tiled TIN", true, 4);
