@@ -265,6 +265,9 @@ int main() {
   addA<strided_cfg<f, radix_list<8, 8, 8>, 512, 32, 4, W>, K_HX>("A HX 8.8.8 wg512(32pt... 16pt x2) fpw32 tiled 2/CU", true, 2);
   addB<strided_cfg<f, radix_list<8, 8, 8>, 512, 32, 4, RD>, K_HX>("B HX 8.8.8 wg512 fpw32 tiled 2/CU", true, 2);
   addA<strided_cfg<f, radix_list<8, 8, 8>, 512, 16, 2, W>, K_PLAIN>("A 8.8.8 wg512 fpw16 tiled 2/CU gpw2", true, 2);
+  addA<strided_cfg<f, radix_list<8, 8, 8>, 512, 16, 2, W>, K_NOSTW>("A 8.8.8 wg512 fpw16 tiled 2/CU WITHOUT stw", true, 4);
+  addB<strided_cfg<f, radix_list<8, 8, 8>, 512, 16, 2, RD>, K_PF_TIN>("B PF+TIN 8.8.8 wg512 fpw16 tiled", true, 4);
+  addB<strided_cfg<f, radix_list<8, 8, 8>, 512, 16, 2, RD>, K_PF_TIN_LTW>("B PF+TIN+LTW 8.8.8 wg512 fpw16 tiled (modifier on loads)", true, 4);
   addA<strided_cfg<f, radix_list<8, 8, 8>, 512, 16, 2, W>, K_PLAIN>("A 8.8.8 wg512 fpw16 tiled 2/CU gpw8", true, 8);
   addB<strided_cfg<f, radix_list<8, 8, 8>, 512, 16, 2, RD>, K_TIN>("B 8.8.8 wg512 fpw16 tiled TIN 2/CU gpw2", true, 2);
   addB<strided_cfg<f, radix_list<8, 8, 8>, 512, 16, 2, RD>, K_TIN>("B 8.8.8 wg512 fpw16 tiled TIN 2/CU gpw8", true, 8);
@@ -287,6 +290,9 @@ int main() {
   addB<strided_cfg<f, radix_list<16, 16>, 256, 16, 2, RD>, K_TIN>("B 16.16 wg256 fpw16 tiled TIN 4/CU", true, 4);
   addB<strided_cfg<f, radix_list<16, 16>, 256, 16, 2, RD>, K_PLAIN>("B 16.16 wg256 fpw16 tiled 4/CU", true, 4);
   addA<strided_cfg<f, radix_list<16, 16>, 256, 16, 2, W>, K_PLAIN>("A 16.16 wg256 fpw16 tiled 4/CU gpw8", true, 8);
+  addA<strided_cfg<f, radix_list<16, 16>, 256, 16, 2, W>, K_NOSTW>("A 16.16 wg256 fpw16 tiled 4/CU WITHOUT stw", true, 4);
+  addB<strided_cfg<f, radix_list<16, 16>, 256, 16, 2, RD>, K_PF_TIN>("B PF+TIN 16.16 wg256 fpw16 tiled", true, 4);
+  addB<strided_cfg<f, radix_list<16, 16>, 256, 16, 2, RD>, K_PF_TIN_LTW>("B PF+TIN+LTW 16.16 wg256 fpw16 tiled (modifier on loads)", true, 4);
   addB<strided_cfg<f, radix_list<16, 16>, 256, 16, 2, RD>, K_TIN>("B 16.16 wg256 fpw16 tiled TIN 4/CU gpw8", true, 8);
   addA<strided_cfg<f, radix_list<8, 8, 4>, 1024, 32, 2, W>, K_PLAIN>("A 8.8.4 wg1024 fpw32 tiled", true, 2);
   addB<strided_cfg<f, radix_list<8, 8, 4>, 1024, 32, 2, RD>, K_TIN>("B 8.8.4 wg1024 fpw32 tiled TIN", true, 2);
