@@ -305,6 +305,18 @@ def test_wave64_prime_factors(prec, oracle):
         got, _ = G.transform_packed(G.make_descriptor([n], prec, batch=3), pf.direction.FORWARD, x)
         ref = oracle.compute(oracle.make_desc([n], prec, batch=3), F, x.ravel(), sg=64).reshape(x.shape)
         _check(got, ref, n, dtype, ("wave64 primes vs oracle(sg=64)", prec, n))
+    # the generic tier's "big radix" kernel (what runs when runtime specialisation is off or unavailable)
+    os.environ["PFFT_JIT"] = "0"
+    try:
+        for n in (61, 43 * 47, 53 * 16, 59 * 59 * 8):
+            x, y = H.gen_fourier_data(3, [n], dtype, seed=n + 1)
+            d = G.make_descriptor([n], prec, batch=3)
+            got, _ = G.transform_packed(d, pf.direction.FORWARD, x)
+            _check(got, y, n, dtype, ("wave64 primes, generic tier", prec, n))
+            back, _ = G.transform_packed(d, pf.direction.BACKWARD, y)
+            _check(back, x.astype(np.complex128) * n, n, dtype, ("wave64 primes, generic tier bwd", prec, n))
+    finally:
+        del os.environ["PFFT_JIT"]
     # batch-interleaved and N-D
     x, y = H.gen_fourier_data(33, [37 * 8], dtype, seed=3)
     d = _layout_desc(G, 37 * 8, prec, 33, 1, "BI", "BI", F, 0)
