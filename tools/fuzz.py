@@ -1,7 +1,9 @@
 """Random descriptors against NumPy: rank, lengths (61-smooth), batch, layout (packed / batch-interleaved / unpacked rows /
-strided), storage, placement, offsets, scales, precision, direction.  usage: fuzz.py [seed] [iterations] [big2d]
+strided), storage, placement, offsets, scales, precision, direction.  usage: fuzz.py [seed] [iterations] [big2d|global]
 With `big2d` the shapes are 2-D / 3-D with a long last dimension (256...2048): the two-pass 2-D plan
-(stockham_rows2d.hpp) and its fall-backs."""
+(stockham_rows2d.hpp) and its fall-backs.  With `global` the lengths are four-step (GLOBAL tier) sizes: powers of two
+2^15 ... 2^21 (the registered stage pairs), 3 / 5 / 6 / 10 times powers of two, powers of ten, lengths with a prime factor
+37 ... 61 -- packed, both storages, both placements."""
 import os, sys, random
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
@@ -25,6 +27,7 @@ def main():
     seed = int(sys.argv[1]) if len(sys.argv) > 1 else 0
     iters = int(sys.argv[2]) if len(sys.argv) > 2 else 200
     big2d = len(sys.argv) > 3 and sys.argv[3] == "big2d"
+    glob = len(sys.argv) > 3 and sys.argv[3] == "global"
     rng = random.Random(seed)
     fails = 0
     for it in range(iters):
@@ -36,6 +39,10 @@ def main():
             last = rng.choice([256, 512, 1024, 2048, 1000, 768])
             mid = rng.choice([8, 16, 24, 40, 64, 96, 128, 250, 256, 512, 1024, 1500, 3000, 2560])
             dims = ([rng.choice([2, 3, 5, 8])] if rank == 3 else []) + [mid, last]
+        elif glob:
+            rank = 1
+            dims = [rng.choice([1 << 15, 1 << 16, 1 << 17, 1 << 18, 1 << 19, 1 << 20, 1 << 21, 3 << 15, 5 << 14, 3 << 17,
+                                6 << 15, 10 << 13, 100000, 1000000, 60000, 37 << 12, 61 << 10, 9 * 5 * 7 * 11 * 13 * 16, 49152])]
         elif rank == 1:
             dims = [smooth(rng, rng.choice([2, 20, 300, 3000]), rng.choice([64, 2000, 20000, 200000]))]
         else:
@@ -43,12 +50,12 @@ def main():
         n = int(np.prod(dims))
         batch = rng.choice([1, 2, 3, 7, 16, 33, 100])
         if n * batch > 4_000_000:
-            batch = max(1, (8_000_000 if big2d else 4_000_000) // n)
+            batch = max(1, (8_000_000 if (big2d or glob) else 4_000_000) // n)
         storage = rng.choice([0, 0, 1])
         kw = {}
         place = rng.choice([0, 1])
         layout = "P"
-        if rank == 1:
+        if rank == 1 and not glob:
             layout = rng.choice(["P", "P", "BI", "ROWS", "STR", "PBI", "BIP"])
             if layout == "BI":
                 kw = dict(fwd_strides=[batch], fwd_distance=1, bwd_strides=[batch], bwd_distance=1)
