@@ -243,6 +243,11 @@ int main() {
   addA<strided_cfg<f, radix_list<16, 8, 8>, 1024, 16, 4, W>, K_NOSTW>("A 16.8.8 wg1024 fpw16 tiled WITHOUT stw (timing only)", true, 4);
   addA<strided_cfg<f, radix_list<32, 32>, 512, 16, 2, W>, K_NOSTW>("A 32.32 wg512 fpw16 tiled WITHOUT stw (timing only)", true, 4);
   addA<strided_cfg<f, radix_list<32, 32>, 512, 16, 2, W>, K_PLAIN>("A 32.32 wg512 fpw16 tiled", true, 4);
+  addA<strided_cfg<f, radix_list<16, 8, 8>, 512, 16, 2, W>, K_PLAIN>("A 16.8.8 wg512(32pt) fpw16 tiled", true, 8);
+  addA<strided_cfg<f, radix_list<16, 8, 8>, 512, 16, 2, W>, K_PREFETCH>("A PF 16.8.8 wg512(32pt) fpw16 tiled", true, 8);
+  addA<strided_cfg<f, radix_list<32, 32>, 512, 16, 1, W>, K_PREFETCH>("A PF 32.32 wg512 fpw16 tiled occ1", true, 8);
+  addA<strided_cfg<f, radix_list<16, 16, 4>, 1024, 16, 4, W>, K_PLAIN>("A 16.16.4 wg1024 fpw16 tiled", true, 8);
+  addA<strided_cfg<f, radix_list<8, 16, 8>, 1024, 16, 4, W>, K_PLAIN>("A 8.16.8 wg1024 fpw16 tiled", true, 8);
   addA<strided_cfg<f, radix_list<16, 8, 8>, 1024, 16, 4, W>, K_PLAIN>("A 16.8.8 wg1024 fpw16 tiled gpw2", true, 2);
   addA<strided_cfg<f, radix_list<16, 8, 8>, 1024, 16, 4, W>, K_PLAIN>("A 16.8.8 wg1024 fpw16 tiled gpw8", true, 8);
   addB<strided_cfg<f, radix_list<16, 8, 8>, 1024, 16, 4, RD>, K_PREFETCH>("B PF 16.8.8 wg1024 fpw16 tiled gpw8", true, 8);
