@@ -9,7 +9,7 @@ python bench.py > $out/r3_bench_c2.json 2> $out/c2.err
 for c in c3 c5 ref16 ref256 ref4096 ref65536 g32_15 g32_17 g32_18 g32_20 g32_22 g64_16; do
   python bench.py --config $c --no-cpu-baseline > $out/r3_bench_$c.json 2> $out/$c.err
 done
-for c in c2 c3 c5 ref65536 g32_18 g32_20 g32_22; do
+for c in c2 c3 c5 ref65536 g32_15 g32_17 g32_18 g32_20 g32_22 g64_16; do
   rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_$c -- python3 bench.py --config $c --steps 20 --warmup 3 --no-cpu-baseline > $out/stats_$c.log 2>&1
   f=$(ls $out/stats_$c/*/*kernel_stats.csv 2>/dev/null | head -1)
   [ -n "$f" ] && cp "$f" $out/r3_${c}_kernel_stats.csv
