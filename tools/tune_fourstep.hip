@@ -37,6 +37,9 @@ constexpr long long N1 = 512, N2 = 512, BATCH = 256;
 #elif TUNE_CASE == 18
 using T = float;
 constexpr long long N1 = 512, N2 = 512, BATCH = 512;
+#elif TUNE_CASE == 15
+using T = float;
+constexpr long long N1 = 128, N2 = 256, BATCH = 4096;
 #elif TUNE_CASE == 22
 using T = float;
 constexpr long long N1 = 2048, N2 = 2048, BATCH = 32;
@@ -257,6 +260,15 @@ int main() {
   addB<strided_cfg<f, radix_list<32, 32>, 512, 16, 2, RD>, K_PF_TIN_LTW>("B PF+TIN+LTW 32.32 wg512 fpw16 tiled (modifier on loads)", true, 4);
   addB<strided_cfg<f, radix_list<16, 8, 8>, 1024, 16, 4, RD>, K_TIN>("B 16.8.8 wg1024 fpw16 tiled TIN gpw2", true, 2);
   addB<strided_cfg<f, radix_list<16, 8, 8>, 1024, 16, 4, RD>, K_TIN>("B 16.8.8 wg1024 fpw16 tiled TIN gpw8", true, 8);
+#elif TUNE_CASE == 15
+  addA<strided_cfg<f, radix_list<16, 8>, 256, 32, 2, W>, K_PLAIN>("A 16.8 wg256 fpw32 plain-layout (production)", false, 1);
+  addB<strided_cfg<f, radix_list<16, 16>, 512, 32, 2, RD>, K_ROW_IN>("B 16.16 wg512 fpw32 row-staged (production)", false, 4);
+  addA<strided_cfg<f, radix_list<8, 16>, 256, 16, 2, W>, K_PLAIN>("A 8.16 wg256 fpw16 tiled", true, 4);
+  addA<strided_cfg<f, radix_list<16, 8>, 128, 16, 2, W>, K_PLAIN>("A 16.8 wg128 fpw16 tiled", true, 4);
+  addA<strided_cfg<f, radix_list<16, 8>, 256, 16, 2, W>, K_PLAIN>("A 16.8 wg256(8pt) fpw16 tiled", true, 4);
+  addA<strided_cfg<f, radix_list<16, 8>, 128, 16, 2, W>, K_PLAIN>("A 16.8 wg128 fpw16 tiled gpw8", true, 8);
+  addB<strided_cfg<f, radix_list<16, 16>, 256, 16, 2, RD>, K_TIN>("B 16.16 wg256 fpw16 tiled TIN 4/CU", true, 4);
+  addB<strided_cfg<f, radix_list<16, 16>, 256, 16, 2, RD>, K_TIN>("B 16.16 wg256 fpw16 tiled TIN 4/CU gpw8", true, 8);
 #elif TUNE_CASE == 18
   addA<strided_cfg<f, radix_list<8, 8, 8>, 1024, 32, 2, W>, K_PLAIN>("A 8.8.8 wg1024 fpw32 plain-layout (production)", false, 2);
   addB<strided_cfg<f, radix_list<8, 8, 8>, 1024, 32, 2, RD>, K_ROW_IN>("B 8.8.8 wg1024 fpw32 row-staged (production)", false, 2);
