@@ -37,8 +37,10 @@ bool choose_spec_params(int precision, long long n, size_t max_lds, wg_params* o
 
 /// Same for the strided tier (FPW adjacent FFTs side by side); `inner_count` is the number of adjacent FFTs the
 /// stage offers (narrow stages get narrower groups).
+/// want_fpw > 0: exactly that many FFTs per work-group or nothing (a four-step stage A that must match the group width
+/// of its stage B, plan.cpp)
 bool choose_strided_params(int precision, long long n, long long inner_count, size_t max_lds, wg_params* out,
-                           bool column_both = false);
+                           bool column_both = false, int want_fpw = 0);
 
 /// Planner of the first pass of the two-pass 2-D plan (stockham_rows2d.hpp) for rows of length n1 in a matrix of n0
 /// rows: the column radix RC taken in that pass (= rows per work-group = wg_params::fpw; n0 % RC == 0), the row
@@ -95,7 +97,7 @@ const spec_kernel* jit_spec_kernel(int precision, long long n, bool split, size_
 /// SPLIT_COMPLEX data), 3 split output (stage B); see stockham_strided.hpp).
 const strided_kernel* jit_strided_kernel(int precision, long long n, long long inner_count, bool store_modifier,
                                          int split_mode, size_t max_lds, std::string* why,
-                                         bool column_both = false, int policy = 0);
+                                         bool column_both = false, int policy = 0, int want_fpw = 0);
 
 /// UNPACKED-layout form (stockham_wg_unpacked_kernel) of the packed configuration `like` (a pre-compiled or a
 /// runtime-specialised entry): forward/backward module functions for interleaved or split storage.

@@ -450,14 +450,14 @@ struct plan_t {
   /// entries that exist only for such pairs are invisible to every other request
   const strided_kernel* find_strided(long long n, bool column_both = false, bool row_side = false,
                                      long long inner_count = -1, int policy = 0, bool store_modifier = false,
-                                     int fs_stage = 0) const {
+                                     int fs_stage = 0, bool allow_ltw = true) const {
     int count = 0;
     const strided_kernel* k =
         desc.precision == PFFT_PRECISION_F64 ? strided_kernels_f64(&count) : strided_kernels_f32(&count);
     const strided_kernel* found = nullptr;
     // (stage B: an entry that carries the modifier on its loads first -- PFFT_NO_LTW=1 hides those entries, their
     //  tiled-input form cannot run without the tables)
-    const bool ltw_ok = getenv("PFFT_NO_LTW") == nullptr;
+    const bool ltw_ok = allow_ltw && getenv("PFFT_NO_LTW") == nullptr;
     for (int pass = 0; pass < 2 && fs_stage != 0; ++pass) {
       for (int i = 0; i < count; ++i) {
         if (k[i].n != n || k[i].lds_bytes > max_lds || k[i].policy != policy) continue;
@@ -1137,7 +1137,48 @@ struct plan_t {
       fail(PFFT_UNSUPPORTED_CONFIGURATION, "FFT size ", n, " cannot be split into two factors that fit local memory",
            " (large prime factors are not supported)");
     }
-    const long long n2 = n / n1;
+    long long n2 = n / n1;
+    // Stage pairs (below) need a registered stage-B entry for n2 and, for n1, a registered stage-A entry or a
+    // runtime-specialised kernel of the same group width.  Among the splits that allow one, a SHORT stage A wins over
+    // a balanced split -- several stage-A work-groups per CU, stage B on the best-tuned entries (n2 = 1024 / 512):
+    // measured (tools/probes/half_pairs_n1.sh, fraction of peak) fp32 3 * 2^17: 384 x 1024 0.313, 768 x 512 0.294,
+    // 512 x 768 without a pair 0.261; 3 * 2^16: 192 x 1024 0.355, 384 x 512 0.310; 5 * 2^15: 160 x 1024 0.347, 320 x 512
+    // 0.275; 2^18: 256 x 1024 0.364, 512 x 512 0.347; fp64 3 * 2^16: 0.372 against 0.326 -- but not a very short one
+    // (3 * 2^15: 192 x 512 0.354, 96 x 1024 0.340; 2^16: 256 x 256 0.375, 64 x 1024 0.316).  So: the smallest n1 >= 128
+    // that pairs, else the largest below.  Entries with groups narrower than a 128-byte line (fp32 n = 2048) are taken
+    // only when the balanced split itself lands on them (5 * 2^18 as 640 x 2048: 0.224 against 0.242).
+    if (desc.complex_storage == PFFT_INTERLEAVED_COMPLEX && jit_enabled() && getenv("PFFT_GLOBAL_N1") == nullptr &&
+        getenv("PFFT_NO_FS_PAIRS") == nullptr && getenv("PFFT_NO_HALF_PAIRS") == nullptr &&
+        getenv("PFFT_NO_TILED_SCRATCH") == nullptr && getenv("PFFT_NO_TILED_LANES") == nullptr &&
+        getenv("PFFT_NO_PRECOMPILED") == nullptr && getenv("PFFT_DEBUG_GLOBAL") == nullptr) {
+      auto pairable = [&](long long m, long long len) {  // m: stage A's length, len: stage B's
+        const strided_kernel* fb = find_strided(len, false, false, -1, 0, false, 2);
+        if (fb == nullptr || fb->launch_tin == nullptr || (fb->fpw & (fb->fpw - 1)) != 0 || len % fb->fpw != 0 ||
+            (len / fb->radices[0]) % fb->fpw != 0 || static_cast<size_t>(fb->fpw) * elem_bytes() < 128) {
+          return false;
+        }
+        if (const strided_kernel* fa = find_strided(m, false, false, -1, 0, true, 1)) return fa->fpw == fb->fpw;
+        wg_params p;
+        return find_strided(m) == nullptr && choose_strided_params(desc.precision, m, len, max_lds, &p, false, fb->fpw) &&
+               p.radices.size() >= 2;
+      };
+      int count_k = 0;
+      const strided_kernel* k =
+          desc.precision == PFFT_PRECISION_F64 ? strided_kernels_f64(&count_k) : strided_kernels_f32(&count_k);
+      long long above = 0, below = 0;  // smallest pairing n1 >= 128, largest pairing n1 < 128
+      for (int i = 0; i < count_k; ++i) {
+        const long long len = k[i].n;
+        if (k[i].fs_b == 0 || k[i].policy != 0 || n % len != 0 || n / len < 2) continue;
+        const long long m = n / len;
+        if (m == above || m == below || strided_fpw(m, len) <= 0 || !pairable(m, len)) continue;
+        if (m >= 128 && (above == 0 || m < above)) above = m;
+        if (m < 128 && m > below) below = m;
+      }
+      if (above != 0 || below != 0) {
+        n1 = above != 0 ? above : below;
+        n2 = n / n1;
+      }
+    }
     // Chunking (the reference's num_batches_in_l2 idea, committed_descriptor_impl.hpp:603-611) bounds the scratch.
     // Measured on MI355X (profiles/r1_notes.md): cache-sized chunks (16-256 MiB) do NOT make stage B's reads hit the
     // Infinity Cache -- they only shrink the launches -- so the default chunk is as large as the scratch cap allows.
@@ -1192,10 +1233,40 @@ struct plan_t {
         fs_pair = true;
       }
     }
+    // Half pair: only stage B's length has a registered entry (N = 3 * 2^18 = 768 x 1024, 5 * 2^17 = 640 x 1024, ...):
+    // stage A is runtime-specialised with stage B's group width, writes the group-major intermediate, and stage B
+    // reads it in its tiled-input form instead of row-staging a row-major one (PFFT_NO_HALF_PAIRS=1: round-3 plan)
+    bool half_pair = false;
+    if (!fs_pair && interleaved_user && jit_enabled() && getenv("PFFT_NO_FS_PAIRS") == nullptr &&
+        getenv("PFFT_NO_HALF_PAIRS") == nullptr && getenv("PFFT_NO_TILED_SCRATCH") == nullptr &&
+        getenv("PFFT_NO_TILED_LANES") == nullptr && getenv("PFFT_NO_PRECOMPILED") == nullptr &&
+        getenv("PFFT_DEBUG_GLOBAL") == nullptr && find_strided(n1) == nullptr) {
+      for (int with_ltw = 1; with_ltw >= 0 && !half_pair; --with_ltw) {
+        const strided_kernel* fb = find_strided(n2, false, false, -1, cached ? 2 : 0, false, 2, with_ltw != 0);
+        if (fb == nullptr || fb->launch_tin == nullptr || (fb->fpw & (fb->fpw - 1)) != 0 || n2 % fb->fpw != 0 ||
+            (n2 / fb->radices[0]) % fb->fpw != 0 ||
+            static_cast<unsigned long long>(n) * elem_bytes() >= 0xFFFFFFF0ull) {
+          continue;
+        }
+        const bool on_loads = fb->fs_ltw != 0;
+        if (on_loads && (with_ltw == 0 || fb->stw_mode != 1 || !store_tables_fit(fb, n))) continue;
+        std::string why;
+        const strided_kernel* fa = jit_strided_kernel(desc.precision, n1, n2, !on_loads, 0, max_lds, &why, false,
+                                                      cached ? 1 : 0, fb->fpw);
+        if (fa == nullptr || fa->fpw != fb->fpw || fa->n_radices < 2 || (!on_loads && !store_tables_fit(fa, n)) ||
+            !strided_fits(fa, n2, in_buf, addressing{ia.offset, n2, 1, n}, BUF_SCRATCH, addressing{0, n2, 1, n})) {
+          continue;
+        }
+        ka = fa;
+        kb = fb;
+        fs_pair = half_pair = true;
+      }
+    }
     // the pair's stage B may carry the inter-stage twiddles on its loads; stage A then has no store modifier
     // (PFFT_NO_LTW=1: the modifier stays on stage A's stores)
-    bool ltw = fs_pair && kb->fs_ltw != 0 && kb->stw_mode == 1 && store_tables_fit(kb, n) && ka->fn[0] != nullptr &&
-               getenv("PFFT_NO_LTW") == nullptr && getenv("PFFT_DEBUG_GLOBAL") == nullptr &&
+    bool ltw = fs_pair && kb->fs_ltw != 0 && kb->stw_mode == 1 && store_tables_fit(kb, n) &&
+               (half_pair || ka->fn[0] != nullptr) && getenv("PFFT_NO_LTW") == nullptr &&
+               getenv("PFFT_DEBUG_GLOBAL") == nullptr &&
                strided_fits(ka, n2, in_buf, addressing{ia.offset, n2, 1, n}, BUF_SCRATCH, addressing{0, n2, 1, n});
     // Scratch: one chunk -- or two halves that alternate when consecutive chunks overlap (the first launch of chunk
     // c + 1 without the in-order barrier).  Only a pre-compiled interleaved stage A can launch that way (pfa_launch);
@@ -1218,7 +1289,7 @@ struct plan_t {
     const bool force_generic_a = dbg != nullptr && std::strstr(dbg, "ga") != nullptr;
     const bool force_generic_b = dbg != nullptr && std::strstr(dbg, "gb") != nullptr;
     stage sa;
-    if (!force_generic_a && strided_fits(ka, n2, in_buf, a_in, BUF_SCRATCH, a_out) && store_tables_fit(ka, n)) {
+    if (!force_generic_a && strided_fits(ka, n2, in_buf, a_in, BUF_SCRATCH, a_out) && (ltw || store_tables_fit(ka, n))) {
       // conjugating on load and store in both stages is the identity in between, so the backward transform can use
       // the kernels' BWD form on both
       sa = make_strided_stage(ka, count * n2, n2, in_buf, a_in, BUF_SCRATCH, a_out, 1.0, backward, ltw ? 0 : 1);

@@ -393,6 +393,64 @@ def test_four_step_stage_pairs_and_split_storage():
             assert diff <= tol, (n, prec, batch, "load-side against store-side modifier", diff)
             del y1
         del x, y, z, y0, plan
+
+
+@pytest.mark.gpu
+def test_four_step_half_pairs_and_split_choice():
+    """Four-step lengths k * 2^m (plan.cpp, half pairs): the split takes a registered stage-B length (1024 / 512 / 256)
+    as n2 and a SHORT runtime-specialised stage A of the same group width as n1 -- factors checked through the plan
+    info --, the intermediate is group-major and stage B reads it in its tiled-input form (fp64: carrying the
+    inter-stage twiddles on its loads).  Against NumPy on sampled transforms, round trip, and against the round's
+    earlier plan of the same descriptor (PFFT_NO_HALF_PAIRS=1: balanced split, row-major intermediate); chunked
+    batches with a ragged last chunk included."""
+    G, pf, torch = _mods()
+
+    def commit(n, prec, batch, env=None):
+        old = {k: os.environ.get(k) for k in (env or {})}
+        os.environ.update(env or {})
+        try:
+            return G.make_descriptor([n], prec, batch=batch).commit()
+        finally:
+            for k, v in old.items():
+                if v is None:
+                    del os.environ[k]
+                else:
+                    os.environ[k] = v
+
+    cases = [  # (n, prec, batch, expected factors or None)
+        (3 << 15, "f32", 5, [192, 512]), (5 << 15, "f32", 3, [160, 1024]), (3 << 16, "f32", 3, [192, 1024]),
+        (7 << 14, "f32", 3, [224, 512]), (9 << 16, "f32", 2, [576, 1024]), (3 << 18, "f32", 2, [768, 1024]),
+        (1 << 18, "f32", 3, [256, 1024]), (3 << 13, "f32", 7, [96, 256]), (5 << 18, "f32", 2, None),
+        (3 << 20, "f32", 2, [1536, 2048]),
+        (12288, "f64", 5, None), (3 << 15, "f64", 3, None), (3 << 17, "f64", 2, [384, 1024]),
+        (5 << 17, "f64", 2, [640, 1024]),
+        (3 << 15, "f32", 700, None), (3 << 16, "f64", 170, None),  # chunked, ragged last chunk
+    ]
+    for n, prec, batch, factors in cases:
+        cdt = torch.complex64 if prec == "f32" else torch.complex128
+        tol = H.REL_L2_TOL[np.dtype(np.complex64 if prec == "f32" else np.complex128)]
+        g = torch.Generator(device="cuda").manual_seed(n % 1000 + batch)
+        x = torch.empty(batch * n, dtype=cdt, device="cuda")
+        torch.view_as_real(x).uniform_(-1, 1, generator=g)
+        plan = commit(n, prec, batch)
+        d0 = plan.info().dims[0]
+        assert d0.tier == 3, (n, prec)
+        if factors is not None:
+            assert list(d0.factors[:d0.n_factors]) == factors, (n, prec, list(d0.factors[:d0.n_factors]))
+        y = torch.empty_like(x)
+        plan.compute_forward(x, y).wait()
+        for b in sorted({0, batch // 2, batch - 1}):
+            ref = np.fft.fft(x.view(batch, n)[b].cpu().numpy().astype(np.complex128))
+            assert H.rel_l2(y.view(batch, n)[b].cpu().numpy(), ref) <= tol, (n, prec, batch, b)
+        z = torch.empty_like(x)
+        plan.compute_backward(y, z).wait()
+        err = float(((z / n - x).abs().double().pow(2).sum() / x.abs().double().pow(2).sum()).sqrt())
+        assert err <= tol, (n, prec, batch, "round trip", err)
+        y0 = torch.empty_like(x)
+        commit(n, prec, batch, {"PFFT_NO_HALF_PAIRS": "1"}).compute_forward(x, y0).wait()
+        diff = float(((y - y0).abs().double().pow(2).sum() / y0.abs().double().pow(2).sum()).sqrt())
+        assert diff <= tol, (n, prec, batch, "vs the plan without half pairs", diff)
+        del x, y, z, y0, plan
         torch.cuda.empty_cache()
 
 
