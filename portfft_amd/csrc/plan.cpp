@@ -1144,9 +1144,13 @@ struct plan_t {
     // measured (tools/probes/half_pairs_n1.sh, fraction of peak) fp32 3 * 2^17: 384 x 1024 0.313, 768 x 512 0.294,
     // 512 x 768 without a pair 0.261; 3 * 2^16: 192 x 1024 0.355, 384 x 512 0.310; 5 * 2^15: 160 x 1024 0.347, 320 x 512
     // 0.275; 2^18: 256 x 1024 0.364, 512 x 512 0.347; fp64 3 * 2^16: 0.372 against 0.326 -- but not a very short one
-    // (3 * 2^15: 192 x 512 0.354, 96 x 1024 0.340; 2^16: 256 x 256 0.375, 64 x 1024 0.316).  So: the smallest n1 >= 128
-    // that pairs, else the largest below.  Entries with groups narrower than a 128-byte line (fp32 n = 2048) are taken
-    // only when the balanced split itself lands on them (5 * 2^18 as 640 x 2048: 0.224 against 0.242).
+    // (3 * 2^15: 192 x 512 0.354, 96 x 1024 0.340; 2^16: 256 x 256 0.379, 128 x 512 0.367, 64 x 1024 0.316; 2^17: 256 x 512
+    // 0.370, 128 x 1024 0.357; in fp64 n1 = 128 still wins: 2^16 0.386 against 0.371, 2^17 0.378 against 0.356).  So: the
+    // smallest n1 >= 160 (fp64: 128) that pairs, else the largest below.  A registered length without a stage-A entry
+    // of stage B's width (n1 = 128, 64) gets a runtime-specialised stage A like any other (2^15 as 128 x 256 with it
+    // 0.375, on the registered 32-column entry 0.358; fp64 0.396 / 0.370).  Entries with groups narrower than a
+    // 128-byte line (fp32 n = 2048) are taken only when the balanced split itself lands on them (5 * 2^18 as 640 x 2048:
+    // 0.224 against 0.242).
     if (desc.complex_storage == PFFT_INTERLEAVED_COMPLEX && jit_enabled() && getenv("PFFT_GLOBAL_N1") == nullptr &&
         getenv("PFFT_NO_FS_PAIRS") == nullptr && getenv("PFFT_NO_HALF_PAIRS") == nullptr &&
         getenv("PFFT_NO_TILED_SCRATCH") == nullptr && getenv("PFFT_NO_TILED_LANES") == nullptr &&
@@ -1159,20 +1163,20 @@ struct plan_t {
         }
         if (const strided_kernel* fa = find_strided(m, false, false, -1, 0, true, 1)) return fa->fpw == fb->fpw;
         wg_params p;
-        return find_strided(m) == nullptr && choose_strided_params(desc.precision, m, len, max_lds, &p, false, fb->fpw) &&
-               p.radices.size() >= 2;
+        return choose_strided_params(desc.precision, m, len, max_lds, &p, false, fb->fpw) && p.radices.size() >= 2;
       };
       int count_k = 0;
       const strided_kernel* k =
           desc.precision == PFFT_PRECISION_F64 ? strided_kernels_f64(&count_k) : strided_kernels_f32(&count_k);
-      long long above = 0, below = 0;  // smallest pairing n1 >= 128, largest pairing n1 < 128
+      const long long short_a = desc.precision == PFFT_PRECISION_F64 ? 128 : 160;
+      long long above = 0, below = 0;  // smallest pairing n1 >= short_a, largest pairing n1 below
       for (int i = 0; i < count_k; ++i) {
         const long long len = k[i].n;
         if (k[i].fs_b == 0 || k[i].policy != 0 || n % len != 0 || n / len < 2) continue;
         const long long m = n / len;
         if (m == above || m == below || strided_fpw(m, len) <= 0 || !pairable(m, len)) continue;
-        if (m >= 128 && (above == 0 || m < above)) above = m;
-        if (m < 128 && m > below) below = m;
+        if (m >= short_a && (above == 0 || m < above)) above = m;
+        if (m < short_a && m > below) below = m;
       }
       if (above != 0 || below != 0) {
         n1 = above != 0 ? above : below;
@@ -1240,7 +1244,7 @@ struct plan_t {
     if (!fs_pair && interleaved_user && jit_enabled() && getenv("PFFT_NO_FS_PAIRS") == nullptr &&
         getenv("PFFT_NO_HALF_PAIRS") == nullptr && getenv("PFFT_NO_TILED_SCRATCH") == nullptr &&
         getenv("PFFT_NO_TILED_LANES") == nullptr && getenv("PFFT_NO_PRECOMPILED") == nullptr &&
-        getenv("PFFT_DEBUG_GLOBAL") == nullptr && find_strided(n1) == nullptr) {
+        getenv("PFFT_DEBUG_GLOBAL") == nullptr && find_strided(n1, false, false, -1, 0, true, 1) == nullptr) {
       for (int with_ltw = 1; with_ltw >= 0 && !half_pair; --with_ltw) {
         const strided_kernel* fb = find_strided(n2, false, false, -1, cached ? 2 : 0, false, 2, with_ltw != 0);
         if (fb == nullptr || fb->launch_tin == nullptr || (fb->fpw & (fb->fpw - 1)) != 0 || n2 % fb->fpw != 0 ||
