@@ -128,6 +128,11 @@ hipError_t jit_launch_strided_split(const strided_kernel* k, hipStream_t stream,
 bool jit_strided_ensure_row(const strided_kernel* k, int row_out, size_t max_lds, std::string* why, int split_mode = 0);
 hipError_t jit_launch_strided_row_mixed(const strided_kernel* k, hipStream_t stream, unsigned grid,
                                         const strided_args& args, int backward);
+/// Tiled-input form of the mixed stage B (interleaved group-major scratch -> split planes) of a runtime-compiled entry;
+/// false when the entry's shape has no such form (stockham_strided.hpp: tin_supported)
+bool jit_strided_ensure_mixed_tin(const strided_kernel* k, std::string* why);
+hipError_t jit_launch_strided_mixed_tin(const strided_kernel* k, hipStream_t stream, unsigned grid,
+                                        const strided_args& args, int backward);
 hipError_t jit_launch_strided_row(const strided_kernel* k, hipStream_t stream, unsigned grid, const strided_args& args,
                                   int backward, int row_out);
 hipError_t jit_launch_strided_mixed(const strided_kernel* k, hipStream_t stream, unsigned grid,

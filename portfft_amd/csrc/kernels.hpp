@@ -76,6 +76,9 @@ struct strided_kernel {
   hipFunction_t mfn_row[4];
   /// ... and the row-staged input form of the mixed stage B (interleaved scratch rows -> split planes): [backward]
   hipFunction_t mfn_row_mixed[2];
+  /// ... and its tiled-input form (stockham_strided_kernel<Cfg, BWD, 0, 3, TIN = true>, jit_strided_ensure_mixed_tin):
+  /// stage B behind a group-major intermediate on SPLIT_COMPLEX data
+  hipFunction_t mfn_mixed_tin[2];
   /// tiled-input form (strided_pass TIN): the four-step stage B behind a group-major stage A of the same group
   /// width; fn_tin[backward]; null when not instantiated
   const void* fn_tin[2];

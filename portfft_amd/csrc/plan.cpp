@@ -697,7 +697,7 @@ struct plan_t {
     // f-fastest form reads 8 bytes per lane from FPW different rows, and there is no tiled-input form to fall back on
     // (power-of-two rows only: fp32 N = 65536 1.88 -> 0.91 ms per GiB, 2^20 1.61 -> 1.28; with 8000-byte rows
     //  -- N = 10^6 -- the f-fastest form spreads over the channels by itself and the staged form loses, 1.84 -> 2.21)
-    if (k->launch == nullptr && mixed && in_buf == BUF_SCRATCH && ia.stride == 1 && ia.dist_inner != 1 &&
+    if (allow_row && k->launch == nullptr && mixed && in_buf == BUF_SCRATCH && ia.stride == 1 && ia.dist_inner != 1 &&
         oa.dist_inner == 1 && (k->n & (k->n - 1)) == 0 && getenv("PFFT_NO_MIXED_ROWS") == nullptr) {
       std::string why;
       if (jit_strided_ensure_row(k, 0, max_lds, &why, 3)) {
@@ -1321,8 +1321,22 @@ struct plan_t {
     addressing b_in{0, 1, n2, n};
     addressing b_out{oa.offset, n1, 1, n};
     stage sb;
+    // SPLIT_COMPLEX user data: when both mixed-storage stage kernels hold the same number of columns, the intermediate
+    // is group-major too and stage B reads it in its tiled-input form (scratch tiles -> the user's planes) instead of
+    // row-staging a row-major one (PFFT_NO_SPLIT_TILED=1: round-3 plan)
+    bool split_tiled = false;
+    if (!interleaved_user && user_io && ka != nullptr && kb != nullptr && ka->launch == nullptr &&
+        kb->launch == nullptr && ka->fpw == kb->fpw && (kb->fpw & (kb->fpw - 1)) == 0 && kb->n_radices >= 2 &&
+        ka->n_radices >= 2 && n2 % kb->fpw == 0 && (n2 / kb->radices[0]) % kb->fpw == 0 &&
+        static_cast<unsigned long long>(n) * elem_bytes() < 0xFFFFFFF0ull && !force_generic_a && !force_generic_b &&
+        sa.strided == ka && getenv("PFFT_NO_SPLIT_TILED") == nullptr && getenv("PFFT_NO_TILED_SCRATCH") == nullptr &&
+        getenv("PFFT_NO_TILED_LANES") == nullptr) {
+      std::string why;
+      split_tiled = jit_strided_ensure_mixed_tin(kb, &why);
+    }
     if (!force_generic_b && strided_fits(kb, n1, BUF_SCRATCH, b_in, out_buf, b_out)) {
-      sb = make_strided_stage(kb, count * n1, n1, BUF_SCRATCH, b_in, out_buf, b_out, scale, backward, 0, !fs_pair);
+      sb = make_strided_stage(kb, count * n1, n1, BUF_SCRATCH, b_in, out_buf, b_out, scale, backward, 0,
+                              !fs_pair && !split_tiled);
       if (fs_pair && kb->fs_groups_per_wg > 0) sb.gpw = kb->fs_groups_per_wg;
     } else {
       sb = make_generic_stage(n2, count * n1, n1, BUF_SCRATCH, b_in, out_buf, b_out, scale, backward, backward);
@@ -1379,6 +1393,7 @@ struct plan_t {
         if (sb.strided->launch_tin != nullptr && sb.strided->fpw == t && getenv("PFFT_NO_TILED_LANES") == nullptr) {
           sb.tiled_in = 1;
         }
+        if (split_tiled && sb.strided->fpw == t) sb.tiled_in = 1;  // (mfn_mixed_tin: run_stage)
         if (ltw && sb.tiled_in == 0) {
           fail(PFFT_INTERNAL_ERROR, "four-step pair: the load-modifier stage B lost its tiled-input form");
         }
@@ -1698,6 +1713,10 @@ struct plan_t {
         a.in_im = in_user ? base_im(s.in_buf) + io : nullptr;
         a.out = const_cast<char*>(base_re(s.out_buf, false)) + oo;
         a.out_im = in_user ? nullptr : const_cast<char*>(base_im(s.out_buf)) + oo;
+        if (s.tiled_in != 0 && !in_user) {
+          hip_check(jit_launch_strided_mixed_tin(s.strided, stream, grid, a, s.backward), "kernel launch");
+          return;
+        }
         hip_check(s.row_mode == 1 && !in_user ? jit_launch_strided_row_mixed(s.strided, stream, grid, a, s.backward)
                                               : jit_launch_strided_mixed(s.strided, stream, grid, a, s.backward, in_user ? 2 : 3),
                   "kernel launch");

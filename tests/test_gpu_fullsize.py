@@ -385,6 +385,12 @@ def test_four_step_stage_pairs_and_split_storage():
         y0 = forward(commit([n], prec, batch, storage, env), x, split)
         diff = float(((y - y0).abs().double().pow(2).sum() / y0.abs().double().pow(2).sum()).sqrt())
         assert diff <= tol, (n, prec, batch, storage, "vs the round-2 plan", diff)
+        if split:
+            # group-major intermediate + tiled-input mixed stage B against the row-major / row-staged plan
+            y1 = forward(commit([n], prec, batch, storage, {"PFFT_NO_SPLIT_TILED": "1"}), x, split)
+            diff = float(((y - y1).abs().double().pow(2).sum() / y1.abs().double().pow(2).sum()).sqrt())
+            assert diff <= tol, (n, prec, batch, "tiled against row-major split intermediate", diff)
+            del y1
         if prec == "f64" and n == 1 << 20 and not split:
             # this pair's stage B carries the inter-stage twiddles on its loads: against the same pair with the
             # modifier on stage A's stores
