@@ -65,6 +65,15 @@ int main(int argc, char** argv) {
         EXPECT(q.wg >= 64 && q.wg <= 1024 && q.wg % q.fpw == 0, "strided n=%lld wg=%d fpw=%d", n, q.wg, q.fpw);
         EXPECT(static_cast<size_t>(n) * q.fpw * es <= 128 * 1024, "strided n=%lld lds", n);
       }
+      // a requested group width (four-step half pairs, plan.cpp) is honoured exactly or refused
+      for (int want : {8, 16}) {
+        pfa::wg_params w;
+        if (n > 32 && pfa::choose_strided_params(prec, n, 1024, max_lds, &w, false, want)) {
+          EXPECT(w.fpw == want && w.wg % want == 0 && w.wg >= 64 && w.wg <= 1024, "strided n=%lld want %d: fpw=%d wg=%d",
+                 n, want, w.fpw, w.wg);
+          EXPECT(static_cast<size_t>(n) * want * es <= 128 * 1024, "strided n=%lld want %d lds", n, want);
+        }
+      }
     }
   }
   std::printf("planned %lld fp32 and %lld fp64 lengths\n", planned[0], planned[1]);
