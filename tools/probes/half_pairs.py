@@ -1,5 +1,5 @@
 """four-step sizes k * 2^m: half pairs (registered stage B + runtime-specialised stage A of the same group width)
-against the round's earlier plan (PFFT_NO_HALF_PAIRS=1) -- error against torch.fft and time, in child processes"""
+against the round's earlier plan (PFFT_NO_HALF_PAIRS=1, or the settings in AB_ENV=K=V,K=V) -- error against torch.fft and time, in child processes"""
 import os, subprocess, sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CHILD = r'''
@@ -32,8 +32,9 @@ if len(sys.argv) > 1:
     cases = [(a.split(":")[0], int(a.split(":")[1])) for a in sys.argv[1:]]
 for prec, n in cases:
     batch = max(1, ((128 << 20) if prec == "f32" else (64 << 20)) // n)
-    for env in ({}, {"PFFT_NO_HALF_PAIRS": "1"}):
+    other = dict(kv.split("=") for kv in os.environ.get("AB_ENV", "PFFT_NO_HALF_PAIRS=1").split(","))  # the B leg
+    for env in ({}, other):
         p = subprocess.run([sys.executable, "-c", CHILD, prec, str(n), str(batch)], env=dict(os.environ, **env),
                            capture_output=True, text=True)
         out = [l for l in p.stdout.splitlines() if "N=" in l]
-        print(("   round-3 plan: " if env else "") + (out[-1] if out else "FAILED: " + p.stderr[-400:]), flush=True)
+        print(("   %s: " % ",".join("%s=%s" % kv for kv in env.items()) if env else "") + (out[-1] if out else "FAILED: " + p.stderr[-400:]), flush=True)
