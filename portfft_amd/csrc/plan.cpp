@@ -766,7 +766,18 @@ struct plan_t {
     if (s.strided != nullptr) {
       const strided_kernel* k = s.strided;
       const long long groups = strided_groups(count, s.sa.inner, k->fpw);
-      if (k->launch == nullptr) return;  // runtime-compiled entries: one group per work-group already
+      if (k->launch == nullptr) {  // runtime-compiled entries: one group per work-group unless asked otherwise
+        int gpw = s.gpw;
+        if (const char* e = getenv("PFFT_JIT_GROUPS_PER_WG")) gpw = std::atoi(e);  // experiments
+        if (gpw > 1 && s.row_mode == 0) {
+          hipFunction_t f = nullptr;
+          for (hipFunction_t c : {k->mfn[0], k->mfn[1], k->mfn[2], k->mfn[3], k->mfn_mixed[0], k->mfn_mixed[2]}) {
+            if (f == nullptr) f = c;
+          }
+          if (f != nullptr) s.grid = persistent_grid(nullptr, f, k->wg, std::max(k->lds_bytes, s.lds_bytes), groups, gpw);
+        }
+        return;
+      }
       const void* fn = s.row_mode != 0 ? k->fn_row[(s.row_mode - 1) * 2 + s.backward]
                                        : (s.tiled_in != 0 ? k->fn_tin[s.backward] : k->fn[s.backward * 2 + (s.store_modifier ? 1 : 0)]);
       if (fn == nullptr) return;
@@ -1299,6 +1310,10 @@ struct plan_t {
       sa = make_strided_stage(ka, count * n2, n2, in_buf, a_in, BUF_SCRATCH, a_out, 1.0, backward, ltw ? 0 : 1);
       if (!ltw) attach_store_tables(sa, n);
       if (fs_pair && ka->fs_groups_per_wg > 0) sa.gpw = ka->fs_groups_per_wg;
+      // a runtime-specialised stage A that is alone on its CU takes eight groups per work-group like the registered
+      // n = 1024 entries (its twiddle / modifier tables are copied to LDS once per work-group): 3 * 2^18 fp32 0.293 ->
+      // 0.303, fp64 0.314 -> 0.332; the short ones (several per CU) are indifferent or lose 1-2 %
+      if (half_pair && ka->launch == nullptr && ka->lds_bytes > 80 * 1024) sa.gpw = 8;
     } else {
       ltw = false;  // (cannot happen for a registered pair; the generic stage A always carries the modifier itself)
       sa = make_generic_stage(n1, count * n2, n2, in_buf, a_in, BUF_SCRATCH, a_out, 1.0, backward, backward);
