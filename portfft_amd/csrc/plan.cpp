@@ -1229,10 +1229,10 @@ struct plan_t {
     addressing a_out{0, n2, 1, n};
     const bool interleaved_user = desc.complex_storage == PFFT_INTERLEAVED_COMPLEX;
     const bool user_io = in_buf != BUF_SCRATCH && out_buf != BUF_SCRATCH;
-    const strided_kernel* ka = interleaved_user ? get_strided(n1, n2, true, false, false, false, cached ? 1 : 0)
-                                                : (user_io ? get_strided_mixed(n1, n2, 2, cached ? 1 : 0) : nullptr);
-    const strided_kernel* kb = interleaved_user ? get_strided(n2, n1, false, false, false, true, cached ? 2 : 0)  // rows in
-                                                : (user_io ? get_strided_mixed(n2, n1, 3, cached ? 2 : 0) : nullptr);
+    // (the default kernels of the two lengths are fetched -- and, for unregistered lengths, compiled -- only when no
+    //  pair takes their place: default_kernels below)
+    const strided_kernel* ka = nullptr;
+    const strided_kernel* kb = nullptr;
     // Four-step pair: entries tuned as stage A / stage B of a group-major intermediate with equal group widths
     // (strided_kernel::fs_a / fs_b; PFFT_NO_FS_PAIRS=1 keeps the default entries of the two lengths)
     bool fs_pair = false;
@@ -1276,6 +1276,12 @@ struct plan_t {
         kb = fb;
         fs_pair = half_pair = true;
       }
+    }
+    if (!fs_pair) {  // default_kernels
+      ka = interleaved_user ? get_strided(n1, n2, true, false, false, false, cached ? 1 : 0)
+                            : (user_io ? get_strided_mixed(n1, n2, 2, cached ? 1 : 0) : nullptr);
+      kb = interleaved_user ? get_strided(n2, n1, false, false, false, true, cached ? 2 : 0)  // rows in
+                            : (user_io ? get_strided_mixed(n2, n1, 3, cached ? 2 : 0) : nullptr);
     }
     // the pair's stage B may carry the inter-stage twiddles on its loads; stage A then has no store modifier
     // (PFFT_NO_LTW=1: the modifier stays on stage A's stores)
