@@ -18,6 +18,7 @@
 #include <vector>
 #include "../portfft_amd/csrc/stockham_strided_hx.hpp"
 #include "probes/stockham_strided_sfr.hpp"
+#include "probes/stockham_strided_dg.hpp"
 #include "../portfft_amd/csrc/kernels.hpp"
 using namespace pfa;
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s line %d\n", hipGetErrorString(e_), __LINE__); exit(1);} } while (0)
@@ -76,7 +77,7 @@ __global__ void fill_uniform(T* p, size_t n, unsigned seed) {
   }
 }
 
-enum kind_t { K_PLAIN = 0, K_PREFETCH = 1, K_HX = 2, K_ROW_IN = 3, K_TIN = 4, K_NOSTW = 5 /* timing only: stage A without its store modifier */, K_PF_TIN = 6, K_SFR = 7, K_PF_TIN_LTW = 8 /* stage B carrying the modifier on its loads */, K_PF_NOSTW = 9 /* timing only */ };
+enum kind_t { K_PLAIN = 0, K_PREFETCH = 1, K_HX = 2, K_ROW_IN = 3, K_TIN = 4, K_NOSTW = 5 /* timing only: stage A without its store modifier */, K_PF_TIN = 6, K_SFR = 7, K_PF_TIN_LTW = 8 /* stage B carrying the modifier on its loads */, K_PF_NOSTW = 9 /* timing only */, K_DG = 10 /* stage A loading two groups' columns at once */ };
 struct variant {
   std::string name;
   int kind, fpw, wg, gpw;
@@ -103,6 +104,7 @@ void add(const char* name, bool tiled, int gpw, size_t extra_lds = 0) {
   else if constexpr (KIND == K_HX) { fn = (const void*)&stockham_strided_hx_kernel<Cfg, false, STW>; lds = strided_hx_lds_bytes<Cfg>(); }
   else if constexpr (KIND == K_ROW_IN) { fn = (const void*)&stockham_strided_row_kernel<Cfg, false, true, false>; lds = strided_row_lds_bytes<Cfg>(); }
   else if constexpr (KIND == K_TIN) { fn = (const void*)&stockham_strided_kernel<Cfg, false, STW, 0, true>; lds = strided_lds_bytes<Cfg>(); }
+  else if constexpr (KIND == K_DG) { fn = (const void*)&stockham_strided_dg_kernel<Cfg, false, STW>; lds = strided_lds_bytes<Cfg>(); }
   else { fn = (const void*)&stockham_strided_kernel<Cfg, false, STW>; lds = strided_lds_bytes<Cfg>(); }
   if (STAGE_A) lds += ((size_t)g_stw_levels << g_stw_shift) * sizeof(cx<T>);
   lds += extra_lds;  // (occupancy experiments: unused LDS that costs resident work-groups)
@@ -119,6 +121,7 @@ void add(const char* name, bool tiled, int gpw, size_t extra_lds = 0) {
     else if constexpr (KIND == K_HX) hipLaunchKernelGGL((stockham_strided_hx_kernel<Cfg, false, STW>), dim3(grid), dim3(Cfg::WG), lds, 0, a);
     else if constexpr (KIND == K_ROW_IN) hipLaunchKernelGGL((stockham_strided_row_kernel<Cfg, false, true, false>), dim3(grid), dim3(Cfg::WG), lds, 0, a);
     else if constexpr (KIND == K_TIN) hipLaunchKernelGGL((stockham_strided_kernel<Cfg, false, STW, 0, true>), dim3(grid), dim3(Cfg::WG), lds, 0, a);
+    else if constexpr (KIND == K_DG) hipLaunchKernelGGL((stockham_strided_dg_kernel<Cfg, false, STW>), dim3(grid), dim3(Cfg::WG), lds, 0, a);
     else hipLaunchKernelGGL((stockham_strided_kernel<Cfg, false, STW>), dim3(grid), dim3(Cfg::WG), lds, 0, a);
   };
   (STAGE_A ? g_a : g_b).push_back(v);
@@ -171,7 +174,7 @@ static result run_pair(const variant& va, const variant& vb, const T* in, T* scr
     for (int c = 0; c < nch; ++c) {
       const long long b0 = c * chunk, nb = std::min(chunk, BATCH - b0);
       const strided_args aa = args_a(va, in + 2 * b0 * N, scratch, nb, t_layout);
-      va.launch(grid_of(va, (nb * N2) / va.fpw), aa);
+      va.launch(grid_of(va, (nb * N2) / (va.kind == K_DG ? 2 * va.fpw : va.fpw)), aa);
       CK(hipEventRecord(ev[2 * c + 1]));
       const strided_args ab = args_b(vb, scratch, out + 2 * b0 * N, nb, t_layout);
       vb.launch(grid_of(vb, (nb * N1) / vb.fpw), ab);
@@ -323,6 +326,12 @@ int main() {
   addB<strided_cfg<f, radix_list<16, 16, 8>, 1024, 8, 4, RD>, K_PF_TIN>("B PF+TIN 16.16.8 wg1024 fpw8 tiled", true, 1);
   addA<strided_cfg<f, radix_list<16, 16, 8>, 1024, 8, 4, W>, K_PLAIN>("A 16.16.8 wg1024 fpw8 tiled gpw4", true, 4);
   addB<strided_cfg<f, radix_list<16, 16, 8>, 1024, 8, 4, RD>, K_TIN>("B 16.16.8 wg1024 fpw8 tiled TIN gpw4", true, 4);
+  addA<strided_cfg<f, radix_list<16, 16, 8>, 1024, 8, 4, W>, K_DG>("A DG 16.16.8 wg1024 fpw8 tiled (16 columns loaded) gpw1", true, 1);
+  addA<strided_cfg<f, radix_list<16, 16, 8>, 1024, 8, 4, W>, K_DG>("A DG 16.16.8 wg1024 fpw8 tiled gpw2", true, 2);
+  addA<strided_cfg<f, radix_list<16, 16, 8>, 1024, 8, 4, W>, K_DG>("A DG 16.16.8 wg1024 fpw8 tiled gpw4", true, 4);
+  addA<strided_cfg<f, radix_list<16, 16, 8>, 512, 8, 2, W>, K_DG>("A DG 16.16.8 wg512 fpw8 tiled gpw2", true, 2);
+  addA<strided_cfg<f, radix_list<16, 16, 8>, 512, 8, 2, W>, K_PLAIN>("A 16.16.8 wg512 fpw8 tiled gpw4", true, 4);
+  addA<strided_cfg<f, radix_list<8, 16, 16>, 1024, 8, 4, W>, K_DG>("A DG 8.16.16 wg1024 fpw8 tiled gpw2", true, 2);
   addA<sfr_cfg<f, radix_list<2, 16, 8, 8>, 1024, 16, 4, W>, K_SFR>("A SFR 2.16.8.8 wg1024 fpw16 tiled 1/CU", true, 4);
   addB<sfr_cfg<f, radix_list<2, 16, 8, 8>, 1024, 16, 4, RD>, K_SFR>("B SFR 2.16.8.8 wg1024 fpw16 tiled 1/CU", true, 4);
   addA<sfr_cfg<f, radix_list<4, 8, 8, 8>, 1024, 16, 4, W>, K_SFR>("A SFR 4.8.8.8 wg1024 fpw16 tiled", true, 4);
