@@ -83,6 +83,11 @@ struct strided_kernel {
   /// width; fn_tin[backward]; null when not instantiated
   const void* fn_tin[2];
   hipError_t (*launch_tin)(hipStream_t stream, unsigned grid, const strided_args& args, int backward);
+  /// ... and the same for tiles of tin_w = 2 * fpw elements (a stage A with groups twice as wide: fp32 n = 2048 holds 8
+  /// columns, its stage A 16 -- 128-byte segments on stage A's side); null / 0 when not instantiated
+  const void* fn_tin_w[2];
+  hipError_t (*launch_tin_w)(hipStream_t stream, unsigned grid, const strided_args& args, int backward);
+  int tin_w;
   /// cache policy of the entry's HBM accesses (stockham_wg.hpp, aux_of_loads / aux_of_stores): 0 everything streamed
   /// (nt), 1 "writer" (streamed loads, default-policy stores: fills an intermediate that should stay in the
   /// Infinity Cache), 2 "reader" (default-policy loads, streamed stores).  Policy twins carry the interleaved forms only.

@@ -18,7 +18,7 @@ std::vector<strided_kernel> build() {
   // (SE_FS_B: the four-step stage B of n2 = 1024 -- software-pipelined, lanes element-fastest inside the tiles of the
   //  group-major intermediate: 86 us per 256 MiB chunk against 113-120 for the row-staged 16.8.8 form)
   add_strided_entries<strided_cfg<f, radix_list<32, 32>, 512, 16, 2, NT>, SE_ROWS | SE_PREFETCH | SE_TIN | SE_FS_B>(v, 4);  // 1024
-  add_strided_entries<strided_cfg<f, radix_list<16, 16, 8>, 1024, 8, 4, NT>, SE_ROWS | SE_TIN | SE_FS_A | SE_FS_B>(v, 1, 4);  // 2048
+  add_strided_entries<strided_cfg<f, radix_list<16, 16, 8>, 1024, 8, 4, NT>, SE_ROWS | SE_TIN | SE_TIN_W | SE_FS_A | SE_FS_B>(v, 1, 4);  // 2048
   add_strided_entries<strided_cfg<f, radix_list<16, 16, 16>, 1024, 4, 4, NT>, SE_ROWS>(v);     // 4096
   // wide groups (512-byte segments) for stages that are column-shaped on both sides with >= 64 adjacent columns: the
   // second pass of the two-pass 2-D plan (1024 x 1024: n = 128 over 8192 columns) and wide batch-interleaved

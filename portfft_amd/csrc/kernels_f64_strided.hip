@@ -27,7 +27,7 @@ std::vector<strided_kernel> build() {
   // ... and it carries the inter-stage twiddles on its loads (SE_LTW): the modifier is 53 % more VALU instructions on
   // stage A, which has no slack, and is hidden behind stage B's memory time -- A 120 -> 108 us, B 90 -> 91-94
   add_strided_entries<strided_cfg<d, radix_list<16, 8, 8>, 512, 8, 2, NT>, SE_PREFETCH | SE_TIN | SE_FS_B | SE_FS_ONLY | SE_LTW>(v, 4);
-  add_strided_entries<strided_cfg<d, radix_list<16, 16, 8>, 512, 4, 2, NT>, SE_TIN>(v);  // 2048
+  add_strided_entries<strided_cfg<d, radix_list<16, 16, 8>, 512, 4, 2, NT>, SE_TIN | SE_TIN_W | SE_FS_B>(v);  // 2048
   // 16 columns per group (256-byte segments) for stages that are column-shaped on both sides (batch-interleaved
   // layouts, N-D outer dimensions): BI N=256 4.7 -> 5.4 TB/s, N=512 4.4 -> 5.0.  The four-step stages keep the
   // 8-column entries above (their row-shaped side gets worse with more rows per wave: N=65536 2.7 -> 2.35).

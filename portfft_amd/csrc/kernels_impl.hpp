@@ -384,6 +384,25 @@ strided_kernel with_tin(strided_kernel k) {
   return k;
 }
 
+/// tiled-input form for tiles twice as wide as the entry's groups (strided_kernel::launch_tin_w)
+template <typename Cfg>
+hipError_t launch_strided_tin_w(hipStream_t stream, unsigned grid, const strided_args& args, int backward) {
+  const size_t lds = strided_lds_bytes<Cfg>();
+  const dim3 g(grid), b(Cfg::WG);
+  if (backward) return pfa_launch(&stockham_strided_kernel<Cfg, true, 0, 0, 2 * Cfg::FPW>, g, b, lds, stream, args);
+  return pfa_launch(&stockham_strided_kernel<Cfg, false, 0, 0, 2 * Cfg::FPW>, g, b, lds, stream, args);
+}
+
+template <typename Cfg>
+strided_kernel with_tin_w(strided_kernel k) {
+  static_assert(tin_supported<Cfg, 2 * Cfg::FPW>(), "see tin_supported()");
+  k.fn_tin_w[0] = reinterpret_cast<const void*>(&stockham_strided_kernel<Cfg, false, 0, 0, 2 * Cfg::FPW>);
+  k.fn_tin_w[1] = reinterpret_cast<const void*>(&stockham_strided_kernel<Cfg, true, 0, 0, 2 * Cfg::FPW>);
+  k.launch_tin_w = &launch_strided_tin_w<Cfg>;
+  k.tin_w = 2 * Cfg::FPW;
+  return k;
+}
+
 template <typename Cfg>
 hipError_t launch_strided_split(hipStream_t stream, unsigned grid, const strided_args& args, int backward) {
   constexpr size_t lds = strided_lds_bytes<Cfg>();
@@ -413,13 +432,15 @@ strided_kernel make_strided_entry_prefetch(int groups_per_wg = 4) {
 /// SE_FS_A / SE_FS_B: the entry of its length for the four-step stage A / stage B (strided_kernel::fs_a / fs_b)
 enum : unsigned { SE_ROWS = 1, SE_TIN = 2, SE_WIDE = 4, SE_ROWISH = 8, SE_PREFETCH = 16, SE_FS_A = 32, SE_FS_B = 64, SE_FS_ONLY = 128,
                 SE_LTW = 256 /* fs_b entry carrying the modifier on its loads (strided_kernel::fs_ltw) */,
-                SE_PLAIN_WRITER = 512 /* the writer twin also carries the forms without store modifier (stage A of an SE_LTW pair) */ };
+                SE_PLAIN_WRITER = 512 /* the writer twin also carries the forms without store modifier (stage A of an SE_LTW pair) */,
+                SE_TIN_W = 1024 /* ... and the tiled-input form for tiles of 2 * FPW elements (strided_kernel::launch_tin_w) */ };
 
 template <typename Cfg, unsigned F>
 strided_kernel make_strided_entry_flags(int groups_per_wg) {
   strided_kernel k = (F & SE_PREFETCH) ? make_strided_entry_prefetch<Cfg>(groups_per_wg) : make_strided_entry<Cfg>(groups_per_wg);
   if constexpr ((F & SE_ROWS) != 0) k = with_rows<Cfg>(k);
   if constexpr ((F & SE_TIN) != 0) k = with_tin<Cfg, (F & SE_PREFETCH) != 0, (F & SE_LTW) != 0 ? 1 : 0>(k);
+  if constexpr ((F & SE_TIN_W) != 0) k = with_tin_w<Cfg>(k);
   k.fs_ltw = (F & SE_LTW) != 0;
   k.wide = (F & SE_WIDE) != 0;
   k.rowish = (F & SE_ROWISH) != 0;
@@ -481,6 +502,9 @@ strided_kernel make_strided_twin(const strided_kernel& base, int policy) {
   for (auto& fp : k.fn_row) fp = nullptr;
   k.fn_split[0] = k.fn_split[1] = nullptr;
   k.fn_tin[0] = k.fn_tin[1] = nullptr;
+  k.fn_tin_w[0] = k.fn_tin_w[1] = nullptr;
+  k.launch_tin_w = nullptr;
+  k.tin_w = 0;
   k.launch_split = nullptr;
   k.launch_row = nullptr;
   k.launch_tin = nullptr;
@@ -514,6 +538,7 @@ strided_kernel make_strided_twin(const strided_kernel& base, int policy) {
       k.launch_row = &launch_strided_row_in<Cfg>;
     }
     if constexpr ((F & SE_TIN) != 0) k = with_tin<Cfg, PF, (F & SE_LTW) != 0 ? 1 : 0>(k);
+    if constexpr ((F & SE_TIN_W) != 0) k = with_tin_w<Cfg>(k);
   }
   return k;
 }

@@ -425,6 +425,15 @@ struct plan_t {
     s.lds_bytes = total;
   }
 
+  /// Width of the intermediate's tiles -- i.e. the group width its stage A must have -- when `fb` is the four-step
+  /// stage B of length n2: its own group width (square tiles, launch_tin) or, `wide`, twice that (launch_tin_w).
+  /// 0 when the entry has no such form or the length does not divide into those tiles.
+  static int pair_tile(const strided_kernel* fb, long long n2, bool wide) {
+    const int t = wide ? (fb->launch_tin_w != nullptr ? fb->tin_w : 0) : (fb->launch_tin != nullptr ? fb->fpw : 0);
+    if (t <= 0 || (t & (t - 1)) != 0 || n2 % t != 0 || (n2 / fb->radices[0]) % t != 0) return 0;
+    return t;
+  }
+
   const spec_kernel* find_spec(long long n) const {
     if (getenv("PFFT_NO_PRECOMPILED") != nullptr) return nullptr;  // experiments: planner-chosen kernels everywhere
     int count = 0;
@@ -730,6 +739,11 @@ struct plan_t {
                                         static_cast<int>(k->lds_bytes)),
                     "hipFuncSetAttribute");
         }
+        if (k->fn_tin_w[i / 2] != nullptr) {
+          hip_check(hipFuncSetAttribute(k->fn_tin_w[i / 2], hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        static_cast<int>(k->lds_bytes)),
+                    "hipFuncSetAttribute");
+        }
         if (k->fn_tin[i / 2] != nullptr) {
           hip_check(hipFuncSetAttribute(k->fn_tin[i / 2], hipFuncAttributeMaxDynamicSharedMemorySize,
                                         static_cast<int>(k->lds_bytes)),
@@ -779,7 +793,8 @@ struct plan_t {
         return;
       }
       const void* fn = s.row_mode != 0 ? k->fn_row[(s.row_mode - 1) * 2 + s.backward]
-                                       : (s.tiled_in != 0 ? k->fn_tin[s.backward] : k->fn[s.backward * 2 + (s.store_modifier ? 1 : 0)]);
+                                       : (s.tiled_in == 2 ? k->fn_tin_w[s.backward]
+                                          : s.tiled_in != 0 ? k->fn_tin[s.backward] : k->fn[s.backward * 2 + (s.store_modifier ? 1 : 0)]);
       if (fn == nullptr) return;
       const size_t lds = s.row_mode != 0 ? k->lds_bytes_row : std::max(k->lds_bytes, s.lds_bytes);
       s.grid = persistent_grid(fn, nullptr, k->wg, lds, groups, s.gpw > 0 ? s.gpw : k->groups_per_wg);
@@ -1166,29 +1181,45 @@ struct plan_t {
         getenv("PFFT_NO_FS_PAIRS") == nullptr && getenv("PFFT_NO_HALF_PAIRS") == nullptr &&
         getenv("PFFT_NO_TILED_SCRATCH") == nullptr && getenv("PFFT_NO_TILED_LANES") == nullptr &&
         getenv("PFFT_NO_PRECOMPILED") == nullptr && getenv("PFFT_DEBUG_GLOBAL") == nullptr) {
+      // 0: no pair; 1: pairs, stage B's own groups span whole lines; 2: pairs, but stage B's OUTPUT segments are
+      // narrower than a line (fp32 n2 = 2048: 8 columns -- its tiles may still be 16 wide, pair_tile)
       auto pairable = [&](long long m, long long len) {  // m: stage A's length, len: stage B's
         const strided_kernel* fb = find_strided(len, false, false, -1, 0, false, 2);
-        if (fb == nullptr || fb->launch_tin == nullptr || (fb->fpw & (fb->fpw - 1)) != 0 || len % fb->fpw != 0 ||
-            (len / fb->radices[0]) % fb->fpw != 0 || static_cast<size_t>(fb->fpw) * elem_bytes() < 128) {
-          return false;
+        if (fb == nullptr) return 0;
+        for (int wide = 1; wide >= 0; --wide) {
+          const int t = pair_tile(fb, len, wide != 0);
+          if (t == 0 || static_cast<size_t>(t) * elem_bytes() < 128) continue;  // stage A in whole lines only
+          const int kind = static_cast<size_t>(fb->fpw) * elem_bytes() < 128 ? 2 : 1;
+          if (const strided_kernel* fa = find_strided(m, false, false, -1, 0, true, 1)) {
+            if (fa->fpw == t) return kind;
+            continue;
+          }
+          wg_params p;
+          if (choose_strided_params(desc.precision, m, len, max_lds, &p, false, t) && p.radices.size() >= 2) return kind;
         }
-        if (const strided_kernel* fa = find_strided(m, false, false, -1, 0, true, 1)) return fa->fpw == fb->fpw;
-        wg_params p;
-        return choose_strided_params(desc.precision, m, len, max_lds, &p, false, fb->fpw) && p.radices.size() >= 2;
+        return 0;
       };
       int count_k = 0;
       const strided_kernel* k =
           desc.precision == PFFT_PRECISION_F64 ? strided_kernels_f64(&count_k) : strided_kernels_f32(&count_k);
       const long long short_a = desc.precision == PFFT_PRECISION_F64 ? 128 : 160;
-      long long above = 0, below = 0;  // smallest pairing n1 >= short_a, largest pairing n1 below
+      // [0]: candidates whose stage B writes whole lines, [1]: the others (taken only when [0] is empty);
+      // per class: the smallest pairing n1 >= short_a, the largest pairing n1 below
+      long long above_c[2] = {0, 0}, below_c[2] = {0, 0};
       for (int i = 0; i < count_k; ++i) {
         const long long len = k[i].n;
         if (k[i].fs_b == 0 || k[i].policy != 0 || n % len != 0 || n / len < 2) continue;
         const long long m = n / len;
-        if (m == above || m == below || strided_fpw(m, len) <= 0 || !pairable(m, len)) continue;
+        if (strided_fpw(m, len) <= 0) continue;
+        const int kind = pairable(m, len);
+        if (kind == 0) continue;
+        long long& above = above_c[kind - 1];
+        long long& below = below_c[kind - 1];
         if (m >= short_a && (above == 0 || m < above)) above = m;
         if (m < short_a && m > below) below = m;
       }
+      const int cls = (above_c[0] != 0 || below_c[0] != 0) ? 0 : 1;
+      const long long above = above_c[cls], below = below_c[cls];
       if (above != 0 || below != 0) {
         n1 = above != 0 ? above : below;
         n2 = n / n1;
@@ -1240,8 +1271,8 @@ struct plan_t {
         getenv("PFFT_NO_TILED_LANES") == nullptr && getenv("PFFT_NO_PRECOMPILED") == nullptr) {
       const strided_kernel* fa = find_strided(n1, false, false, -1, cached ? 1 : 0, true, 1);
       const strided_kernel* fb = find_strided(n2, false, false, -1, cached ? 2 : 0, false, 2);
-      if (fa != nullptr && fb != nullptr && fb->launch_tin != nullptr && fa->fpw == fb->fpw &&
-          (fa->fpw & (fa->fpw - 1)) == 0 && n2 % fa->fpw == 0 && (n2 / fb->radices[0]) % fa->fpw == 0 &&
+      if (fa != nullptr && fb != nullptr &&
+          (fa->fpw == pair_tile(fb, n2, false) || fa->fpw == pair_tile(fb, n2, true)) &&
           static_cast<unsigned long long>(n) * elem_bytes() < 0xFFFFFFF0ull && store_tables_fit(fa, n)) {
         ka = fa;
         kb = fb;
@@ -1256,19 +1287,21 @@ struct plan_t {
         getenv("PFFT_NO_HALF_PAIRS") == nullptr && getenv("PFFT_NO_TILED_SCRATCH") == nullptr &&
         getenv("PFFT_NO_TILED_LANES") == nullptr && getenv("PFFT_NO_PRECOMPILED") == nullptr &&
         getenv("PFFT_DEBUG_GLOBAL") == nullptr && find_strided(n1, false, false, -1, 0, true, 1) == nullptr) {
-      for (int with_ltw = 1; with_ltw >= 0 && !half_pair; --with_ltw) {
-        const strided_kernel* fb = find_strided(n2, false, false, -1, cached ? 2 : 0, false, 2, with_ltw != 0);
-        if (fb == nullptr || fb->launch_tin == nullptr || (fb->fpw & (fb->fpw - 1)) != 0 || n2 % fb->fpw != 0 ||
-            (n2 / fb->radices[0]) % fb->fpw != 0 ||
-            static_cast<unsigned long long>(n) * elem_bytes() >= 0xFFFFFFF0ull) {
-          continue;
-        }
+      const strided_kernel* da = find_strided(n1);  // (a registered default of the pairing width pairs by itself below)
+      for (int pass = 0; pass < 4 && !half_pair; ++pass) {
+        const bool with_ltw = pass < 2, wide = (pass & 1) == 0;
+        const strided_kernel* fb = find_strided(n2, false, false, -1, cached ? 2 : 0, false, 2, with_ltw);
+        if (fb == nullptr || static_cast<unsigned long long>(n) * elem_bytes() >= 0xFFFFFFF0ull) continue;
+        const int t = pair_tile(fb, n2, wide);
+        if (t == 0 || (da != nullptr && da->fpw == t)) continue;
         const bool on_loads = fb->fs_ltw != 0;
-        if (on_loads && (with_ltw == 0 || fb->stw_mode != 1 || !store_tables_fit(fb, n))) continue;
+        if (on_loads && (!with_ltw || wide || fb->stw_mode != 1 || !store_tables_fit(fb, n))) continue;
+        wg_params probe;
+        if (!choose_strided_params(desc.precision, n1, n2, max_lds, &probe, false, t) || probe.radices.size() < 2) continue;
         std::string why;
-        const strided_kernel* fa = jit_strided_kernel(desc.precision, n1, n2, !on_loads, 0, max_lds, &why, false,
-                                                      cached ? 1 : 0, fb->fpw);
-        if (fa == nullptr || fa->fpw != fb->fpw || fa->n_radices < 2 || (!on_loads && !store_tables_fit(fa, n)) ||
+        const strided_kernel* fa =
+            jit_strided_kernel(desc.precision, n1, n2, !on_loads, 0, max_lds, &why, false, cached ? 1 : 0, t);
+        if (fa == nullptr || fa->fpw != t || fa->n_radices < 2 || (!on_loads && !store_tables_fit(fa, n)) ||
             !strided_fits(fa, n2, in_buf, addressing{ia.offset, n2, 1, n}, BUF_SCRATCH, addressing{0, n2, 1, n})) {
           continue;
         }
@@ -1415,6 +1448,11 @@ struct plan_t {
           sb.tiled_in = 1;
         }
         if (split_tiled && sb.strided->fpw == t) sb.tiled_in = 1;  // (mfn_mixed_tin: run_stage)
+        // tiles twice as wide as stage B's groups (fp32 n2 = 2048 behind a 16-column stage A)
+        if (sb.tiled_in == 0 && sb.strided->launch_tin_w != nullptr && sb.strided->tin_w == t &&
+            getenv("PFFT_NO_TILED_LANES") == nullptr && getenv("PFFT_NO_WIDE_TILES") == nullptr) {
+          sb.tiled_in = 2;
+        }
         if (ltw && sb.tiled_in == 0) {
           fail(PFFT_INTERNAL_ERROR, "four-step pair: the load-modifier stage B lost its tiled-input form");
         }
@@ -1771,7 +1809,9 @@ struct plan_t {
         return;
       }
       if (s.tiled_in != 0) {
-        hip_check(s.strided->launch_tin(stream, grid, a, s.backward), "kernel launch");
+        hip_check(s.tiled_in == 2 ? s.strided->launch_tin_w(stream, grid, a, s.backward)
+                                  : s.strided->launch_tin(stream, grid, a, s.backward),
+                  "kernel launch");
         return;
       }
       hip_check(s.strided->launch != nullptr

@@ -177,21 +177,29 @@ PFA_DEV void strided_store_butterfly(const IO& io, const strided_args& a, unsign
 }
 
 /// TIN (tiled input, the four-step stage B behind a group-major stage A): the input of the group is a sequence of
-/// tiles [f][i % FPW] of FPW x FPW elements (strided_args::in_tile_shift == log2 FPW).  Addressed f-fastest a wave
-/// would read one whole tile per instruction but with its lanes transposed inside it (16-byte pieces 128 B apart:
-/// 5.1 instead of 5.8 TB/s on the C3 stage B, profiles/r2_notes.md).  With TIN pass 0 takes its lanes
-/// element-fastest inside a tile -- lane = (i % FPW) + FPW * f + FPW^2 * (i / FPW) -- so every wave-instruction reads
-/// consecutive addresses, and the exchange behind pass 0 stores f ^ (i % FPW) in place of f so that the scatter
-/// (lane stride R0 elements = a multiple of all banks) stays conflict-free; pass 1 reads through the same
-/// permutation, the later passes are unchanged.  Needs FPW^2 | WG and (N / R0) % FPW == 0.
-template <typename Cfg>
+/// tiles [f][i % TW] of FPW x TW elements (strided_args::in_tile_shift == log2 TW; TW = the group width of the stage A
+/// that wrote them).  Addressed f-fastest a wave would read one whole tile per instruction but with its lanes transposed
+/// inside it (16-byte pieces 128 B apart: 5.1 instead of 5.8 TB/s on the C3 stage B, profiles/r2_notes.md).  With TIN
+/// pass 0 takes its lanes element-fastest inside a tile -- lane = (i % TW) + TW * f + TW * FPW * (i / TW) -- so every
+/// wave-instruction reads consecutive addresses, and the exchange behind pass 0 stores f ^ (i % FPW) in place of f so
+/// that the scatter (lane stride R0 elements = a multiple of all banks) stays conflict-free (TW <= FPW; two-way
+/// conflicts when TW = 2 * FPW); pass 1 reads through the same permutation, the later passes are unchanged.
+/// Template value: 0 off, 1 square tiles (TW = FPW), any other value = TW (a stage A with wider groups: fp32 n2 = 2048
+/// holds 8 columns, its stage A 16).  Needs TW * FPW | WG, (N / R0) % TW == 0 and (N / R0) % TPF == 0.
+template <typename Cfg, int TIN = 1>
+constexpr int tin_width() {
+  return TIN == 1 ? Cfg::FPW : TIN;
+}
+template <typename Cfg, int TIN = 1>
 constexpr bool tin_supported() {
-  return Cfg::NP >= 2 && (Cfg::FPW & (Cfg::FPW - 1)) == 0 && Cfg::WG % (Cfg::FPW * Cfg::FPW) == 0 &&
-         (Cfg::N / Cfg::Seq::r[0]) % Cfg::FPW == 0 && (Cfg::N / Cfg::Seq::r[0]) % Cfg::TPF == 0;
+  constexpr int TW = tin_width<Cfg, TIN>();
+  return TIN != 0 && Cfg::NP >= 2 && (Cfg::FPW & (Cfg::FPW - 1)) == 0 && (TW & (TW - 1)) == 0 && TW >= 2 &&
+         Cfg::WG % (TW * Cfg::FPW) == 0 && (Cfg::N / Cfg::Seq::r[0]) % TW == 0 &&
+         (Cfg::N / Cfg::Seq::r[0]) % Cfg::TPF == 0;
 }
 
 template <typename Cfg, bool BWD, int STW, int P, typename IO, bool ROW_IN = false, bool ROW_OUT = false,
-          bool TIN = false>
+          int TIN = 0>
 PFA_DEV void strided_pass(const IO& io, const strided_args& a, unsigned f,
                           unsigned tid, bool live, long long c0, cx<typename Cfg::T>* lds,
                           const cx<typename Cfg::T>* __restrict__ tw, long long nlive = 0) {
@@ -208,15 +216,16 @@ PFA_DEV void strided_pass(const IO& io, const strided_args& a, unsigned f,
   constexpr int FPW = strided_pitch<Cfg, ROW_IN || ROW_OUT>();
   [[maybe_unused]] constexpr unsigned ES_IN = IO::ES_IN;
 
-  constexpr bool tin0 = TIN && P == 0;  // lanes element-fastest inside the input tiles
-  constexpr bool tin1 = TIN && P == 1;  // reads through the permutation pass 0 stored with
+  constexpr bool tin0 = TIN != 0 && P == 0;  // lanes element-fastest inside the input tiles
+  constexpr bool tin1 = TIN != 0 && P == 1;  // reads through the permutation pass 0 stored with
   [[maybe_unused]] unsigned tin_jl = 0;
   if constexpr (tin0) {
-    static_assert(first && tin_supported<Cfg>(), "TIN: see tin_supported()");
+    static_assert(first && tin_supported<Cfg, TIN>(), "TIN: see tin_supported()");
+    constexpr unsigned TW = tin_width<Cfg, TIN>();
     const unsigned lane = threadIdx.x;
-    tin_jl = lane % Cfg::FPW;
-    f = (lane / Cfg::FPW) % Cfg::FPW;
-    tid = (lane / (Cfg::FPW * Cfg::FPW)) * Cfg::FPW + tin_jl;
+    tin_jl = lane % TW;
+    f = (lane / TW) % Cfg::FPW;
+    tid = (lane / (TW * Cfg::FPW)) * TW + tin_jl;
     live = static_cast<long long>(f) < nlive;
   }
   cx<T> v[BPT][R];
@@ -295,7 +304,7 @@ PFA_DEV void strided_pass(const IO& io, const strided_args& a, unsigned f,
 }
 
 template <typename Cfg, bool BWD, int STW, int P, typename IO, bool ROW_IN = false, bool ROW_OUT = false,
-          bool TIN = false>
+          int TIN = 0>
 PFA_DEV void strided_passes(const IO& io, const strided_args& a, unsigned f, unsigned tid, bool live, long long c0,
                             cx<typename Cfg::T>* lds, const cx<typename Cfg::T>* __restrict__ tw,
                             long long nlive = 0) {
@@ -305,12 +314,13 @@ PFA_DEV void strided_passes(const IO& io, const strided_args& a, unsigned f, uns
   }
 }
 
-/// TIN lane mapping of pass 0 (see strided_pass): lanes element-fastest inside the FPW x FPW input tiles
-template <typename Cfg>
+/// TIN lane mapping of pass 0 (see strided_pass): lanes element-fastest inside the FPW x TW input tiles
+template <typename Cfg, int TIN = 1>
 PFA_DEV void tin_lanes(unsigned* f, unsigned* tid, bool* live, long long nlive) {
+  constexpr unsigned TW = tin_width<Cfg, TIN>();
   const unsigned lane = threadIdx.x;
-  *f = (lane / Cfg::FPW) % Cfg::FPW;
-  *tid = (lane / (Cfg::FPW * Cfg::FPW)) * Cfg::FPW + lane % Cfg::FPW;
+  *f = (lane / TW) % Cfg::FPW;
+  *tid = (lane / (TW * Cfg::FPW)) * TW + lane % TW;
   *live = static_cast<long long>(*f) < nlive;
 }
 
@@ -344,7 +354,7 @@ PFA_DEV void strided_pass0_load(const IO& io, const strided_args& a, unsigned f,
 /// LTW (1 LDS tables / 2 global tables, as STW): the inter-stage twiddles applied to the INPUTS of the stage -- element
 /// j + t * NB of the FFT with inner index c0 + f is multiplied by W_M^{(j + t*NB) * c} before pass 0 (the four-step
 /// stage B carrying the modifier instead of stage A's stores)
-template <typename Cfg, bool TIN = false, int LTW = 0>
+template <typename Cfg, int TIN = 0, int LTW = 0>
 PFA_DEV void strided_pass0_compute(cx<typename Cfg::T> (&v)[Cfg::bpt(0)][Cfg::Seq::r[0]], unsigned f, unsigned tid,
                                    cx<typename Cfg::T>* lds, const strided_args* a = nullptr, long long c0 = 0) {
   constexpr int R = Cfg::Seq::r[0];
@@ -357,7 +367,7 @@ PFA_DEV void strided_pass0_compute(cx<typename Cfg::T> (&v)[Cfg::bpt(0)][Cfg::Se
       if constexpr (LTW != 0) stw_apply<Cfg, LTW, R>(*a, j, static_cast<unsigned>(NB), stw_column(*a, c0, f), v[i]);
       dft<R>(v[i]);
       // TIN: element e = j * R + u of FFT f goes to slot f ^ (j % FPW) (strided_pass)
-      cx<typename Cfg::T>* p = lds + (j * R) * Cfg::FPW + (TIN ? (f ^ (j % Cfg::FPW)) : f);
+      cx<typename Cfg::T>* p = lds + (j * R) * Cfg::FPW + (TIN != 0 ? (f ^ (j % Cfg::FPW)) : f);
       sfor<0, R>([&](auto u_) PFA_LAMBDA {
         constexpr int u = decltype(u_)::value;
         p[u * Cfg::FPW] = v[i][u];
@@ -436,11 +446,11 @@ PFA_DEV void strided_copy_twiddles(cx<typename Cfg::T>* lds, const cx<typename C
 /// Software-pipelined strided kernel: the loads of the work-group's next group are in flight during the LDS passes
 /// of the current one (see stockham_wg_prefetch_kernel).  TIN: tiled input read with the lanes element-fastest inside
 /// the tiles (strided_pass), for the four-step stage B behind a group-major stage A.
-template <typename Cfg, bool BWD, int STW, int SPLIT = 0, bool TIN = false, int LTW = 0>
+template <typename Cfg, bool BWD, int STW, int SPLIT = 0, int TIN = 0, int LTW = 0>
 __global__ __launch_bounds__(Cfg::WG, Cfg::OCC) void stockham_strided_prefetch_kernel(const strided_args a) {
   using T = typename Cfg::T;
   static_assert(Cfg::NP >= 2, "the strided tier needs at least two passes (LDS exchange)");
-  static_assert(!TIN || tin_supported<Cfg>(), "TIN: see tin_supported()");
+  static_assert(TIN == 0 || tin_supported<Cfg, TIN>(), "TIN: see tin_supported()");
   extern __shared__ __attribute__((aligned(16))) char pfa_smem_strided[];
   cx<T>* lds = reinterpret_cast<cx<T>*>(pfa_smem_strided);
   const unsigned f = threadIdx.x % Cfg::FPW;
@@ -461,7 +471,7 @@ __global__ __launch_bounds__(Cfg::WG, Cfg::OCC) void stockham_strided_prefetch_k
   // pass 0 runs on the TIN lane mapping (f0, tid0), the later passes on (f, tid)
   unsigned f0 = f, tid0 = tid;
   bool live0 = live;
-  if constexpr (TIN) tin_lanes<Cfg>(&f0, &tid0, &live0, nlive);
+  if constexpr (TIN != 0) tin_lanes<Cfg, TIN>(&f0, &tid0, &live0, nlive);
   strided_pass0_load<Cfg, BWD>(io, a, f0, tid0, live0, cur);
   for (; g < ngroups; g += gridDim.x) {
     strided_pass0_compute<Cfg, TIN, LTW>(cur, f0, tid0, lds, &a, c0);
@@ -469,7 +479,7 @@ __global__ __launch_bounds__(Cfg::WG, Cfg::OCC) void stockham_strided_prefetch_k
     if (gn < ngroups) {
       io_n = strided_group<Cfg, SPLIT>(a, gn, f, &live_n, &c0_n, &nlive_n);
       bool live0_n = live_n;
-      if constexpr (TIN) tin_lanes<Cfg>(&f0, &tid0, &live0_n, nlive_n);
+      if constexpr (TIN != 0) tin_lanes<Cfg, TIN>(&f0, &tid0, &live0_n, nlive_n);
       strided_pass0_load<Cfg, BWD>(io_n, a, f0, tid0, live0_n, nxt);
     }
     strided_passes<Cfg, BWD, STW, 1, decltype(io), false, false, TIN>(io, a, f, tid, live, c0, lds, tw, nlive);
@@ -584,7 +594,7 @@ PFA_DEV void strided_copy_twiddles(cx<typename Cfg::T>* lds, const cx<typename C
   }
 }
 
-template <typename Cfg, bool BWD, int STW, int SPLIT = 0, bool TIN = false>
+template <typename Cfg, bool BWD, int STW, int SPLIT = 0, int TIN = 0>
 __global__ __launch_bounds__(Cfg::WG, Cfg::OCC) void stockham_strided_kernel(const strided_args a) {
   using T = typename Cfg::T;
   // (a single-pass plan -- one lane per FFT, the reference's WORKITEM tier on strided data -- uses no LDS at all)

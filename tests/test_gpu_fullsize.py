@@ -428,6 +428,8 @@ def test_four_step_half_pairs_and_split_choice():
         (7 << 14, "f32", 3, [224, 512]), (9 << 16, "f32", 2, [576, 1024]), (3 << 18, "f32", 2, [768, 1024]),
         (1 << 18, "f32", 3, [256, 1024]), (3 << 13, "f32", 7, [96, 256]), (5 << 18, "f32", 2, None),
         (3 << 20, "f32", 2, [1536, 2048]),
+        # stage B n2 = 2048 reading tiles twice as wide as its groups (launch_tin_w) behind a 16-column stage A
+        (1 << 21, "f32", 2, [1024, 2048]), (3 << 19, "f32", 2, [768, 2048]), (1 << 21, "f64", 2, [1024, 2048]),
         (12288, "f64", 5, None), (3 << 15, "f64", 3, None), (3 << 17, "f64", 2, [384, 1024]),
         (5 << 17, "f64", 2, [640, 1024]),
         (3 << 15, "f32", 700, None), (3 << 16, "f64", 170, None),  # chunked, ragged last chunk
@@ -453,9 +455,9 @@ def test_four_step_half_pairs_and_split_choice():
         err = float(((z / n - x).abs().double().pow(2).sum() / x.abs().double().pow(2).sum()).sqrt())
         assert err <= tol, (n, prec, batch, "round trip", err)
         y0 = torch.empty_like(x)
-        commit(n, prec, batch, {"PFFT_NO_HALF_PAIRS": "1"}).compute_forward(x, y0).wait()
+        commit(n, prec, batch, {"PFFT_NO_HALF_PAIRS": "1", "PFFT_NO_WIDE_TILES": "1"}).compute_forward(x, y0).wait()
         diff = float(((y - y0).abs().double().pow(2).sum() / y0.abs().double().pow(2).sum()).sqrt())
-        assert diff <= tol, (n, prec, batch, "vs the plan without half pairs", diff)
+        assert diff <= tol, (n, prec, batch, "vs the plan without half pairs / wide tiles", diff)
         del x, y, z, y0, plan
         torch.cuda.empty_cache()
 
