@@ -1035,6 +1035,150 @@ struct plan_t {
   }
 
   /// Plan `count` 1-D FFTs of length n.  Returns the tier used.
+  /// Three-stage plan of the GLOBAL tier for lengths whose two-factor split needs a factor above 2048 (N >= 2^23: n = 4096
+  /// holds 4 fp32 columns -- 32-byte segments, 0.11 of peak at N = 2^23, 0.086 at 2^24): N = n1 * n2 * n3, the four-step
+  /// applied twice (reference: global_dispatcher.hpp:343-408 runs one kernel per factor of an arbitrary factor list).
+  ///   S1  n1-point FFTs over stride n2 * n3 for every column c of [0, n2 * n3), x W_N^(k1 * c)        user in -> user out
+  ///   S2  per row k1: n2-point FFTs over stride n3 for every column c3, x W_(n2 n3)^(k2 * c3)         user out -> scratch
+  ///   S3  n3-point FFTs over c3 for every (k1, k2), result to X[k1 + n1 * k2 + n1 * n2 * k3]             scratch -> user out
+  /// S1 and S2 are ordinary stage-A launches.  S3's work-groups take t ADJACENT k1 (the index its output is contiguous
+  /// in), which are rows n2 * n3 apart after S2 -- so S2 writes the scratch as tiles [k1 % t][c3 % t] (blocks
+  /// [k1 / t][k2][c3 / t]: two-level outer index + group-major addressing of strided_args) and S3 reads each group's
+  /// t * n3 elements contiguously in its tiled-input form.  S2 / S3 run chunk by chunk like the two-stage plan.
+  bool plan_three_stage(std::vector<stage>& out, long long n, long long count, const addressing& ia,
+                        const addressing& oa, double scale, int backward, pfft_dim_info_t* info) {
+    if (getenv("PFFT_NO_THREE_STAGE") != nullptr || getenv("PFFT_NO_PRECOMPILED") != nullptr ||
+        getenv("PFFT_DEBUG_GLOBAL") != nullptr || getenv("PFFT_NO_TILED_SCRATCH") != nullptr ||
+        getenv("PFFT_NO_TILED_LANES") != nullptr) {
+      return false;
+    }
+    long long min_n = 1ll << 23;
+    if (const char* e = getenv("PFFT_THREE_STAGE_MIN")) min_n = std::atoll(e);  // experiments
+    if (n < min_n || static_cast<unsigned long long>(n) * elem_bytes() >= 0xFFFFFFF0ull) return false;
+    const size_t per_transform = static_cast<size_t>(n) * elem_bytes();
+    const bool cached = cache_chunk_bytes() >= per_transform &&
+                        per_transform * static_cast<size_t>(count) >= cache_chunk_bytes() / 2;
+    // S3: a registered stage-B entry with whole-line groups and square tiles
+    const strided_kernel* k3 = nullptr;
+    long long n3 = 0;
+    int t = 0;
+    for (long long len : {1024ll, 512ll, 256ll}) {
+      if (n % len != 0) continue;
+      const strided_kernel* fb = find_strided(len, false, false, -1, cached ? 2 : 0, false, 2, false);
+      if (fb == nullptr) continue;
+      const int tt = pair_tile(fb, len, false);
+      if (tt == 0 || static_cast<size_t>(tt) * elem_bytes() < 128) continue;
+      k3 = fb;
+      n3 = len;
+      t = tt;
+      break;
+    }
+    if (k3 == nullptr) return false;
+    // n1 * n2 = N / n3, n1 <= n2, t | n1 (tiles over k1); S2 needs a stage-A kernel of t columns
+    const long long m12 = n / n3;
+    long long n1 = 0;
+    const strided_kernel* k2 = nullptr;
+    bool k2_jit = false;
+    for (long long c = static_cast<long long>(std::sqrt(static_cast<double>(m12))); c >= t && n1 == 0; --c) {
+      if (m12 % c != 0 || c % t != 0) continue;
+      const long long c2 = m12 / c;
+      if (c2 > 2048 || strided_fpw(c, c2 * n3) <= 0) continue;
+      if (const strided_kernel* fa = find_strided(c2, false, false, -1, cached ? 1 : 0, true, 1)) {
+        if (fa->fpw != t) continue;
+        k2 = fa;
+        k2_jit = false;
+      } else {
+        wg_params p;
+        if (!jit_enabled() || !choose_strided_params(desc.precision, c2, n3, max_lds, &p, false, t) ||
+            p.radices.size() < 2) {
+          continue;
+        }
+        k2 = nullptr;
+        k2_jit = true;
+      }
+      n1 = c;
+    }
+    if (n1 == 0) return false;
+    const long long n2 = m12 / n1, M = n2 * n3;
+    if (k2_jit) {
+      std::string why;
+      k2 = jit_strided_kernel(desc.precision, n2, n3, true, 0, max_lds, &why, false, cached ? 1 : 0, t);
+      if (k2 == nullptr || k2->fpw != t) return false;
+    }
+    const strided_kernel* k1 = get_strided(n1, M, true, false, false, false, 0);
+    int sh = 0;
+    while ((1 << sh) < t) ++sh;
+    const addressing a1_in{ia.offset, M, 1, n}, a1_out{oa.offset, M, 1, n};
+    const addressing a2_in{oa.offset, n3, 1, M}, a2_out{0, static_cast<long long>(t) * n3, 1, t};
+    const addressing a3_in{0, 1, t, static_cast<long long>(t) * n3}, a3_out{oa.offset, n1 * n2, 1, n1};
+    if (!strided_fits(k1, M, BUF_IN, a1_in, BUF_OUT, a1_out) || !store_tables_fit(k1, n) ||
+        !strided_fits(k2, n3, BUF_OUT, a2_in, BUF_SCRATCH, a2_out) || !store_tables_fit(k2, M) ||
+        !strided_fits(k3, n1, BUF_SCRATCH, a3_in, BUF_OUT, a3_out)) {
+      return false;
+    }
+    long long chunk = static_cast<long long>((cached ? cache_chunk_bytes() : global_chunk_bytes()) / per_transform);
+    chunk = std::max<long long>(1, std::min<long long>(chunk, count));
+    scratch_bytes = std::max(scratch_bytes, static_cast<size_t>(chunk) * per_transform);
+    const int group_id = n_chunk_groups++;
+    stage s1 = make_strided_stage(k1, count * M, M, BUF_IN, a1_in, BUF_OUT, a1_out, 1.0, backward, 1);
+    attach_store_tables(s1, n);
+    out.push_back(s1);
+    stage s2 = make_strided_stage(k2, count * n1 * n3, n3, BUF_OUT, a2_in, BUF_SCRATCH, a2_out, 1.0, backward, 1, false);
+    attach_store_tables(s2, M);
+    {  // rows (b, k1) in, tiles [k1 % t][c3 % t] of the blocks [k1 / t][k2][c3 / t] out
+      strided_args& a = s2.sa;
+      a.outer_lo = t;
+      a.in_dist_outer = M;
+      a.in_dist_outer_hi = static_cast<long long>(t) * M;
+      a.out_dist_outer = t;
+      a.out_dist_outer_hi = static_cast<long long>(t) * M;
+      a.out_gdist = static_cast<long long>(t) * t;
+      a.out_stride = static_cast<unsigned>(static_cast<long long>(t) * n3);
+      a.out_fdist = 1;
+    }
+    s2.chunk_group = group_id;
+    s2.chunk_batches = chunk;
+    s2.ffts_per_batch = n1 * n3;
+    s2.in_batch_dist = n;
+    s2.out_batch_dist = 0;
+    if (k2->launch != nullptr && k2->fs_groups_per_wg > 0) s2.gpw = k2->fs_groups_per_wg;
+    stage s3 = make_strided_stage(k3, count * n1 * n2, n1, BUF_SCRATCH, a3_in, BUF_OUT, a3_out, scale, backward, 0, false);
+    {  // groups of t adjacent k1 for every (b, k2): t * n3 contiguous elements in, X[k1 + n1 * k2 + n1 * n2 * k3] out
+      strided_args& a = s3.sa;
+      a.outer_lo = n2;
+      a.in_tile_shift = sh;
+      a.in_stride = static_cast<unsigned>(t * t);
+      a.in_fdist = static_cast<unsigned>(t);
+      a.in_gdist = static_cast<long long>(t) * M;
+      a.in_dist_outer = static_cast<long long>(t) * n3;
+      a.in_dist_outer_hi = n;
+      a.out_dist_outer = n1;
+      a.out_dist_outer_hi = n;
+    }
+    s3.tiled_in = 1;
+    s3.chunk_group = group_id;
+    s3.chunk_batches = chunk;
+    s3.ffts_per_batch = n1 * n2;
+    s3.in_batch_dist = 0;
+    s3.out_batch_dist = n;
+    if (k3->fs_groups_per_wg > 0) s3.gpw = k3->fs_groups_per_wg;
+    regrid_for_chunk(s2, std::min(chunk, count) * n1 * n3);
+    regrid_for_chunk(s3, std::min(chunk, count) * n1 * n2);
+    out.push_back(s2);
+    out.push_back(s3);
+    if (info != nullptr) {
+      info->tier = PFFT_TIER_GLOBAL;
+      info->n_factors = 3;
+      info->factors[0] = static_cast<int>(n1);
+      info->factors[1] = static_cast<int>(n2);
+      info->factors[2] = static_cast<int>(n3);
+      info->workgroup_size = k3->wg;
+      info->ffts_per_workgroup = k3->fpw;
+      info->lds_bytes = std::max(k1->lds_bytes, std::max(k2->lds_bytes, k3->lds_bytes));
+    }
+    return true;
+  }
+
   int plan_1d(std::vector<stage>& out, long long n, long long count, long long inner_count, int in_buf,
               const addressing& ia, int out_buf, const addressing& oa, bool packed_io, double scale, int backward,
               pfft_dim_info_t* info) {
@@ -1138,6 +1282,10 @@ struct plan_t {
       fail(PFFT_UNSUPPORTED_CONFIGURATION, "FFT size ", n,
            " needs the multi-kernel (global) implementation, which is only supported for 1-D transforms in the "
            "default (packed) layout");
+    }
+    if (interleaved && in_buf == BUF_IN && out_buf == BUF_OUT &&
+        plan_three_stage(out, n, count, ia, oa, scale, backward, info)) {
+      return PFFT_TIER_GLOBAL;
     }
     const long long gmax = generic_max_n();
     long long n1 = 0;

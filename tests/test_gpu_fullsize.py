@@ -402,6 +402,76 @@ def test_four_step_stage_pairs_and_split_storage():
 
 
 @pytest.mark.gpu
+def test_three_stage_plan_for_very_long_transforms():
+    """N >= 2^23 (plan.cpp plan_three_stage): N = n1 * n2 * n3, the four-step applied twice -- S1 in place on the user's
+    output buffer, S2 into tiles of the scratch, S3 (tiled-input stage B of n3 = 1024) to X[k1 + n1 k2 + n1 n2 k3];
+    S2 / S3 chunk by chunk.  Factors through the plan info; against NumPy, round trip, in-place execution, a ragged last
+    chunk, and the two-stage plan of the same descriptor (PFFT_NO_THREE_STAGE=1).  Also forced on a shorter length
+    (PFFT_THREE_STAGE_MIN) so that a batch of several chunks stays small."""
+    G, pf, torch = _mods()
+
+    def commit(n, prec, batch, env=None, placement=None):
+        old = {k: os.environ.get(k) for k in (env or {})}
+        os.environ.update(env or {})
+        try:
+            d = G.make_descriptor([n], prec, batch=batch)
+            if placement is not None:
+                d.placement = placement
+            return d.commit()
+        finally:
+            for k, v in old.items():
+                if v is None:
+                    del os.environ[k]
+                else:
+                    os.environ[k] = v
+
+    cases = [  # (n, prec, batch, factors, env)
+        (1 << 23, "f32", 2, [64, 128, 1024], None), (3 << 22, "f32", 1, None, None), (1 << 24, "f32", 3, [128, 128, 1024], None),
+        (1 << 25, "f32", 1, [128, 256, 1024], None), (1 << 23, "f64", 1, [64, 128, 1024], None),
+        (1 << 22, "f32", 5, [64, 64, 1024], {"PFFT_THREE_STAGE_MIN": "4194304", "PFFT_CACHE_CHUNK_MIB": "64"}),
+        (5 << 20, "f64", 3, None, {"PFFT_THREE_STAGE_MIN": "4194304", "PFFT_CACHE_CHUNK_MIB": "96"}),
+    ]
+    for n, prec, batch, factors, env in cases:
+        cdt = torch.complex64 if prec == "f32" else torch.complex128
+        tol = H.REL_L2_TOL[np.dtype(np.complex64 if prec == "f32" else np.complex128)]
+        g = torch.Generator(device="cuda").manual_seed(n % 1000 + batch)
+        x = torch.empty(batch * n, dtype=cdt, device="cuda")
+        torch.view_as_real(x).uniform_(-1, 1, generator=g)
+        plan = commit(n, prec, batch, env)
+        d0 = plan.info().dims[0]
+        assert d0.tier == 3 and d0.n_factors == 3, (n, prec, d0.n_factors)
+        if factors is not None:
+            assert list(d0.factors[:3]) == factors, (n, prec, list(d0.factors[:3]))
+        y = torch.empty_like(x)
+        plan.compute_forward(x, y).wait()
+        for b in sorted({0, batch - 1}):
+            ref = np.fft.fft(x.view(batch, n)[b].cpu().numpy().astype(np.complex128))
+            assert H.rel_l2(y.view(batch, n)[b].cpu().numpy(), ref) <= tol, (n, prec, batch, b)
+            del ref
+        z = torch.empty_like(x)
+        plan.compute_backward(y, z).wait()
+        err = float(((z / n - x).abs().double().pow(2).sum() / x.abs().double().pow(2).sum()).sqrt())
+        assert err <= tol, (n, prec, batch, "round trip", err)
+        del z
+        y0 = torch.empty_like(x)
+        e2 = dict(env or {})
+        e2["PFFT_NO_THREE_STAGE"] = "1"
+        plan2 = commit(n, prec, batch, e2)
+        assert plan2.info().dims[0].n_factors == 2
+        plan2.compute_forward(x, y0).wait()
+        diff = float(((y - y0).abs().double().pow(2).sum() / y0.abs().double().pow(2).sum()).sqrt())
+        assert diff <= tol, (n, prec, batch, "vs the two-stage plan", diff)
+        del y0, plan2
+        # in place: S1 works on the user's buffer itself
+        pin = commit(n, prec, batch, env, pf.placement.IN_PLACE)
+        w = x.clone()
+        pin.compute_forward(w).wait()
+        assert torch.equal(w, y), (n, prec, batch, "in place")
+        del w, x, y, plan, pin
+        torch.cuda.empty_cache()
+
+
+@pytest.mark.gpu
 def test_four_step_half_pairs_and_split_choice():
     """Four-step lengths k * 2^m (plan.cpp, half pairs): the split takes a registered stage-B length (1024 / 512 / 256)
     as n2 and a SHORT runtime-specialised stage A of the same group width as n1 -- factors checked through the plan

@@ -45,7 +45,8 @@ def main():
                                 6 << 15, 10 << 13, 100000, 1000000, 60000, 37 << 12, 61 << 10, 9 * 5 * 7 * 11 * 13 * 16, 49152,
                                 # k * 2^m: a registered stage B behind a runtime-specialised stage A (plan.cpp, half pairs)
                                 3 << 13, 5 << 13, 7 << 14, 3 << 16, 5 << 15, 9 << 16, 15 << 15, 11 << 13, 3 << 18,
-                                5 << 17, 3 << 20, 12288, 20480, 13 << 12, 25 << 12, 3 << 19, 5 << 18])]
+                                5 << 17, 3 << 20, 12288, 20480, 13 << 12, 25 << 12, 3 << 19, 5 << 18,
+                                1 << 23, 3 << 22])]  # (three-stage plan)
         elif rank == 1:
             dims = [smooth(rng, rng.choice([2, 20, 300, 3000]), rng.choice([64, 2000, 20000, 200000]))]
         else:
