@@ -428,6 +428,7 @@ def test_three_stage_plan_for_very_long_transforms():
     cases = [  # (n, prec, batch, factors, env)
         (1 << 23, "f32", 2, [64, 128, 1024], None), (3 << 22, "f32", 1, None, None), (1 << 24, "f32", 3, [128, 128, 1024], None),
         (1 << 25, "f32", 1, [128, 256, 1024], None), (1 << 23, "f64", 1, [64, 128, 1024], None),
+        (1 << 27, "f32", 1, [256, 512, 1024], None),  # (no two-stage plan exists for this length)
         (1 << 22, "f32", 5, [64, 64, 1024], {"PFFT_THREE_STAGE_MIN": "4194304", "PFFT_CACHE_CHUNK_MIB": "64"}),
         (5 << 20, "f64", 3, None, {"PFFT_THREE_STAGE_MIN": "4194304", "PFFT_CACHE_CHUNK_MIB": "96"}),
     ]
@@ -456,11 +457,16 @@ def test_three_stage_plan_for_very_long_transforms():
         y0 = torch.empty_like(x)
         e2 = dict(env or {})
         e2["PFFT_NO_THREE_STAGE"] = "1"
-        plan2 = commit(n, prec, batch, e2)
-        assert plan2.info().dims[0].n_factors == 2
-        plan2.compute_forward(x, y0).wait()
-        diff = float(((y - y0).abs().double().pow(2).sum() / y0.abs().double().pow(2).sum()).sqrt())
-        assert diff <= tol, (n, prec, batch, "vs the two-stage plan", diff)
+        try:
+            plan2 = commit(n, prec, batch, e2)
+        except pf.unsupported_configuration:
+            plan2 = None
+            assert n >= 1 << 27
+        if plan2 is not None:
+            assert plan2.info().dims[0].n_factors == 2
+            plan2.compute_forward(x, y0).wait()
+            diff = float(((y - y0).abs().double().pow(2).sum() / y0.abs().double().pow(2).sum()).sqrt())
+            assert diff <= tol, (n, prec, batch, "vs the two-stage plan", diff)
         del y0, plan2
         # in place: S1 works on the user's buffer itself
         pin = commit(n, prec, batch, env, pf.placement.IN_PLACE)

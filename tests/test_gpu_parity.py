@@ -277,7 +277,7 @@ def test_maximum_sizes():
     with pytest.raises(pf.unsupported_configuration):
         G.make_descriptor([67 * 64]).commit()  # prime factor beyond the wavefront size (test_wave64_prime_factors)
     with pytest.raises(pf.unsupported_configuration):
-        G.make_descriptor([1 << 28]).commit()  # longer than (LDS/2 elements)^2
+        G.make_descriptor([1 << 29]).commit()  # beyond the 32-bit byte offsets of one transform (2^28 runs: three stages)
 
 
 @pytest.mark.gpu
