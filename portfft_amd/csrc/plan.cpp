@@ -1035,7 +1035,7 @@ struct plan_t {
   }
 
   /// Plan `count` 1-D FFTs of length n.  Returns the tier used.
-  /// Three-stage plan of the GLOBAL tier for lengths whose two-factor split needs a factor above 2048 (N >= 2^23: n = 4096
+  /// Three-stage plan of the GLOBAL tier for lengths whose two-factor split needs a factor above 2048 (N > 2^22: n = 4096
   /// holds 4 fp32 columns -- 32-byte segments, 0.11 of peak at N = 2^23, 0.086 at 2^24): N = n1 * n2 * n3, the four-step
   /// applied twice (reference: global_dispatcher.hpp:343-408 runs one kernel per factor of an arbitrary factor list).
   ///   S1  n1-point FFTs over stride n2 * n3 for every column c of [0, n2 * n3), x W_N^(k1 * c)        user in -> user out
@@ -1052,7 +1052,7 @@ struct plan_t {
         getenv("PFFT_NO_TILED_LANES") != nullptr) {
       return false;
     }
-    long long min_n = 1ll << 23;
+    long long min_n = (1ll << 22) + 1;  // beyond 2048 x 2048 a two-factor split needs n > 2048 (5 * 2^20: 0.121 against 0.222)
     if (const char* e = getenv("PFFT_THREE_STAGE_MIN")) min_n = std::atoll(e);  // experiments
     if (n < min_n || static_cast<unsigned long long>(n) * elem_bytes() >= 0xFFFFFFF0ull) return false;
     const size_t per_transform = static_cast<size_t>(n) * elem_bytes();
