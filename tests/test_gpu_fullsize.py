@@ -403,7 +403,7 @@ def test_four_step_stage_pairs_and_split_storage():
 
 @pytest.mark.gpu
 def test_three_stage_plan_for_very_long_transforms():
-    """N >= 2^23 (plan.cpp plan_three_stage): N = n1 * n2 * n3, the four-step applied twice -- S1 in place on the user's
+    """N > 2^22 (plan.cpp plan_three_stage): N = n1 * n2 * n3, the four-step applied twice -- S1 in place on the user's
     output buffer, S2 into tiles of the scratch, S3 (tiled-input stage B of n3 = 1024) to X[k1 + n1 k2 + n1 n2 k3];
     S2 / S3 chunk by chunk.  Factors through the plan info; against NumPy, round trip, in-place execution, a ragged last
     chunk, and the two-stage plan of the same descriptor (PFFT_NO_THREE_STAGE=1).  Also forced on a shorter length
@@ -426,7 +426,7 @@ def test_three_stage_plan_for_very_long_transforms():
                     os.environ[k] = v
 
     cases = [  # (n, prec, batch, factors, env)
-        (1 << 23, "f32", 2, [64, 128, 1024], None), (3 << 22, "f32", 1, None, None), (1 << 24, "f32", 3, [128, 128, 1024], None),
+        (1 << 23, "f32", 2, [64, 128, 1024], None), (3 << 22, "f32", 1, None, None), (5 << 20, "f32", 3, None, None), (1 << 24, "f32", 3, [128, 128, 1024], None),
         (1 << 25, "f32", 1, [128, 256, 1024], None), (1 << 23, "f64", 1, [64, 128, 1024], None),
         (1 << 27, "f32", 1, [256, 512, 1024], None),  # (no two-stage plan exists for this length)
         (1 << 22, "f32", 5, [64, 64, 1024], {"PFFT_THREE_STAGE_MIN": "4194304", "PFFT_CACHE_CHUNK_MIB": "64"}),
