@@ -1062,8 +1062,13 @@ struct plan_t {
     const strided_kernel* k3 = nullptr;
     long long n3 = 0;
     int t = 0;
-    for (long long len : {1024ll, 512ll, 256ll}) {
-      if (n % len != 0) continue;
+    // fp32 up to 2^25: n3 = 256 first (all three stages on short kernels, several work-groups per CU: 2^23 0.232 -> 0.239,
+    // 2^24 0.228 -> 0.237, 5 * 2^20 0.222 -> 0.233); fp64 and longer transforms: n3 = 1024 first (fp64 2^23 0.233 / 0.231, 2^26 equal)
+    const long long want_n3 = getenv("PFFT_THREE_STAGE_N3") != nullptr ? std::atoll(getenv("PFFT_THREE_STAGE_N3")) : 0;
+    const bool short_first = desc.precision == PFFT_PRECISION_F32 && n <= (1ll << 25);
+    const long long order[3] = {short_first ? 256ll : 1024ll, 512ll, short_first ? 1024ll : 256ll};
+    for (long long len : order) {
+      if (n % len != 0 || (want_n3 != 0 && len != want_n3)) continue;  // (PFFT_THREE_STAGE_N3: experiments)
       const strided_kernel* fb = find_strided(len, false, false, -1, cached ? 2 : 0, false, 2, false);
       if (fb == nullptr) continue;
       const int tt = pair_tile(fb, len, false);

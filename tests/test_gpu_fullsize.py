@@ -426,10 +426,10 @@ def test_three_stage_plan_for_very_long_transforms():
                     os.environ[k] = v
 
     cases = [  # (n, prec, batch, factors, env)
-        (1 << 23, "f32", 2, [64, 128, 1024], None), (3 << 22, "f32", 1, None, None), (5 << 20, "f32", 3, None, None), (1 << 24, "f32", 3, [128, 128, 1024], None),
-        (1 << 25, "f32", 1, [128, 256, 1024], None), (1 << 23, "f64", 1, [64, 128, 1024], None),
+        (1 << 23, "f32", 2, [128, 256, 256], None), (3 << 22, "f32", 1, None, None), (5 << 20, "f32", 3, None, None), (1 << 24, "f32", 3, [256, 256, 256], None),
+        (1 << 25, "f32", 1, [256, 512, 256], None), (1 << 23, "f64", 1, [64, 128, 1024], None),
         (1 << 27, "f32", 1, [256, 512, 1024], None),  # (no two-stage plan exists for this length)
-        (1 << 22, "f32", 5, [64, 64, 1024], {"PFFT_THREE_STAGE_MIN": "4194304", "PFFT_CACHE_CHUNK_MIB": "64"}),
+        (1 << 22, "f32", 5, [128, 128, 256], {"PFFT_THREE_STAGE_MIN": "4194304", "PFFT_CACHE_CHUNK_MIB": "64"}),
         (5 << 20, "f64", 3, None, {"PFFT_THREE_STAGE_MIN": "4194304", "PFFT_CACHE_CHUNK_MIB": "96"}),
     ]
     for n, prec, batch, factors, env in cases:
