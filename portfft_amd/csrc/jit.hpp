@@ -120,7 +120,7 @@ hipError_t jit_launch_spec_split(const spec_kernel* k, hipStream_t stream, unsig
 hipError_t jit_launch_strided(const strided_kernel* k, hipStream_t stream, unsigned grid, const strided_args& args,
                               int backward, int store_modifier);
 hipError_t jit_launch_strided_split(const strided_kernel* k, hipStream_t stream, unsigned grid,
-                                    const strided_args& args, int backward);
+                                    const strided_args& args, int backward, int store_modifier = 0);
 /// Make the row-staged form (stockham_strided_row_kernel; fp32, interleaved, no store modifier) of a
 /// runtime-compiled strided entry available: row_out 0 = row-shaped input, 1 = row-shaped output.
 /// split_mode 3 (row_out 0): the row-staged input form of the mixed stage B (interleaved scratch -> split planes),

@@ -69,6 +69,8 @@ struct strided_kernel {
   /// runtime-compiled entries (jit.cpp): mfn[backward * 2 + store_modifier], mfn_split[backward]
   hipFunction_t mfn[4];
   hipFunction_t mfn_split[2];
+  /// ... with the store modifier on SPLIT_COMPLEX user planes on both sides (S1 of the three-stage plan): [backward]
+  hipFunction_t mfn_split_stw[2];
   /// mixed storage for the four-step tier on SPLIT_COMPLEX data: [backward] split input -> interleaved scratch with
   /// store modifier (stage A), [2 + backward] interleaved scratch -> split output (stage B)
   hipFunction_t mfn_mixed[4];

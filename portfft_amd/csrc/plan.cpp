@@ -757,7 +757,7 @@ struct plan_t {
                                k->wg, k->lds_bytes_row, groups, 1);
     } else if (k->launch == nullptr) {  // runtime-compiled: whichever variant this stage will launch
       const bool split_storage = desc.complex_storage == PFFT_SPLIT_COMPLEX;
-      hipFunction_t f = user_split ? k->mfn_split[backward] : k->mfn[backward * 2];
+      hipFunction_t f = user_split ? (store_modifier ? k->mfn_split_stw[backward] : k->mfn_split[backward]) : k->mfn[backward * 2];
       if (split_storage && (in_buf == BUF_SCRATCH) != (out_buf == BUF_SCRATCH)) {
         f = k->mfn_mixed[(in_buf == BUF_SCRATCH ? 2 : 0) + backward];
       }
@@ -1058,6 +1058,10 @@ struct plan_t {
     const size_t per_transform = static_cast<size_t>(n) * elem_bytes();
     const bool cached = cache_chunk_bytes() >= per_transform &&
                         per_transform * static_cast<size_t>(count) >= cache_chunk_bytes() / 2;
+    // SPLIT_COMPLEX user planes: the same three stages on runtime-specialised kernels -- S1 planes -> planes (in place on
+    // the output planes), S2 planes -> interleaved scratch tiles, S3 tiles -> planes (mixed-storage forms, jit.cpp)
+    const bool split = desc.complex_storage == PFFT_SPLIT_COMPLEX;
+    if (split && !jit_enabled()) return false;
     // S3: a registered stage-B entry with whole-line groups and square tiles
     const strided_kernel* k3 = nullptr;
     long long n3 = 0;
@@ -1069,6 +1073,18 @@ struct plan_t {
     const long long order[3] = {short_first ? 256ll : 1024ll, 512ll, short_first ? 1024ll : 256ll};
     for (long long len : order) {
       if (n % len != 0 || (want_n3 != 0 && len != want_n3)) continue;  // (PFFT_THREE_STAGE_N3: experiments)
+      if (split) {
+        std::string why;
+        const strided_kernel* fb = jit_strided_kernel(desc.precision, len, 1024, false, 3, max_lds, &why, false, cached ? 2 : 0);
+        if (fb == nullptr || fb->n_radices < 2 || (fb->fpw & (fb->fpw - 1)) != 0 || len % fb->fpw != 0 ||
+            (len / fb->radices[0]) % fb->fpw != 0 || !jit_strided_ensure_mixed_tin(fb, &why)) {
+          continue;
+        }
+        k3 = fb;
+        n3 = len;
+        t = fb->fpw;
+        break;
+      }
       const strided_kernel* fb = find_strided(len, false, false, -1, cached ? 2 : 0, false, 2, false);
       if (fb == nullptr) continue;
       const int tt = pair_tile(fb, len, false);
@@ -1088,7 +1104,8 @@ struct plan_t {
       if (m12 % c != 0 || c % t != 0) continue;
       const long long c2 = m12 / c;
       if (c2 > 2048 || strided_fpw(c, c2 * n3) <= 0) continue;
-      if (const strided_kernel* fa = find_strided(c2, false, false, -1, cached ? 1 : 0, true, 1)) {
+      const strided_kernel* fa = split ? nullptr : find_strided(c2, false, false, -1, cached ? 1 : 0, true, 1);
+      if (fa != nullptr) {
         if (fa->fpw != t) continue;
         k2 = fa;
         k2_jit = false;
@@ -1107,10 +1124,17 @@ struct plan_t {
     const long long n2 = m12 / n1, M = n2 * n3;
     if (k2_jit) {
       std::string why;
-      k2 = jit_strided_kernel(desc.precision, n2, n3, true, 0, max_lds, &why, false, cached ? 1 : 0, t);
+      k2 = jit_strided_kernel(desc.precision, n2, n3, true, split ? 2 : 0, max_lds, &why, false, cached ? 1 : 0, t);
       if (k2 == nullptr || k2->fpw != t) return false;
     }
-    const strided_kernel* k1 = get_strided(n1, M, true, false, false, false, 0);
+    const strided_kernel* k1 = nullptr;
+    if (split) {
+      std::string why;
+      k1 = jit_strided_kernel(desc.precision, n1, M, true, 1, max_lds, &why);
+      if (k1 == nullptr || k1->n_radices < 2) return false;
+    } else {
+      k1 = get_strided(n1, M, true, false, false, false, 0);
+    }
     int sh = 0;
     while ((1 << sh) < t) ++sh;
     const addressing a1_in{ia.offset, M, 1, n}, a1_out{oa.offset, M, 1, n};
@@ -1288,8 +1312,7 @@ struct plan_t {
            " needs the multi-kernel (global) implementation, which is only supported for 1-D transforms in the "
            "default (packed) layout");
     }
-    if (interleaved && in_buf == BUF_IN && out_buf == BUF_OUT &&
-        plan_three_stage(out, n, count, ia, oa, scale, backward, info)) {
+    if (in_buf == BUF_IN && out_buf == BUF_OUT && plan_three_stage(out, n, count, ia, oa, scale, backward, info)) {
       return PFFT_TIER_GLOBAL;
     }
     const long long gmax = generic_max_n();
@@ -1946,7 +1969,7 @@ struct plan_t {
         a.out = const_cast<char*>(base_re(s.out_buf, false)) + oo;
         a.out_im = const_cast<char*>(base_im(s.out_buf)) + oo;
         hip_check(s.strided->launch != nullptr ? s.strided->launch_split(stream, grid, a, s.backward)
-                                               : jit_launch_strided_split(s.strided, stream, grid, a, s.backward),
+                                               : jit_launch_strided_split(s.strided, stream, grid, a, s.backward, s.store_modifier),
                   "kernel launch");
         return;
       }

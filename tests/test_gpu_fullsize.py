@@ -478,6 +478,66 @@ def test_three_stage_plan_for_very_long_transforms():
 
 
 @pytest.mark.gpu
+def test_three_stage_plan_split_storage():
+    """The three-stage plan on SPLIT_COMPLEX data (runtime-specialised kernels on all three stages: planes -> planes with
+    the store modifier in place on the output planes, planes -> interleaved scratch tiles, tiles -> planes): against NumPy,
+    round trip, in place, and the two-stage plan of the same descriptor."""
+    G, pf, torch = _mods()
+
+    def commit(n, prec, batch, env=None, placement=None):
+        old = {k: os.environ.get(k) for k in (env or {})}
+        os.environ.update(env or {})
+        try:
+            d = G.make_descriptor([n], prec, batch=batch, storage=1)
+            if placement is not None:
+                d.placement = placement
+            return d.commit()
+        finally:
+            for k, v in old.items():
+                if v is None:
+                    del os.environ[k]
+                else:
+                    os.environ[k] = v
+
+    for n, prec, batch in ((1 << 23, "f32", 3), (5 << 20, "f64", 2), (3 << 22, "f32", 1)):
+        rdt = torch.float32 if prec == "f32" else torch.float64
+        tol = H.REL_L2_TOL[np.dtype(np.complex64 if prec == "f32" else np.complex128)]
+        g = torch.Generator(device="cuda").manual_seed(n % 1000 + batch)
+        re = torch.empty(batch * n, dtype=rdt, device="cuda").uniform_(-1, 1, generator=g)
+        im = torch.empty(batch * n, dtype=rdt, device="cuda").uniform_(-1, 1, generator=g)
+        plan = commit(n, prec, batch)
+        assert plan.info().dims[0].tier == 3 and plan.info().dims[0].n_factors == 3, (n, prec)
+        ore, oim = torch.empty_like(re), torch.empty_like(im)
+        plan.compute_forward(re, im, ore, oim).wait()
+        for b in sorted({0, batch - 1}):
+            x = re.view(batch, n)[b].cpu().numpy().astype(np.float64) + 1j * im.view(batch, n)[b].cpu().numpy().astype(np.float64)
+            ref = np.fft.fft(x)
+            got = ore.view(batch, n)[b].cpu().numpy() + 1j * oim.view(batch, n)[b].cpu().numpy()
+            assert H.rel_l2(got, ref) <= tol, (n, prec, batch, b)
+            del x, ref, got
+        zre, zim = torch.empty_like(re), torch.empty_like(im)
+        plan.compute_backward(ore, oim, zre, zim).wait()
+        num = ((zre / n - re).double().pow(2).sum() + (zim / n - im).double().pow(2).sum()).sqrt()
+        den = (re.double().pow(2).sum() + im.double().pow(2).sum()).sqrt()
+        assert float(num / den) <= tol, (n, prec, batch, "round trip")
+        del zre, zim
+        plan2 = commit(n, prec, batch, {"PFFT_NO_THREE_STAGE": "1"})
+        assert plan2.info().dims[0].n_factors == 2
+        o2re, o2im = torch.empty_like(re), torch.empty_like(im)
+        plan2.compute_forward(re, im, o2re, o2im).wait()
+        num = ((ore - o2re).double().pow(2).sum() + (oim - o2im).double().pow(2).sum()).sqrt()
+        den = (o2re.double().pow(2).sum() + o2im.double().pow(2).sum()).sqrt()
+        assert float(num / den) <= tol, (n, prec, batch, "vs the two-stage plan")
+        del o2re, o2im, plan2
+        pin = commit(n, prec, batch, None, pf.placement.IN_PLACE)
+        wre, wim = re.clone(), im.clone()
+        pin.compute_forward(wre, wim).wait()
+        assert torch.equal(wre, ore) and torch.equal(wim, oim), (n, prec, batch, "in place")
+        del wre, wim, re, im, ore, oim, plan, pin
+        torch.cuda.empty_cache()
+
+
+@pytest.mark.gpu
 def test_four_step_half_pairs_and_split_choice():
     """Four-step lengths k * 2^m (plan.cpp, half pairs): the split takes a registered stage-B length (1024 / 512 / 256)
     as n2 and a SHORT runtime-specialised stage A of the same group width as n1 -- factors checked through the plan

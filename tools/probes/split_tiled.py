@@ -36,8 +36,8 @@ if len(sys.argv) > 1:
     cases = [(a.split(":")[0], int(a.split(":")[1])) for a in sys.argv[1:]]
 for prec, n in cases:
     batch = max(1, ((128 << 20) if prec == "f32" else (64 << 20)) // n)
-    for env in ({}, {"PFFT_NO_SPLIT_TILED": "1"}):
+    for env in ({}, dict(kv.split("=") for kv in os.environ.get("AB_ENV", "PFFT_NO_SPLIT_TILED=1").split(","))):
         p = subprocess.run([sys.executable, "-c", CHILD, prec, str(n), str(batch)], env=dict(os.environ, **env),
                            capture_output=True, text=True)
         out = [l for l in p.stdout.splitlines() if "N=" in l]
-        print(("   round-3 plan: " if env else "") + (out[-1] if out else "FAILED: " + p.stderr[-600:]), flush=True)
+        print(("   %s: " % ",".join("%s=%s" % kv for kv in env.items()) if env else "") + (out[-1] if out else "FAILED: " + p.stderr[-600:]), flush=True)
