@@ -1350,9 +1350,9 @@ struct plan_t {
     // 0.370, 128 x 1024 0.357; in fp64 n1 = 128 still wins: 2^16 0.386 against 0.371, 2^17 0.378 against 0.356).  So: the
     // smallest n1 >= 160 (fp64: 128) that pairs, else the largest below.  A registered length without a stage-A entry
     // of stage B's width (n1 = 128, 64) gets a runtime-specialised stage A like any other (2^15 as 128 x 256 with it
-    // 0.375, on the registered 32-column entry 0.358; fp64 0.396 / 0.370).  Entries with groups narrower than a
-    // 128-byte line (fp32 n = 2048) are taken only when the balanced split itself lands on them (5 * 2^18 as 640 x 2048:
-    // 0.224 against 0.242).
+    // 0.375, on the registered 32-column entry 0.358; fp64 0.396 / 0.370).  A stage A narrower than a 128-byte line
+    // never comes out of this search (5 * 2^18 as 640 x 2048 on 8 columns: 0.224 against 0.242), and stage-B entries whose
+    // own output segments are that narrow (n2 = 2048 -- their tiles may still be a line wide, pair_tile) rank last.
     if (desc.complex_storage == PFFT_INTERLEAVED_COMPLEX && jit_enabled() && getenv("PFFT_GLOBAL_N1") == nullptr &&
         getenv("PFFT_NO_FS_PAIRS") == nullptr && getenv("PFFT_NO_HALF_PAIRS") == nullptr &&
         getenv("PFFT_NO_TILED_SCRATCH") == nullptr && getenv("PFFT_NO_TILED_LANES") == nullptr &&
