@@ -140,7 +140,9 @@ hipError_t jit_launch_strided_mixed(const strided_kernel* k, hipStream_t stream,
 
 /// Compile (do not load) the forward + backward kernels of `p` for `arch`: needs no device, used by the build check
 /// and the CPU tests.  kind 0: packed interleaved, 1: packed split, 2: strided, 3: strided with store modifier,
-/// 4: first pass of the two-pass 2-D plan (p from choose_rows2d_params).
+/// 4: first pass of the two-pass 2-D plan (p from choose_rows2d_params), 5: strided on split planes with the store
+/// modifier (S1 of the three-stage plan), 6: mixed stage B (interleaved tiles -> planes) in its tiled-input form,
+/// 7: interleaved tiled-input form (p must satisfy tin_supported: a half-pair stage B is registered, this is its template).
 bool jit_compile_only(const wg_params& p, int kind, const char* arch, size_t* code_bytes, std::string* why);
 bool jit_compile_only_nd(const nd_kernel& p, bool split, const char* arch, size_t* code_bytes, std::string* why);
 

@@ -109,12 +109,15 @@ int main(int argc, char** argv) {
   }
   if (argc > 1 && std::string(argv[1]) == "compile") {
     struct { int prec; long long n; int kind; } cases[] = {{0, 1200, 0}, {1, 625, 1}, {0, 30, 0}, {0, 120, 2}, {1, 250, 3},
-                                                            {0, 1000, 4}, {1, 768, 4}};
+                                                            {0, 1000, 4}, {1, 768, 4},
+                                                            // forms of the three-stage / tiled plans that exist only at run time
+                                                            {0, 128, 5}, {1, 1024, 6}, {0, 1024, 7}};
     for (auto& c : cases) {
       pfa::wg_params q;
       const bool ok = c.kind < 2 ? pfa::choose_spec_params(c.prec, c.n, max_lds, &q)
                       : c.kind == 4 ? pfa::choose_rows2d_params(c.prec, c.n, 1200, max_lds, &q)
-                                    : pfa::choose_strided_params(c.prec, c.n, 1024, max_lds, &q);
+                                    : pfa::choose_strided_params(c.prec, c.n, 1024, max_lds, &q, false,
+                                                                 c.kind >= 6 ? (c.prec ? 8 : 16) : 0);
       EXPECT(ok, "plan %lld", c.n);
       size_t bytes = 0;
       std::string why;
