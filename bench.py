@@ -52,7 +52,9 @@ WORKLOADS = {
     "g32_17": ([131072], 1024, "f32", "fp32 four-step N=131072 batch=1Ki (reference GlobalTest size)", 2),
     "g32_18": ([1 << 18], 512, "f32", "fp32 four-step N=2^18 batch=512", 2),
     "g32_20": ([1 << 20], 128, "f32", "fp32 four-step N=2^20 batch=128", 2),
+    "g32_21": ([1 << 21], 64, "f32", "fp32 four-step N=2^21 batch=64 (stage B reads tiles twice its group width)", 2),
     "g32_22": ([1 << 22], 32, "f32", "fp32 four-step N=2^22 batch=32", 2),
+    "g32_24": ([1 << 24], 8, "f32", "fp32 three-stage N=2^24 batch=8", 3),
     "g64_16": ([65536], 1024, "f64", "fp64 four-step N=65536 batch=1Ki (reference GlobalTest size)", 2),
 }
 
@@ -403,7 +405,9 @@ def main():
                              "frac_of_copy": round(achieved / (alg_bytes / (copy_ms * 1e-3) / 1e9), 4)},
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "note": "achieved = algorithmic bytes of one execute / event-timed duration of its launches"
-                                 + (" (two HBM passes: 0.5 is the ceiling)" if launches == 2 else "")},
+                                 + (" (two HBM passes: a plain copy pair of the same access shapes tops out at 0.41-0.44 "
+                                    "of the peak, DESIGN.md section 5)" if launches == 2 else "")
+                                 + (" (three HBM passes)" if launches == 3 else "")},
         }
         if pg.fallback_reason:
             result["config"]["rccl_fallback_reason"] = pg.fallback_reason

@@ -6,7 +6,7 @@ cd "$GRAFT_REPO_ROOT" || exit 1
 export TMPDIR=/tmp
 out=gpurun_out/final_r3; mkdir -p $out
 python bench.py > $out/r3_bench_c2.json 2> $out/c2.err
-for c in c3 c5 ref16 ref256 ref4096 ref65536 g32_15 g32_17 g32_18 g32_20 g32_22 g64_16; do
+for c in c3 c5 ref16 ref256 ref4096 ref65536 g32_15 g32_17 g32_18 g32_20 g32_21 g32_22 g32_24 g64_16; do
   python bench.py --config $c --no-cpu-baseline > $out/r3_bench_$c.json 2> $out/$c.err
 done
 for c in c2 c3 c5 ref65536 g32_15 g32_17 g32_18 g32_20 g32_22 g64_16; do
