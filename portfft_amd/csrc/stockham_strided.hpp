@@ -388,7 +388,8 @@ PFA_DEV long long strided_ngroups(const strided_args& a) {
 template <typename Cfg, int SPLIT>
 PFA_DEV strided_io<typename Cfg::T, Cfg::AUX, SPLIT> strided_group(const strided_args& a, long long g, unsigned f,
                                                                    bool* live, long long* c0_out,
-                                                                   long long* nlive_out = nullptr) {
+                                                                   long long* nlive_out = nullptr,
+                                                                   long long in_base = 0, long long out_base = 0) {
   using T = typename Cfg::T;
   using IO = strided_io<T, Cfg::AUX, SPLIT>;
   constexpr unsigned ES_IN = IO::ES_IN, ES_OUT = IO::ES_OUT;
@@ -411,8 +412,9 @@ PFA_DEV strided_io<typename Cfg::T, Cfg::AUX, SPLIT> strided_group(const strided
     obase_in = ohi * a.in_dist_outer_hi + olo * a.in_dist_outer;
     obase_out = ohi * a.out_dist_outer_hi + olo * a.out_dist_outer;
   }
-  const long long ioff = obase_in + (a.in_gdist != 0 ? gw * a.in_gdist : c0 * a.in_fdist);
-  const long long ooff = obase_out + (a.out_gdist != 0 ? gw * a.out_gdist : c0 * a.out_fdist);
+  // (in_base / out_base: the XCD-local four-step kernel places the scratch side of a group in a slot of its own choice)
+  const long long ioff = in_base + obase_in + (a.in_gdist != 0 ? gw * a.in_gdist : c0 * a.in_fdist);
+  const long long ooff = out_base + obase_out + (a.out_gdist != 0 ? gw * a.out_gdist : c0 * a.out_fdist);
   // ranges: last element of the last FFT of the group (the planner guarantees < 4 GiB)
   const unsigned in_bytes = (static_cast<unsigned>(Cfg::FPW - 1) * a.in_fdist +
                              (static_cast<unsigned>(Cfg::N - 1) >> a.in_tile_shift) * a.in_stride +
