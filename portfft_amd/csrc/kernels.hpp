@@ -14,6 +14,7 @@
 
 #include "generic_args.hpp"
 #include "strided_args.hpp"
+#include "xcd_args.hpp"
 
 namespace pfa {
 
@@ -136,6 +137,23 @@ struct rows2d_kernel {
   int split;  // runtime-compiled entries: mfn are the split-storage forms
 };
 const rows2d_kernel* rows2d_kernels(int* count);
+
+/// XCD-local four-step kernel (stockham_xcd.hpp): both stages of an n1 x n2 transform in one persistent launch
+struct xcd_kernel {
+  int precision;
+  int n1, n2;
+  int wg, fpw;
+  size_t lds_bytes;  // the stage configuration's own (image + leading twiddle tables); the launch adds the
+                     // store-modifier tables and XCD_LDS_CTL_BYTES of control words
+  int n_radices;
+  int radices[8];
+  const void* fn[2];  // [backward]
+  hipError_t (*launch)(hipStream_t stream, unsigned grid, size_t lds, const xcd_args& args, int backward);
+  int slots, lag, lookahead;  // tuned schedule (xcd_args)
+};
+const xcd_kernel* xcd_kernels(int* count);
+/// XCC ids the device hands to work-groups (0: the census failed)
+int xcd_census(hipStream_t stream);
 
 /// AUX template values of the three cache policies (stockham_wg.hpp: loads in bits 0-7, stores + 1 in bits 8-15;
 /// hardware bits 1 = sc0, 2 = nt, 16 = sc1).  The writer's stores carry sc1: written through the XCD's L2 instead of

@@ -61,6 +61,8 @@ struct stage {
   strided_args sa{};
   const rows2d_kernel* rows2d = nullptr;  // first pass of the two-pass 2-D plan (stockham_rows2d.hpp)
   rows2d_args ra{};
+  const xcd_kernel* xcd = nullptr;  // XCD-local four-step launch (stockham_xcd.hpp): both stages of N = n1 x n2
+  xcd_args xa{};
   // two-pass 2-D plan: pass 1 permutes rows between distinct buffers (IN -> OUT), pass 2 works in place on OUT.
   // When the caller's buffers alias (in-place transform) the intermediate goes through scratch instead:
   // 1: this stage writes it (out_buf -> scratch), 2: this stage reads it (in_buf -> scratch)
@@ -226,6 +228,8 @@ struct plan_t {
   void* scratch = nullptr;                                                     // scratch: one per copy
   size_t scratch_bytes = 0;
   size_t twiddle_bytes = 0;
+  void* xcd_ctl = nullptr;        // control block of the XCD-local four-step launch (xcd_args.hpp): one per copy
+  size_t xcd_ctl_bytes = 0;
   void* alias_scratch = nullptr;  // intermediate of the two-pass 2-D plan for aliasing (in-place) executes
   size_t alias_scratch_bytes = 0;
   size_t two_pass_chunk_bytes = 0;  // bytes of one chunk of the two-pass 2-D plan (what an aliasing execute needs)
@@ -265,6 +269,14 @@ struct plan_t {
     for (hipEvent_t e : chunk_events) (void)hipEventDestroy(e);
     if (scratch != nullptr) (void)hipFree(scratch);
     if (alias_scratch != nullptr) (void)hipFree(alias_scratch);
+    if (xcd_ctl != nullptr) (void)hipFree(xcd_ctl);
+  }
+
+  /// the control block of the XCD-local launch: all zero before its first launch (the kernel keeps it that way)
+  void alloc_xcd_ctl() {
+    if (xcd_ctl_bytes == 0 || xcd_ctl != nullptr) return;
+    hip_check(hipMalloc(&xcd_ctl, xcd_ctl_bytes), "hipMalloc(control block)");
+    hip_check(hipMemset(xcd_ctl, 0, xcd_ctl_bytes), "hipMemset(control block)");
   }
 
   void* upload(const void* host, size_t bytes) {
@@ -375,6 +387,15 @@ struct plan_t {
     int levels = 0, shift = 0;
     store_table_shape(k, M, &levels, &shift);
     const size_t extra = (static_cast<size_t>(levels) << shift) * elem_bytes();
+    s.sa.stw_tab = store_tables_for(M, levels, shift);
+    s.sa.stw_levels = levels;
+    s.sa.stw_lshift = shift;
+    const size_t total = k->lds_bytes + extra;
+    finish_store_tables(s, k, total, on_loads);
+  }
+
+  /// device copy of the multi-level tables W_M^(i << (l * shift)), l < levels, i < 2^shift (cached per (M, shift))
+  const void* store_tables_for(long long M, int levels, int shift) {
     auto& slot = store_tables[std::make_pair(M, shift)];
     if (slot == nullptr) {
       const long long per = 1ll << shift;
@@ -395,10 +416,10 @@ struct plan_t {
       };
       slot = desc.precision == PFFT_PRECISION_F64 ? fill(double{}) : fill(float{});
     }
-    s.sa.stw_tab = slot;
-    s.sa.stw_levels = levels;
-    s.sa.stw_lshift = shift;
-    const size_t total = k->lds_bytes + extra;
+    return slot;
+  }
+
+  void finish_store_tables(stage& s, const strided_kernel* k, size_t total, bool on_loads) {
     if (on_loads) {
       for (int d = 0; d < 2; ++d) {
         if (k->fn_tin[d] != nullptr && total > 48 * 1024) {
@@ -1208,6 +1229,145 @@ struct plan_t {
     return true;
   }
 
+  /// XCC ids of the plan's device (census kernel, once per device and process); 0 when the census failed
+  int xcd_queue_count() {
+    static std::mutex m;
+    static std::map<int, int> cache;
+    std::lock_guard<std::mutex> lock(m);
+    auto it = cache.find(device);
+    if (it != cache.end()) return it->second;
+    const int n = xcd_census(stream);
+    cache[device] = n;
+    return n;
+  }
+
+  /// GLOBAL tier, XCD-local form (stockham_xcd.hpp; the reference keeps its batches-in-flight inside the last-level cache,
+  /// committed_descriptor_impl.hpp:603-611, and runs one kernel per factor, dispatcher/global_dispatcher.hpp:343-408):
+  /// N = n1 x n2 with a registered pair runs as ONE persistent launch over the whole batch -- per-XCD task queues, stage
+  /// A of a transform and stage B of an earlier one side by side, the intermediate in per-XCD slot rings.  Taken only for
+  /// the pairs registered in kernels_xcd.hip (where the launch beat the two-launch plan on hardware) and batches that
+  /// fill its pipeline; PFFT_NO_XCD_LOCAL=1 keeps the two-launch plan (A/B twin of the parity tests).
+  bool plan_xcd_local(std::vector<stage>& out, long long n, long long count, const addressing& ia, const addressing& oa,
+                      double scale, int backward, pfft_dim_info_t* info) {
+    if (desc.complex_storage != PFFT_INTERLEAVED_COMPLEX || getenv("PFFT_NO_XCD_LOCAL") != nullptr ||
+        getenv("PFFT_NO_PRECOMPILED") != nullptr || getenv("PFFT_GLOBAL_N1") != nullptr ||
+        getenv("PFFT_DEBUG_GLOBAL") != nullptr) {
+      return false;
+    }
+    int nk = 0;
+    const xcd_kernel* ks = xcd_kernels(&nk);
+    const xcd_kernel* k = nullptr;
+    for (int i = 0; i < nk; ++i) {
+      if (ks[i].precision == desc.precision && static_cast<long long>(ks[i].n1) * ks[i].n2 == n) k = &ks[i];
+    }
+    if (k == nullptr || static_cast<unsigned long long>(n) * elem_bytes() >= 0xFFFFFFF0ull || count >= (1ll << 31)) {
+      return false;
+    }
+    const int n_queues = xcd_queue_count();
+    if (n_queues <= 0) return false;
+    // A queue needs transforms to run ahead of: below that the two launches win (measured: profiles/r4_xcd_local.md)
+    long long min_batch = 16ll * n_queues;
+    if (const char* e = getenv("PFFT_XCD_MIN_BATCH")) min_batch = std::atoll(e);
+    if (count < min_batch) return false;
+    const long long n1 = k->n1, n2 = k->n2;
+    const int t = k->fpw;
+    int tsh = 0;
+    while ((1 << tsh) < t) ++tsh;
+    int slots = k->slots, lag = k->lag, lookahead = k->lookahead;
+    if (const char* e = getenv("PFFT_XCD_SLOTS")) slots = std::atoi(e);  // schedule experiments
+    if (const char* e = getenv("PFFT_XCD_LAG")) lag = std::atoi(e);
+    if (slots < 2 || lag < 1 || lag >= slots || slots > 64) return false;
+    // store-modifier tables W_N^(k1 * c) behind the kernel's own LDS (same shape rule as the two-launch stage A)
+    strided_kernel shape{};
+    shape.lds_bytes = k->lds_bytes + XCD_LDS_CTL_BYTES;
+    shape.stw_mode = 1;
+    int levels = 0, shift = 0;
+    store_table_shape(&shape, n, &levels, &shift);
+    const size_t stw_bytes = (static_cast<size_t>(levels) << shift) * elem_bytes();
+    const size_t own = ((k->lds_bytes + stw_bytes + 15) & ~static_cast<size_t>(15)) + XCD_LDS_CTL_BYTES;
+    if (levels > 4 || own > max_lds) return false;
+    stage s;
+    s.xcd = k;
+    s.n = static_cast<int>(std::min<long long>(n, 0x7fffffff));
+    s.in_buf = BUF_IN;
+    s.out_buf = BUF_OUT;
+    s.count = count;
+    s.in_addr = ia;
+    s.out_addr = oa;
+    s.backward = backward;
+    s.lds_bytes = own;
+    const void* tw = upload_twiddles(std::vector<int>(k->radices, k->radices + k->n_radices));
+    xcd_args& x = s.xa;
+    // stage A: for every transform and column c: length-n1 FFT over rows (stride n2), x W_N^(k1 * c), group-major tiles out
+    strided_args& a = x.a;
+    a.tw = tw;
+    a.total = count * n2;
+    a.inner = n2;
+    a.in_dist_outer = n;
+    a.out_dist_outer = 0;  // (the kernel adds the slot's base)
+    a.in_stride = static_cast<unsigned>(n2);
+    a.in_fdist = 1;
+    a.scale = 1.0;
+    a.stw_tab = store_tables_for(n, levels, shift);
+    a.stw_levels = levels;
+    a.stw_lshift = shift;
+    a.stw_cdiv = 1;
+    a.out_gdist = n1 * t;
+    a.out_stride = static_cast<unsigned>(t);
+    a.out_fdist = 1;
+    // stage B: for every transform and row k1: length-n2 FFT read from the tiles, output X[k1 + n1 * k2]
+    strided_args& b = x.b;
+    b.tw = tw;
+    b.total = count * n1;
+    b.inner = n1;
+    b.in_dist_outer = 0;
+    b.out_dist_outer = n;
+    b.out_stride = static_cast<unsigned>(n1);
+    b.out_fdist = 1;
+    b.scale = scale;
+    b.stw_cdiv = 1;
+    b.in_tile_shift = tsh;
+    b.in_stride = static_cast<unsigned>(n1 * t);
+    b.in_fdist = static_cast<unsigned>(t);
+    x.batch = count;
+    x.n_queues = n_queues;
+    x.slots = slots;
+    x.lag = lag;
+    x.lookahead = lookahead;
+    // claim map: must outlast every ticket in flight -- slots + lag + lookahead batches plus three tickets per work-group
+    const long long tpt = n2 / t + n1 / t;
+    int per_cu = 0;
+    hip_check(hipFuncSetAttribute(k->fn[backward], hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(own)),
+              "hipFuncSetAttribute");
+    hip_check(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k->fn[backward], k->wg, own), "occupancy query");
+    per_cu = std::max(per_cu, 1);
+    s.grid = static_cast<unsigned>(per_cu * n_cus);
+    // (sized for the largest grid the device could hold, not for this direction's: forward and backward share the block)
+    const long long in_flight = 3ll * (8ll * n_cus) / std::max<long long>(tpt, 1) + slots + lag + 2 * lookahead + 8;
+    int map_log2 = 6;
+    while ((1ll << map_log2) < 2 * in_flight) ++map_log2;
+    if (map_log2 > 14) return false;
+    x.map_log2 = map_log2;
+    x.max_iters = static_cast<unsigned>(std::min<long long>((count + lag + lookahead + 6) * tpt, 0xFFFFFFF0ll));
+    x.lds_ctl_off = static_cast<unsigned>(own - XCD_LDS_CTL_BYTES);
+    x.prof = nullptr;
+    const size_t ring = static_cast<size_t>(n_queues) * static_cast<size_t>(slots) * static_cast<size_t>(n) * elem_bytes();
+    if (ring > global_chunk_bytes()) return false;
+    scratch_bytes = std::max(scratch_bytes, ring);
+    xcd_ctl_bytes = std::max(xcd_ctl_bytes, static_cast<size_t>(xcd_ctl_words(n_queues, slots, map_log2)) * sizeof(unsigned));
+    out.push_back(s);
+    if (info != nullptr) {
+      info->tier = PFFT_TIER_GLOBAL;
+      info->n_factors = 2;
+      info->factors[0] = static_cast<int>(n1);
+      info->factors[1] = static_cast<int>(n2);
+      info->workgroup_size = k->wg;
+      info->ffts_per_workgroup = k->fpw;
+      info->lds_bytes = own;
+    }
+    return true;
+  }
+
   int plan_1d(std::vector<stage>& out, long long n, long long count, long long inner_count, int in_buf,
               const addressing& ia, int out_buf, const addressing& oa, bool packed_io, double scale, int backward,
               pfft_dim_info_t* info) {
@@ -1313,6 +1473,9 @@ struct plan_t {
            "default (packed) layout");
     }
     if (in_buf == BUF_IN && out_buf == BUF_OUT && plan_three_stage(out, n, count, ia, oa, scale, backward, info)) {
+      return PFFT_TIER_GLOBAL;
+    }
+    if (in_buf == BUF_IN && out_buf == BUF_OUT && plan_xcd_local(out, n, count, ia, oa, scale, backward, info)) {
       return PFFT_TIER_GLOBAL;
     }
     const long long gmax = generic_max_n();
@@ -1821,6 +1984,7 @@ struct plan_t {
     if (scratch_bytes > 0) {
       hip_check(hipMalloc(&scratch, scratch_bytes), "hipMalloc(scratch)");
     }
+    alloc_xcd_ctl();
     if (alias_scratch_bytes > 0) ensure_alias_scratch();
     info.twiddle_bytes = twiddle_bytes;
     info.scratch_bytes = scratch_bytes + alias_scratch_bytes;
@@ -1845,8 +2009,10 @@ struct plan_t {
         overlap_mode(o.overlap_mode) {
     stages[0] = o.stages[0];
     stages[1] = o.stages[1];
+    xcd_ctl_bytes = o.xcd_ctl_bytes;
     device_guard dg(device);
     if (scratch_bytes > 0) hip_check(hipMalloc(&scratch, scratch_bytes), "hipMalloc(scratch)");
+    alloc_xcd_ctl();
     if (o.alias_scratch != nullptr) ensure_alias_scratch();
   }
   plan_t& operator=(const plan_t&) = delete;
@@ -1898,6 +2064,17 @@ struct plan_t {
     // (split storage: either pair of planes aliasing means the pass cannot write its output over its input)
     const bool aliased = s.alias_scratch != 0 && (in_re == out_re || (split && in_im != nullptr && in_im == out_im));
     if (aliased) ensure_alias_scratch();
+    if (s.xcd != nullptr) {  // one launch for the whole batch: stage A and stage B tasks from per-XCD queues
+      xcd_args x = s.xa;
+      x.a.in = static_cast<const char*>(in_re) + static_cast<size_t>(s.in_addr.offset) * elem_bytes();
+      x.a.out = scratch;
+      x.b.in = scratch;
+      x.b.out = static_cast<char*>(out_re) + static_cast<size_t>(s.out_addr.offset) * elem_bytes();
+      x.ctl = static_cast<unsigned*>(xcd_ctl);
+      hip_check(s.xcd->launch(stream, s.grid, s.lds_bytes, x, s.backward), "kernel launch");
+      if (xcd_check_enabled()) check_xcd_timeouts();
+      return;
+    }
     if (s.rows2d != nullptr) {
       rows2d_args a = s.ra;
       a.any_order = any_order ? 1 : 0;
@@ -2161,6 +2338,21 @@ struct plan_t {
       i = j;
     }
     return rode;
+  }
+
+  /// PFFT_XCD_CHECK=1 (tests): wait for every XCD-local launch and fail when one of its bounded hand-off waits gave up
+  static bool xcd_check_enabled() {
+    const char* e = getenv("PFFT_XCD_CHECK");
+    return e != nullptr && std::atoi(e) != 0;
+  }
+  void check_xcd_timeouts() {
+    hip_check(hipStreamSynchronize(stream), "hipStreamSynchronize");
+    unsigned h[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    hip_check(hipMemcpy(h, static_cast<unsigned*>(xcd_ctl) + XCD_W_TIMEOUT, sizeof h, hipMemcpyDeviceToHost), "hipMemcpy");
+    if (h[0] != 0) {
+      fail(PFFT_INTERNAL_ERROR, "XCD-local four-step launch: ", h[0], " hand-off waits gave up (first: site ", h[1],
+           ", local transform ", h[2], ", wanted ", h[3], ", saw ", h[4], ")");
+    }
   }
 
   /// PFFT_PAIR_XCD=0: never pair narrow-segment groups on one XCD (A/B)

@@ -314,6 +314,17 @@ PFA_DEV void strided_passes(const IO& io, const strided_args& a, unsigned f, uns
   }
 }
 
+/// passes [P, PEND) (the XCD-local four-step kernel puts its hand-off waits between passes)
+template <typename Cfg, bool BWD, int STW, int P, int PEND, typename IO, int TIN = 0>
+PFA_DEV void strided_passes_range(const IO& io, const strided_args& a, unsigned f, unsigned tid, bool live, long long c0,
+                                  cx<typename Cfg::T>* lds, const cx<typename Cfg::T>* __restrict__ tw,
+                                  long long nlive = 0) {
+  if constexpr (P < PEND) {
+    strided_pass<Cfg, BWD, STW, P, IO, false, false, TIN>(io, a, f, tid, live, c0, lds, tw, nlive);
+    strided_passes_range<Cfg, BWD, STW, P + 1, PEND, IO, TIN>(io, a, f, tid, live, c0, lds, tw, nlive);
+  }
+}
+
 /// TIN lane mapping of pass 0 (see strided_pass): lanes element-fastest inside the FPW x TW input tiles
 template <typename Cfg, int TIN = 1>
 PFA_DEV void tin_lanes(unsigned* f, unsigned* tid, bool* live, long long nlive) {

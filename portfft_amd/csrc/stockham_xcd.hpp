@@ -61,6 +61,13 @@ __device__ __forceinline__ unsigned xcd_load(xcd_gu32* p) {
 __device__ __forceinline__ unsigned xcd_add(xcd_gu32* p, unsigned v) {
   return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+/// The next ticket of a queue.  An atomic INCREMENT (wrapping at 2^32 - 1, i.e. never), not an add: hipcc's atomic
+/// optimizer rewrites a fetch-add as one atomic per wave + v_readfirstlane of its result, which waits for the atomic on
+/// the spot (0.7-1.6 us on wave 0 of every task: measured); it leaves the increment alone, so the ticket returns behind
+/// the task's own loads and is first read in duties().
+__device__ __forceinline__ unsigned xcd_take(xcd_gu32* p) {
+  return __builtin_amdgcn_atomic_inc32((unsigned*)p, 0xFFFFFFFFu, __ATOMIC_RELAXED, "agent");
+}
 
 /// a spin gave up: the first one records what it waited for behind the timeout word (tmo[1..7]; read by the tuner and
 /// by pfft_plan_check)
@@ -88,17 +95,35 @@ __device__ __forceinline__ void xcd_wait_ge(xcd_gu32* p, unsigned want, xcd_gu32
   }
 }
 
+typedef unsigned xcd_u4 __attribute__((ext_vector_type(4)));
+
+/// claim-map entry {launch epoch, local transform + 1, claimed transform + 1, 0}: one 16-byte PLAIN store -- the line
+/// stays in this XCD's L2, where every reader of the queue finds it ...
+__device__ __forceinline__ void xcd_map_store(__amdgpu_buffer_rsrc_t map, unsigned M, unsigned epoch, unsigned k, unsigned gid1) {
+  xcd_u4 v;
+  v.x = epoch;
+  v.y = k + 1u;
+  v.z = gid1;
+  v.w = 0u;
+  __builtin_amdgcn_raw_buffer_store_b128(v, map, (k & (M - 1u)) * 16u, 0, 0);
+}
+/// ... and one 16-byte load past the L1 (sc1: served by the L2)
+__device__ __forceinline__ xcd_u4 xcd_map_load(__amdgpu_buffer_rsrc_t map, unsigned M, unsigned k) {
+  return __builtin_amdgcn_raw_buffer_load_b128(map, (k & (M - 1u)) * 16u, 0, 16);
+}
+
 /// the claim-map entry of local transform k: spins until its tag shows up; returns claimed transform + 1 (0: none)
-__device__ __forceinline__ unsigned xcd_wait_claim(xcd_gu64* e, unsigned k, xcd_gu32* tmo) {
+__device__ __forceinline__ unsigned xcd_wait_claim(__amdgpu_buffer_rsrc_t map, unsigned M, unsigned epoch, unsigned k,
+                                                   xcd_gu32* tmo) {
   unsigned lo = 0;
   for (unsigned n = 0;; ++n) {
-    const unsigned long long v = __hip_atomic_load(e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const unsigned hi = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(v >> 32));
-    lo = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(v));
-    if (hi == k + 1u) break;
+    const xcd_u4 v = xcd_map_load(map, M, k);
+    const unsigned ep = __builtin_amdgcn_readfirstlane(v.x), tag = __builtin_amdgcn_readfirstlane(v.y);
+    lo = __builtin_amdgcn_readfirstlane(v.z);
+    if (ep == epoch && tag == k + 1u) break;
     __builtin_amdgcn_s_sleep(2);
     if (n > XCD_SPIN_LIMIT || (n % 64u == 63u && xcd_load(tmo) != 0u)) {
-      xcd_give_up(tmo, 3u, k, hi, lo, n);
+      xcd_give_up(tmo, 3u, k, tag, lo, n);
       lo = 0;
       break;
     }
@@ -119,13 +144,23 @@ struct xcd_with_aux<wg_cfg<T, Seq, WG, FPW, PADS, PADW, TWM, OCC, AUX, STAGED, T
   using type = wg_cfg<T, Seq, WG, FPW, PADS, PADW, TWM, OCC, AUX2, STAGED, TWL>;
 };
 
+constexpr unsigned XCD_UNKNOWN = 0xFFFFFFFFu;  // a claim-map entry that was not yet published when it was looked at
+
 /// CfgA / CfgB: the strided configurations of the two stages (lengths n1 = CfgA::N, n2 = CfgB::N).  This first form
 /// takes pairs with equal work-group size, group width and radix sequence (the registered square pairs: fp32 256 x 256,
 /// 512 x 512, fp64 256 x 256): one LDS image, one copy of the leading twiddle tables.
 /// STW: store modifier W_N^(k1 * c) on stage A's stores (1: tables in LDS, 2: global tables).  TIN: stage B's
-/// tiled-input form (1 = tiles of its own group width).
-template <typename CfgA_, typename CfgB_, bool BWD, int STW, int TIN>
-__global__ __launch_bounds__(CfgA_::WG, CfgA_::OCC) void stockham_xcd_fourstep_kernel(const xcd_args x) {
+/// tiled-input form (1 = tiles of its own group width).  FREERUN (tuner only; results are garbage): 1 no claims and no hand-off waits -- the
+/// bound of the task structure; 2 no waits; 3 static transform map instead of claims, waits kept.  OCCX: waves per SIMD the register allocator must leave room for.
+///
+/// Control traffic stays off the tasks' critical path: thread 0 keeps the work-group TWO tickets ahead -- while ticket
+/// t is processed it already knows t' (the next one), looks up t' 's claim-map entry and hand-off counter (memory round
+/// trips of 0.5-1.6 us under load), takes t'' and publishes {t', transform, counter value} in LDS behind pass 0's
+/// barrier.  A wave polls for itself only when the published value was not yet sufficient.  A stage-A task waits for
+/// its slot only in front of its LAST pass (the stores), so a slot's previous occupant may still be read while the
+/// task loads and computes: the ring needs lag + 1 slots, not lag + (task length in ticket batches).
+template <typename CfgA_, typename CfgB_, bool BWD, int STW, int TIN, int FREERUN = 0, int OCCX = CfgA_::OCC>
+__global__ __launch_bounds__(CfgA_::WG, OCCX) void stockham_xcd_fourstep_kernel(const xcd_args x) {
   using CfgA = typename xcd_with_aux<CfgA_, XCD_AUX_A>::type;
   using CfgB = typename xcd_with_aux<CfgB_, XCD_AUX_B>::type;
   using T = typename CfgA::T;
@@ -140,8 +175,9 @@ __global__ __launch_bounds__(CfgA_::WG, CfgA_::OCC) void stockham_xcd_fourstep_k
   static_assert(CfgB::N % CfgA::FPW == 0 && CfgA::N % CfgB::FPW == 0, "whole groups");
   extern __shared__ __attribute__((aligned(16))) char pfa_smem_strided[];
   cx<T>* lds = reinterpret_cast<cx<T>*>(pfa_smem_strided);
-  // control words behind everything else in the dynamic region: [0], [1] next ticket (double-buffered), [2] stage-A
-  // arrivals of the work-group's waves, [3] "this work-group clears the control block"
+  // control words behind everything else in the dynamic region (XCD_LDS_CTL_BYTES): [4 p .. 4 p + 2], p = 0 / 1: the
+  // record {ticket, transform + 1 or XCD_UNKNOWN, hand-off counter value} of the iteration with parity p; [8] stage-A
+  // arrivals of the work-group's waves; [9] "this work-group clears the control block"
   unsigned* const s_ctl = reinterpret_cast<unsigned*>(pfa_smem_strided + x.lds_ctl_off);
   const unsigned f = threadIdx.x % CfgA::FPW;
   const unsigned tid = threadIdx.x / CfgA::FPW;
@@ -150,69 +186,116 @@ __global__ __launch_bounds__(CfgA_::WG, CfgA_::OCC) void stockham_xcd_fourstep_k
   xcd_gu32* const ctl = (xcd_gu32*)x.ctl;
   xcd_gu32* const tmo = ctl + XCD_W_TIMEOUT;
   const unsigned q = xcd_id();
-  const unsigned S = 1u << x.slots_log2, M = 1u << x.map_log2;
+  const unsigned S = static_cast<unsigned>(x.slots), M = 1u << x.map_log2;
   if (threadIdx.x == 0) {
-    s_ctl[2] = 0u;
-    s_ctl[3] = 0u;
+    s_ctl[8] = 0u;
+    s_ctl[9] = 0u;
   }
   strided_copy_twiddles<CfgA>(lds, tw_a);
   strided_copy_stw<CfgA, STW>(x.a);
   if (q < static_cast<unsigned>(x.n_queues)) {  // (an id the census did not see: nothing claimed, nothing lost)
-    xcd_gu32* const qb = ctl + XCD_W_QUEUES + q * xcd_queue_words(x.slots_log2, x.map_log2);
+    xcd_gu32* const qb = ctl + XCD_W_QUEUES + q * xcd_queue_words(x.slots, x.map_log2);
     xcd_gu32* const ticket = qb;
-    xcd_gu64* const map = (xcd_gu64*)(qb + 32);
-    xcd_gu32* const done = qb + 32 + 2 * M;
+    const __amdgpu_buffer_rsrc_t map = __builtin_amdgcn_make_buffer_rsrc((void*)(qb + 32), 0, M * 16u, 0x00020000);
+    xcd_gu32* const done = qb + 32 + 4 * M;
+    const unsigned epoch = xcd_load(ctl + XCD_W_EPOCH);
     const long long slot_elems = static_cast<long long>(CfgA::N) * CfgB::N;
     const unsigned batch = static_cast<unsigned>(x.batch);
-    if (threadIdx.x == 0) s_ctl[0] = xcd_add(ticket, 1u);
+    // transform, slot and hand-off counter of a ticket
+    auto decode = [&](unsigned tk, unsigned* kl_, unsigned* r_, bool* is_a_, int* k_) PFA_LAMBDA {
+      *kl_ = tk / TPT;
+      *r_ = tk % TPT;
+      *is_a_ = *r_ < TA;
+      *k_ = *is_a_ ? static_cast<int>(*kl_) : static_cast<int>(*kl_) - x.lag;
+    };
+    auto claim = [&](unsigned kc) PFA_LAMBDA {
+      const unsigned g = xcd_add(ctl + XCD_W_NEXT, 1u);
+      xcd_map_store(map, M, epoch, kc, g < batch ? g + 1u : 0u);
+    };
+    unsigned t_next = 0;  // thread 0: the ticket after the one being processed
+    if (threadIdx.x == 0) {
+      const unsigned t0 = xcd_take(ticket);
+      t_next = xcd_take(ticket);
+      s_ctl[0] = t0;
+      s_ctl[1] = XCD_UNKNOWN;
+      s_ctl[2] = 0u;
+      // the queue's very first ticket claims transforms 0 .. lookahead before anybody -- itself included -- waits for them
+      if (t0 == 0u) {
+        for (unsigned kc = 0; kc <= static_cast<unsigned>(x.lookahead); ++kc) claim(kc);
+      }
+    }
     __syncthreads();
-    unsigned t = __builtin_amdgcn_readfirstlane(s_ctl[0]);
-    unsigned par = 1;
-    bool stop = false, last = false;
+    unsigned par = 0;
+    bool stop = false;
+    int left = -1;  // -1: running; otherwise the iterations that remain, this one included (tickets already in hand)
 #ifdef PFA_XCD_PROF
     unsigned long long prof_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #endif
     PFA_XCD_STAMP(p_begin);
-    for (unsigned it = 0; !last && it < x.max_iters; ++it) {
+    bool more = true;
+    for (unsigned it = 0; more && it < x.max_iters; ++it) {
       PFA_XCD_STAMP(p_it0);
-      const unsigned kl = t / TPT, r = t % TPT;
-      const bool is_a = r < TA;
-      const int k = is_a ? static_cast<int>(kl) : static_cast<int>(kl) - x.lag;
-      last = stop;  // the ticket in hand when the end showed up is still processed (it carries a claim duty), no further one taken
-      unsigned tn = 0;
-      if (threadIdx.x == 0 && !last) tn = xcd_add(ticket, 1u);  // the next ticket: its latency hides behind this task
-      // Duties of thread 0 in the middle of a task (a barrier follows): publish the next ticket to the work-group, and --
-      // the first ticket of a batch -- claim the transform `lookahead` batches ahead (batch 0: all up to there).  Claims of
-      // a queue are chained: entry kc is claimed after entry kc - 1 has been published, so "no transform left" is
-      // monotone in the local index (the claimer of kc - 1 holds a lower ticket: no deadlock).
-      auto claim = [&](unsigned kc) PFA_LAMBDA {
-        const unsigned g = xcd_add(ctl + XCD_W_NEXT, 1u);
-        const unsigned long long e = (static_cast<unsigned long long>(kc + 1u) << 32) | (g < batch ? g + 1u : 0u);
-        __hip_atomic_store(map + (kc & (M - 1u)), e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      };
+      const unsigned t = __builtin_amdgcn_readfirstlane(s_ctl[4 * par]);
+      unsigned gid1 = __builtin_amdgcn_readfirstlane(s_ctl[4 * par + 1]);
+      const unsigned depv = __builtin_amdgcn_readfirstlane(s_ctl[4 * par + 2]);
+      unsigned kl, r;
+      bool is_a;
+      int k;
+      decode(t, &kl, &r, &is_a, &k);
+      const bool has_next = left != 1;  // a further iteration follows (its ticket is t_next)
+      // ---- thread 0: take the ticket two ahead, look up the next one's claim and counter (used in duties())
+      unsigned t2 = 0;
+      xcd_u4 e1 = {0u, 0u, 0u, 0u};
+      unsigned d1 = 0, k1u = 0;
+      bool real1 = false;
+      if (threadIdx.x == 0 && has_next) {
+        if (left < 0) t2 = xcd_take(ticket);
+        unsigned kl1, r1;
+        bool a1;
+        int k1;
+        decode(t_next, &kl1, &r1, &a1, &k1);
+        real1 = k1 >= 0;
+        if (real1 && FREERUN != 1) {
+          k1u = static_cast<unsigned>(k1);
+          e1 = xcd_map_load(map, M, k1u);
+          d1 = __hip_atomic_load(done + (k1u % S) * 64u + (a1 ? 32u : 0u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
+      // Duties of thread 0 in the middle of a task (a barrier follows): publish the next iteration's record, and -- the
+      // first ticket of a batch -- claim the transform `lookahead` batches ahead.  Claims of a queue are chained: entry kc
+      // is claimed after entry kc - 1 has been published, so "no transform left" is monotone in the local index (the
+      // claimer of kc - 1 holds a lower ticket: no deadlock).
       auto duties = [&]() PFA_LAMBDA {
         if (threadIdx.x == 0) {
-          s_ctl[par] = tn;
-          if (r == 0 && kl != 0) {
+          if (has_next) {
+            unsigned* rec = s_ctl + 4 * (par ^ 1u);
+            rec[0] = t_next;
+            rec[1] = !real1 ? 0u : (e1.x == epoch && e1.y == k1u + 1u ? e1.z : XCD_UNKNOWN);
+            if constexpr (FREERUN == 1 || FREERUN == 3) rec[1] = XCD_UNKNOWN;
+            rec[2] = d1;
+            t_next = t2;
+          }
+          if (r == 0 && kl != 0 && (FREERUN == 0 || FREERUN == 2)) {
             const unsigned kc = kl + static_cast<unsigned>(x.lookahead);
-            (void)xcd_wait_claim(map + ((kc - 1u) & (M - 1u)), kc - 1u, tmo);
+            (void)xcd_wait_claim(map, M, epoch, kc - 1u, tmo);
             claim(kc);
           }
         }
       };
-      // the queue's very first ticket claims transforms 0 .. lookahead before anybody -- itself included -- waits for them
-      if (t == 0 && threadIdx.x == 0) {
-        for (unsigned kc = 0; kc <= static_cast<unsigned>(x.lookahead); ++kc) claim(kc);
+      if (k < 0) gid1 = 0u;
+      if (k >= 0 && gid1 == XCD_UNKNOWN) {
+        if constexpr (FREERUN == 1 || FREERUN == 3) {  // (timing experiments: static transform map)
+          const unsigned g = static_cast<unsigned>(k) * static_cast<unsigned>(x.n_queues) + q;
+          gid1 = g < batch ? g + 1u : 0u;
+        } else {
+          gid1 = xcd_wait_claim(map, M, epoch, static_cast<unsigned>(k), tmo);
+        }
       }
-      unsigned gid1 = 0;
-      if (k >= 0) {
-        gid1 = xcd_wait_claim(map + (static_cast<unsigned>(k) & (M - 1u)), static_cast<unsigned>(k), tmo);
-        stop = stop || (!is_a && gid1 == 0u);  // the stage-B side has run out: everything real has a lower ticket
-      }
+      stop = stop || (k >= 0 && !is_a && gid1 == 0u);  // the stage-B side has run out: everything real has a lower ticket
       PFA_XCD_STAMP(p_claimed);
       PFA_XCD_ACC(1, p_it0, p_claimed);
       if (k >= 0 && gid1 != 0u) {
-        const unsigned slot = static_cast<unsigned>(k) & (S - 1u), rnd = static_cast<unsigned>(k) >> x.slots_log2;
+        const unsigned slot = static_cast<unsigned>(k) % S, rnd = static_cast<unsigned>(k) / S;
         const long long sbase = (static_cast<long long>(q) * S + slot) * slot_elems;
         const long long gid = static_cast<long long>(gid1) - 1;
         xcd_gu32* const done_a = done + slot * 64u;
@@ -220,30 +303,33 @@ __global__ __launch_bounds__(CfgA_::WG, CfgA_::OCC) void stockham_xcd_fourstep_k
         bool live;
         long long c0, nlive;
         if (is_a) {
-          xcd_wait_ge(done_b, rnd * TB, tmo, 1u, static_cast<unsigned>(k));  // the slot's previous occupant has been read
-          PFA_XCD_STAMP(p_dep);
-          PFA_XCD_ACC(2, p_claimed, p_dep);
           const auto io = strided_group<CfgA, 0>(x.a, gid * TA + r, f, &live, &c0, &nlive, 0, sbase);
           strided_pass<CfgA, BWD, STW, 0, decltype(io)>(io, x.a, f, tid, live, c0, lds, tw_a, nlive);
           PFA_XCD_STAMP(p_p0);
-          PFA_XCD_ACC(4, p_dep, p_p0);
+          PFA_XCD_ACC(4, p_claimed, p_p0);
           duties();
-          PFA_XCD_STAMP(p_du);
-          PFA_XCD_ACC(5, p_p0, p_du);
-          strided_passes<CfgA, BWD, STW, 1, decltype(io)>(io, x.a, f, tid, live, c0, lds, tw_a, nlive);
+          strided_passes_range<CfgA, BWD, STW, 1, CfgA::NP - 1, decltype(io)>(io, x.a, f, tid, live, c0, lds, tw_a, nlive);
+          PFA_XCD_STAMP(p_mid);
+          PFA_XCD_ACC(5, p_p0, p_mid);
+          // the slot's previous occupant must have been read before this task's stores (the last pass)
+          if ((FREERUN == 0 || FREERUN == 3) && depv < rnd * TB) xcd_wait_ge(done_b, rnd * TB, tmo, 1u, static_cast<unsigned>(k));
+          PFA_XCD_STAMP(p_dep);
+          PFA_XCD_ACC(2, p_mid, p_dep);
+          strided_pass<CfgA, BWD, STW, CfgA::NP - 1, decltype(io)>(io, x.a, f, tid, live, c0, lds, tw_a, nlive);
           PFA_XCD_STAMP(p_st);
-          PFA_XCD_ACC(6, p_du, p_st);
+          PFA_XCD_ACC(6, p_dep, p_st);
           // every storing wave waits for its stores to reach the L2; the wave that arrives last signals
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
           PFA_XCD_STAMP(p_dr);
           PFA_XCD_ACC(7, p_st, p_dr);
           PFA_XCD_CNT(8);
           if (threadIdx.x % 64u == 0u) {
-            const unsigned old = __hip_atomic_fetch_add(&s_ctl[2], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            const unsigned old = __hip_atomic_fetch_add(&s_ctl[8], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             if ((old + 1u) % NW == 0u) xcd_add(done_a, 1u);
           }
         } else {
-          xcd_wait_ge(done_a, (rnd + 1u) * TA, tmo, 2u, static_cast<unsigned>(k));  // all stage-A tasks have stored
+          // all of the transform's stage-A tasks have stored
+          if ((FREERUN == 0 || FREERUN == 3) && depv < (rnd + 1u) * TA) xcd_wait_ge(done_a, (rnd + 1u) * TA, tmo, 2u, static_cast<unsigned>(k));
           PFA_XCD_STAMP(p_dep);
           PFA_XCD_ACC(3, p_claimed, p_dep);
           const auto io = strided_group<CfgB, 0>(x.b, gid * TB + (r - TA), f, &live, &c0, &nlive, sbase, 0);
@@ -253,7 +339,7 @@ __global__ __launch_bounds__(CfgA_::WG, CfgA_::OCC) void stockham_xcd_fourstep_k
           // behind pass 0's barrier every wave has its input in registers: the slot is read
           if (threadIdx.x == 0) xcd_add(done_b, 1u);
           duties();
-          strided_passes<CfgB, BWD, 0, 1, decltype(io), false, false, TIN>(io, x.b, f, tid, live, c0, lds, tw_b, nlive);
+          strided_passes_range<CfgB, BWD, 0, 1, CfgB::NP, decltype(io), TIN>(io, x.b, f, tid, live, c0, lds, tw_b, nlive);
           PFA_XCD_STAMP(p_st);
           PFA_XCD_ACC(10, p_p0, p_st);
           PFA_XCD_CNT(11);
@@ -263,7 +349,12 @@ __global__ __launch_bounds__(CfgA_::WG, CfgA_::OCC) void stockham_xcd_fourstep_k
         __syncthreads();
         PFA_XCD_CNT(12);
       }
-      t = __builtin_amdgcn_readfirstlane(s_ctl[par]);
+      // the tickets in hand when the end showed up are still processed (they carry claim duties), no further one is taken
+      if (left > 0) {
+        if (--left == 0) more = false;
+      } else if (stop) {
+        left = 2;  // two iterations remain: the published next ticket and the one thread 0 took in this iteration
+      }
       par ^= 1u;
     }
 #ifdef PFA_XCD_PROF
@@ -282,21 +373,30 @@ __global__ __launch_bounds__(CfgA_::WG, CfgA_::OCC) void stockham_xcd_fourstep_k
   __syncthreads();
   if (threadIdx.x == 0) {
     const unsigned old = xcd_add(ctl + XCD_W_EXIT, 1u);
-    s_ctl[3] = old == gridDim.x - 1u ? 1u : 0u;
+    s_ctl[9] = old == gridDim.x - 1u ? 1u : 0u;
   }
   __syncthreads();
-  if (s_ctl[3] != 0u) {
-    const unsigned words = xcd_ctl_words(x.n_queues, x.slots_log2, x.map_log2);
+  if (s_ctl[9] != 0u) {
+    // counters only: tickets, done_a / done_b, the launch-wide words.  The claim maps are left alone (xcd_args.hpp);
+    // the epoch makes their entries invalid for the next launch.
+    const unsigned qw = xcd_queue_words(x.slots, x.map_log2), mw = 4u << x.map_log2;
+    const unsigned words = xcd_ctl_words(x.n_queues, x.slots, x.map_log2);
     for (unsigned i = threadIdx.x; i < words; i += CfgA::WG) {
-      if (i < XCD_W_TIMEOUT || i >= XCD_W_QUEUES) __hip_atomic_store(ctl + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      bool clear = i < XCD_W_EXIT + 1u;
+      if (i >= XCD_W_QUEUES) {
+        const unsigned o = (i - XCD_W_QUEUES) % qw;
+        clear = o < 32u || o >= 32u + mw;
+      }
+      if (clear) __hip_atomic_store(ctl + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    if (threadIdx.x == 0) xcd_add(ctl + XCD_W_EPOCH, 1u);
   }
 }
 
-/// LDS bytes of the launch: the configuration's own, the store-modifier tables, 16 bytes of control words
+/// LDS bytes of the launch: the configuration's own, the store-modifier tables, the control words
 template <typename Cfg>
 constexpr size_t xcd_lds_bytes(size_t stw_bytes) {
-  return ((strided_lds_bytes<Cfg>() + stw_bytes + 15) & ~static_cast<size_t>(15)) + 16;
+  return ((strided_lds_bytes<Cfg>() + stw_bytes + 15) & ~static_cast<size_t>(15)) + XCD_LDS_CTL_BYTES;
 }
 
 }  // namespace pfa

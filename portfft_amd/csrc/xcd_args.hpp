@@ -5,24 +5,31 @@
 
 namespace pfa {
 
-/// Control block (32-bit words, device memory, all zero between launches -- the last work-group to leave a launch
-/// clears it again, so a replayed HIP graph needs no memset node):
+/// Control block (32-bit words, device memory).  Its counters are zero between launches -- the last work-group to leave
+/// a launch clears them again, so a replayed HIP graph needs no memset node:
 ///   [XCD_W_NEXT]     next unclaimed transform of the launch (queues claim transforms one by one)
 ///   [XCD_W_EXIT]     work-groups that have left the launch
+///   [XCD_W_EPOCH]    launches completed on this block (never cleared; tags the claim-map entries of a launch)
 ///   [XCD_W_TIMEOUT]  sticky: a bounded spin gave up (never cleared by the kernel; pfft_plan_check reads it)
 ///   [XCD_W_QUEUES + q * queue_words(...)]  queue q -- one per XCC id:
 ///       +0                 ticket: tasks handed out
-///       +32 .. +32 + 2M    map: M 64-bit entries {tag = local transform + 1, claimed transform + 1 (0: none left)}
-///       +32 + 2M + 64 s    done_a of slot s: stage-A tasks finished, cumulative over the slot's occupants
-///       +32 + 2M + 64 s + 32   done_b of slot s: stage-B tasks that have their input in registers
-/// Every polled word sits on a 128-byte line of its own (the map entries share lines: written once, read by all).
-enum : unsigned { XCD_W_NEXT = 0, XCD_W_EXIT = 32, XCD_W_TIMEOUT = 64, XCD_W_QUEUES = 96 };
-constexpr unsigned xcd_queue_words(int slots_log2, int map_log2) {
-  return 32u + (2u << map_log2) + (64u << slots_log2);
+///       +32 .. +32 + 4M    map: M 16-byte entries {launch epoch, local transform + 1, claimed transform + 1 (0: none
+///                          left), 0}.  Written with PLAIN stores and read past the L1: writer and readers of a queue
+///                          share one XCD, so the entries live in its L2 (an entry read from memory cost every task
+///                          ~1.5 us: measured).  Never cleared -- a dirty line of another XCD's L2 could come back
+///                          after the clearing stores -- the epoch makes the entries of older launches invalid.
+///       +32 + 4M + 64 s    done_a of slot s: stage-A tasks finished, cumulative over the slot's occupants
+///       +32 + 4M + 64 s + 32   done_b of slot s: stage-B tasks that have their input in registers
+/// Every polled counter sits on a 128-byte line of its own.
+enum : unsigned { XCD_W_NEXT = 0, XCD_W_EXIT = 32, XCD_W_EPOCH = 33, XCD_W_TIMEOUT = 64, XCD_W_QUEUES = 96 };
+constexpr unsigned xcd_queue_words(int slots, int map_log2) {
+  return 32u + (4u << map_log2) + 64u * static_cast<unsigned>(slots);
 }
-constexpr unsigned xcd_ctl_words(int queues, int slots_log2, int map_log2) {
-  return XCD_W_QUEUES + static_cast<unsigned>(queues) * xcd_queue_words(slots_log2, map_log2);
+constexpr unsigned xcd_ctl_words(int queues, int slots, int map_log2) {
+  return XCD_W_QUEUES + static_cast<unsigned>(queues) * xcd_queue_words(slots, map_log2);
 }
+/// bytes of control words at the end of the kernel's dynamic LDS
+constexpr unsigned XCD_LDS_CTL_BYTES = 64;
 
 /// One launch = the whole batch.  `a` / `b` are the stage arguments of the two-launch plan with the scratch side
 /// rebased: a.out = b.in = the slot rings, a.out_dist_outer = b.in_dist_outer = 0 (the kernel adds the slot's base).
@@ -31,12 +38,12 @@ struct xcd_args {
   unsigned* ctl;
   long long batch;      // transforms of this launch
   int n_queues;         // queues in the control block = XCC ids the device reports (work-groups with another id idle)
-  int slots_log2;       // intermediate slots per queue (each one transform)
+  int slots;            // intermediate slots per queue (each one transform); lag < slots
   int map_log2;         // entries of a queue's claim map
   int lag;              // stage-B tickets of a transform come `lag` transforms behind its stage-A tickets
   int lookahead;        // transforms a queue claims ahead of its stage-A tickets
   unsigned max_iters;   // bound of a work-group's ticket loop: (batch + lag + lookahead + 2) * tickets per transform
-  unsigned lds_ctl_off; // byte offset of the kernel's 16 bytes of control words in its dynamic LDS
+  unsigned lds_ctl_off; // byte offset of the kernel's XCD_LDS_CTL_BYTES of control words in its dynamic LDS
   unsigned long long* prof;  // tuner builds (PFA_XCD_PROF) only: cycle sums of wave 0 of every work-group
 };
 

@@ -1,0 +1,174 @@
+"""The XCD-local single-launch four-step plan (portfft_amd/csrc/stockham_xcd.hpp, plan.cpp plan_xcd_local) through the
+C ABI on an MI355X: fp32 N = 2^18 (512 x 512), the reference's GLOBAL-tier size range
+(ref: test/unit_test/instantiate_fft_tests.hpp:147-151, src/portfft/dispatcher/global_dispatcher.hpp:343-408).
+
+Every launch runs with PFFT_XCD_CHECK=1: the library waits for it and fails when one of the kernel's bounded hand-off
+waits gave up.  Results are compared with NumPy in double precision on sampled transforms (rel-L2 <= 2e-6, the bar of
+tests/test_gpu_parity.py), with the two-launch plan of the same descriptor (PFFT_NO_XCD_LOCAL=1: another split of N, so
+equal within the tolerance, not bit for bit -- the bit-for-bit comparison against the two launches of the SAME stage
+kernels is tools/tune_xcd.hip), and through Parseval / round trips on every transform.
+"""
+import os
+
+import numpy as np
+import pytest
+
+import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+N = 1 << 18
+TOL = 2e-6
+
+
+def _mods():
+    import gpu_utils as G
+    import portfft_amd as pf
+    return G, pf, G.torch_mod()
+
+
+class _env:
+    def __init__(self, **kv):
+        self.kv = kv
+
+    def __enter__(self):
+        self.old = {k: os.environ.get(k) for k in self.kv}
+        os.environ.update(self.kv)
+
+    def __exit__(self, *a):
+        for k, v in self.old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+@pytest.fixture(autouse=True)
+def _checked_launches():
+    with _env(PFFT_XCD_CHECK="1"):
+        yield
+
+
+def _random(torch, count, seed=5):
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    x = torch.empty(count, dtype=torch.complex64, device="cuda")
+    torch.view_as_real(x).uniform_(-1, 1, generator=g)
+    return x
+
+
+def _check_samples(x, y, batch, samples, scale=1.0):
+    for b in samples:
+        ref = np.fft.fft(x.view(batch, N)[b].cpu().numpy().astype(np.complex128)) * scale
+        assert H.rel_l2(y.view(batch, N)[b].cpu().numpy(), ref) <= TOL, ("transform", b)
+
+
+def test_xcd_local_plan_is_taken_and_matches_numpy_and_the_two_launch_plan():
+    G, pf, torch = _mods()
+    for batch in (128, 131, 515):  # the smallest batch that takes the plan on 8 XCDs, ragged counts
+        for placement in (1, 0):
+            desc = G.make_descriptor([N], "f32", batch=batch, placement=placement)
+            plan = desc.commit()
+            assert list(plan.info().launches) == [1, 1], "one launch per execute"
+            x = _random(torch, batch * N)
+            y = x.clone() if placement == 0 else torch.full_like(x, float("nan"))
+            (plan.compute_forward(y) if placement == 0 else plan.compute_forward(x, y)).wait()
+            _check_samples(x, y, batch, (0, 1, batch // 2, batch - 2, batch - 1))
+            # Parseval on every transform: no transform skipped, none computed from a stale intermediate
+            ex = (x.view(batch, N).abs().double() ** 2).sum(dim=1)
+            ey = (y.view(batch, N).abs().double() ** 2).sum(dim=1)
+            assert float(((ey / (N * ex)) - 1).abs().max()) < 1e-5
+            with _env(PFFT_NO_XCD_LOCAL="1"):
+                plan2 = G.make_descriptor([N], "f32", batch=batch, placement=placement).commit()
+            assert min(plan2.info().launches) >= 2
+            y2 = x.clone() if placement == 0 else torch.empty_like(x)
+            (plan2.compute_forward(y2) if placement == 0 else plan2.compute_forward(x, y2)).wait()
+            d = (y - y2).abs().double().pow(2).sum(dim=0).sqrt() / y2.abs().double().pow(2).sum(dim=0).sqrt()
+            assert float(d) <= TOL, (batch, placement, float(d))
+            # backward through the same plan restores the input, on every transform
+            z = torch.empty_like(x)
+            plan.compute_backward(y, z).wait()
+            err = (z.view(batch, N) / N - x.view(batch, N)).abs().double().pow(2).sum(dim=1).sqrt() / ex.sqrt()
+            assert float(err.max()) <= TOL, (batch, placement, float(err.max()))
+            del y, y2, z
+        torch.cuda.empty_cache()
+
+
+def test_small_batches_keep_the_two_launch_plan():
+    G, pf, torch = _mods()
+    plan = G.make_descriptor([N], "f32", batch=16).commit()
+    assert min(plan.info().launches) >= 2
+    # other lengths and precisions have no registered pair
+    assert min(G.make_descriptor([1 << 16], "f32", batch=512).commit().info().launches) >= 2
+    assert min(G.make_descriptor([N], "f64", batch=256).commit().info().launches) >= 2
+
+
+def test_repeated_launches_offsets_scales_and_graph_replay():
+    """The control block is left clean by every launch (the last work-group out clears it): 20 executes of one plan,
+    then a captured execute replayed on new data.  Offsets and scales ride on the stage arguments."""
+    G, pf, torch = _mods()
+    batch = 200
+    off_f, off_b = 24, 8
+    desc = G.make_descriptor([N], "f32", batch=batch, fwd_offset=off_f, bwd_offset=off_b, fwd_scale=0.5, bwd_scale=2.0 / N)
+    plan = desc.commit()
+    assert list(plan.info().launches) == [1, 1]
+    x = _random(torch, batch * N + off_f, seed=9)
+    y = torch.full((batch * N + off_b,), 7.0, dtype=torch.complex64, device="cuda")
+    for _ in range(20):
+        plan.compute_forward(x, y)
+    plan.wait()
+    assert bool((y[:off_b] == 7.0).all()), "elements in front of the offset stay untouched"
+    _check_samples(x[off_f:], y[off_b:], batch, (0, 77, batch - 1), scale=0.5)
+    z = torch.zeros_like(x)
+    plan.compute_backward(y, z).wait()  # backward: input at the backward offset, output at the forward offset
+    err = float(((z[off_f:] - x[off_f:]).abs().double().pow(2).sum() / x[off_f:].abs().double().pow(2).sum()).sqrt())
+    assert err <= TOL, err
+    # graph capture: one kernel node, no memset node -- replays leave the control block as they found it
+    s1 = torch.cuda.Stream()
+    plan_s = G.make_descriptor([N], "f32", batch=batch).commit(s1)
+    xin = torch.zeros(batch * N, dtype=torch.complex64, device="cuda")
+    out = torch.empty_like(xin)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with _env(PFFT_XCD_CHECK="0"):  # (the check synchronises, which a capture does not allow)
+        with torch.cuda.graph(g, stream=s1):
+            plan_s.compute_forward(xin, out, want_event=False)
+        torch.cuda.synchronize()
+        for seed in (1, 2, 3):
+            xr = _random(torch, batch * N, seed=seed)
+            xin.copy_(xr)
+            g.replay()
+            torch.cuda.synchronize()
+            _check_samples(xr, out, batch, (0, batch - 1))
+    # and an ordinary checked launch of the replayed plan still finds its control block clean
+    plan_s.compute_forward(xin, out).wait()
+    _check_samples(xin, out, batch, (3,))
+
+
+def test_copies_run_concurrently_with_partial_residency():
+    """Two plans of one descriptor (each with its own slot rings and control block) on two streams at once: the work-groups of
+    the two launches share the CUs, so neither launch has its full grid resident -- the hand-offs may not depend on that
+    (every wait is for a task with a lower ticket, held by a running work-group)."""
+    G, pf, torch = _mods()
+    batch = 256
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    p1 = G.make_descriptor([N], "f32", batch=batch).commit(s1)
+    p2 = G.make_descriptor([N], "f32", batch=batch).commit(s2)
+    p3 = p1.copy()  # (a copy shares kernels and twiddles, owns its slot rings and control block; same stream as p1)
+    x1, x2 = _random(torch, batch * N, seed=21), _random(torch, batch * N, seed=22)
+    y1, y2 = torch.empty_like(x1), torch.empty_like(x2)
+    torch.cuda.synchronize()
+    with _env(PFFT_XCD_CHECK="0"):  # enqueue without waiting, so that the launches overlap
+        for _ in range(5):
+            p1.compute_forward(x1, y1)
+            p2.compute_forward(x2, y2)
+    torch.cuda.synchronize()
+    p1.compute_forward(x1, y1).wait()  # checked launches: no wait gave up in any of the launches before
+    p2.compute_forward(x2, y2).wait()
+    _check_samples(x1, y1, batch, (0, 100, batch - 1))
+    _check_samples(x2, y2, batch, (0, 100, batch - 1))
+    ex = (x1.view(batch, N).abs().double() ** 2).sum(dim=1)
+    ey = (y1.view(batch, N).abs().double() ** 2).sum(dim=1)
+    assert float(((ey / (N * ex)) - 1).abs().max()) < 1e-5
+    y3 = torch.empty_like(x1)
+    p3.compute_forward(x1, y3).wait()
+    assert torch.equal(y3, y1), "a copy of the plan computes the same bits"

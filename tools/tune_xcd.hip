@@ -2,8 +2,9 @@
 // production pair of the same stage kernels (Infinity-Cache-sized chunks, writer / reader policies), bit for bit.
 //
 //   hipcc -O3 -std=c++17 --offload-arch=gfx950 -DTUNE_CASE=<case> tools/tune_xcd.hip -o build/tune_xcd_<case>
-//   cases: 16 = fp32 65536 (256 x 256), 18 = fp32 2^18 (512 x 512), 116 = fp64 65536 (256 x 256)
-//   env:   TUNE_BATCH, TUNE_SWEEP=1 (slots / lag / work-groups per CU sweep), TUNE_SLOTS_LOG2, TUNE_LAG, TUNE_LOOKAHEAD,
+//   cases: 16 = fp32 65536 (256 x 256), 18 = fp32 2^18 (512 x 512), 116 = fp64 65536 (256 x 256), 118 = fp64 2^18 (512 x 512),
+//          120 = fp64 2^20 (1024 x 1024, BASELINE config 3)
+//   env:   TUNE_BATCH, TUNE_SWEEP=1 (slots / lag / work-groups per CU sweep), TUNE_SLOTS, TUNE_LAG, TUNE_LOOKAHEAD,
 //          TUNE_WG_PER_CU, TUNE_REPS
 #include <hip/hip_runtime.h>
 #include <algorithm>
@@ -23,10 +24,24 @@ using namespace pfa;
 #ifndef TUNE_CASE
 #define TUNE_CASE 16
 #endif
+#ifndef TUNE_OCCX
+#define TUNE_OCCX 2  // waves per SIMD the fused kernel's register budget leaves room for
+#endif
+#ifndef TUNE_FREERUN
+#define TUNE_FREERUN 0  // 1: timing experiment without claims and hand-off waits (results are garbage)
+#endif
 #if TUNE_CASE == 116
 using T = double;
 using Cfg = strided_cfg<double, radix_list<16, 16>, 128, 8, 2, PFA_AUX_NT>;
 constexpr long long DEF_BATCH = 2048;
+#elif TUNE_CASE == 118
+using T = double;
+using Cfg = strided_cfg<double, radix_list<8, 8, 8>, 512, 8, 2, PFA_AUX_NT>;
+constexpr long long DEF_BATCH = 256;
+#elif TUNE_CASE == 120
+using T = double;
+using Cfg = strided_cfg<double, radix_list<16, 8, 8>, 512, 8, 2, PFA_AUX_NT>;
+constexpr long long DEF_BATCH = 128;
 #elif TUNE_CASE == 18
 using T = float;
 using Cfg = strided_cfg<float, radix_list<8, 8, 8>, 512, 16, 2, PFA_AUX_NT>;
@@ -116,7 +131,7 @@ int main() {
   const size_t total = (size_t)g_batch * N * 2;  // scalars
   T *in, *out, *ref, *scratch;
   CK(hipMalloc(&in, total * sizeof(T))); CK(hipMalloc(&out, total * sizeof(T))); CK(hipMalloc(&ref, total * sizeof(T)));
-  CK(hipMalloc(&scratch, (size_t)512 << 20));
+  CK(hipMalloc(&scratch, (size_t)2048 << 20));
   fill_uniform<<<4096, 256>>>(in, total, 7);
   CK(hipDeviceSynchronize());
   {
@@ -170,10 +185,10 @@ int main() {
   unsigned n_queues = 0; CK(hipMemcpy(&n_queues, d_census, 4, hipMemcpyDeviceToHost));
   printf("XCC ids seen: %u\n", n_queues);
   unsigned long long* d_diff; CK(hipMalloc(&d_diff, 8));
-  const void* fx = (const void*)&stockham_xcd_fourstep_kernel<Cfg, Cfg, false, 1, 1>;
+  const void* fx = (const void*)&stockham_xcd_fourstep_kernel<Cfg, Cfg, false, 1, 1, TUNE_FREERUN, TUNE_OCCX>;
   hipFuncAttributes fattr; CK(hipFuncGetAttributes(&fattr, fx));
   printf("fused kernel: %d VGPRs, %d SGPRs... numRegs %d, static LDS %zu\n", fattr.numRegs, 0, fattr.numRegs, fattr.sharedSizeBytes);
-  auto run = [&](int slots_log2, int lag, int lookahead, int wg_per_cu, bool verbose) {
+  auto run = [&](int slots, int lag, int lookahead, int wg_per_cu, bool verbose) {
     const int map_log2 = 8;
     const size_t own = xcd_lds_bytes<Cfg>(stw_bytes);
     // pad the LDS request so that exactly wg_per_cu work-groups fit a CU
@@ -186,15 +201,15 @@ int main() {
     CK(hipFuncSetAttribute(fx, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     int per_cu = 0; CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fx, Cfg::WG, lds));
     const unsigned grid = (unsigned)(per_cu * g_cus);
-    const unsigned words = xcd_ctl_words((int)n_queues, slots_log2, map_log2);
+    const unsigned words = xcd_ctl_words((int)n_queues, slots, map_log2);
     unsigned* ctl; CK(hipMalloc(&ctl, words * 4)); CK(hipMemset(ctl, 0, words * 4));
-    const size_t scratch_need = (size_t)n_queues * ((size_t)1 << slots_log2) * N * sizeof(cx<T>);
-    if (scratch_need > ((size_t)512 << 20)) { printf("scratch too small\n"); return; }
+    const size_t scratch_need = (size_t)n_queues * (size_t)slots * N * sizeof(cx<T>);
+    if (scratch_need > ((size_t)2048 << 20)) { printf("scratch too small\n"); return; }
     xcd_args x{};
     x.a = args_a(in, scratch, g_batch, true);
     x.b = args_b(scratch, out, g_batch, true);
-    x.ctl = ctl; x.batch = g_batch; x.n_queues = (int)n_queues; x.slots_log2 = slots_log2; x.map_log2 = map_log2;
-    x.lag = lag; x.lookahead = lookahead; x.max_iters = (unsigned)((g_batch + lag + lookahead + 2) * (N1 / Cfg::FPW + N2 / Cfg::FPW)); x.lds_ctl_off = (unsigned)(own - 16);
+    x.ctl = ctl; x.batch = g_batch; x.n_queues = (int)n_queues; x.slots = slots; x.map_log2 = map_log2;
+    x.lag = lag; x.lookahead = lookahead; x.max_iters = (unsigned)((g_batch + lag + lookahead + 2) * (N1 / Cfg::FPW + N2 / Cfg::FPW)); x.lds_ctl_off = (unsigned)(own - XCD_LDS_CTL_BYTES);
     unsigned long long* d_prof; CK(hipMalloc(&d_prof, 128)); x.prof = d_prof;
     std::vector<double> tt;
     unsigned long long bad = 0; unsigned tmo = 0;
@@ -202,7 +217,7 @@ int main() {
       if (rep == 0) CK(hipMemset(out, 0xff, total * sizeof(T)));
       CK(hipMemset(d_prof, 0, 128));
       CK(hipEventRecord(e0));
-      hipLaunchKernelGGL((stockham_xcd_fourstep_kernel<Cfg, Cfg, false, 1, 1>), dim3(grid), dim3(Cfg::WG), lds, 0, x);
+      hipLaunchKernelGGL((stockham_xcd_fourstep_kernel<Cfg, Cfg, false, 1, 1, TUNE_FREERUN, TUNE_OCCX>), dim3(grid), dim3(Cfg::WG), lds, 0, x);
       CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
       float ms; CK(hipEventElapsedTime(&ms, e0, e1)); if (rep) tt.push_back(ms);
       if (rep == 0) printf("   first launch %.3f ms\n", ms);
@@ -215,13 +230,18 @@ int main() {
         if (h[XCD_W_TIMEOUT]) printf("   rep %d: timeouts %u, first: site %u k %u want %u saw %u after %u polls\n", rep, h[XCD_W_TIMEOUT], h[XCD_W_TIMEOUT + 1],
                                      h[XCD_W_TIMEOUT + 2], h[XCD_W_TIMEOUT + 3], h[XCD_W_TIMEOUT + 4], h[XCD_W_TIMEOUT + 5]);
         CK(hipMemset(ctl + XCD_W_TIMEOUT, 0, 32));
-        unsigned dirty = 0; for (unsigned i = 0; i < words; ++i) if (i != XCD_W_TIMEOUT && h[i] != 0) ++dirty;
+        unsigned dirty = 0;
+        const unsigned qw = xcd_queue_words(slots, map_log2), mw = 4u << map_log2;
+        for (unsigned i = 0; i < words; ++i) {
+          const bool map_word = i >= XCD_W_QUEUES && (i - XCD_W_QUEUES) % qw >= 32u && (i - XCD_W_QUEUES) % qw < 32u + mw;
+          if (!map_word && i != XCD_W_EPOCH && (i < XCD_W_TIMEOUT || i >= XCD_W_QUEUES) && h[i] != 0) ++dirty;
+        }
         if (dirty) printf("   !! control block not clean after the launch: %u words\n", dirty);
       }
     }
     CK(hipGetLastError());
     const double ms = median(tt);
-    printf("XCD-local  S=%2d lag=%d look=%d  %d WG/CU (grid %4u, lds %6zu)  %.3f ms = %.3f of 8 TB/s  min %.3f  %s\n", 1 << slots_log2, lag, lookahead,
+    printf("XCD-local  S=%2d lag=%d look=%d  %d WG/CU (grid %4u, lds %6zu)  %.3f ms = %.3f of 8 TB/s  min %.3f  %s\n", slots, lag, lookahead,
            per_cu, grid, lds, ms, bytes / (ms * 1e-3) / 8e12, *std::min_element(tt.begin(), tt.end()),
            (bad || tmo) ? "!! MISMATCH / TIMEOUT" : "bit-identical");
     if (bad || tmo) printf("   !! %llu mismatching words, timeouts %u\n", bad, tmo);
@@ -229,27 +249,23 @@ int main() {
     if (verbose) {
       unsigned long long h[16]; CK(hipMemcpy(h, d_prof, 128, hipMemcpyDeviceToHost));
       const double tot = (double)h[0], na = (double)h[8], nb = (double)h[11];
-      printf("   wave-0 cycles (100 MHz ticks), share of work-group lifetime: claim wait %.1f %%, slot wait (A) %.1f %%, input wait (B) %.1f %%, A pass0 %.1f %%, duties %.1f %%, A rest %.1f %%, A store drain %.1f %%, B pass0 %.1f %%, B rest %.1f %%\n",
-             100 * h[1] / tot, 100 * h[2] / tot, 100 * h[3] / tot, 100 * h[4] / tot, 100 * h[5] / tot, 100 * h[6] / tot, 100 * h[7] / tot, 100 * h[9] / tot, 100 * h[10] / tot);
-      printf("   per task (us): A: slot wait %.2f pass0 %.2f duties %.2f rest %.2f drain %.2f | B: input wait %.2f pass0 %.2f rest %.2f | claim wait per iteration %.2f; null iterations %llu; lifetime per WG %.1f us\n",
-             h[2] / na / 100, h[4] / na / 100, h[5] / na / 100, h[6] / na / 100, h[7] / na / 100, h[3] / nb / 100, h[9] / nb / 100, h[10] / nb / 100,
-             h[1] / (na + nb + h[12]) / 100, h[12], tot / grid / 100);
+      printf("   wave 0, per task (us): A: pass0 %.2f middle %.2f slot wait %.2f last pass %.2f store drain %.2f | B: input wait %.2f pass0 %.2f rest %.2f | claim wait per iteration %.2f; null iterations %llu; lifetime per WG %.1f us; waits %.1f %% of it\n",
+             h[4] / na / 100, h[5] / na / 100, h[2] / na / 100, h[6] / na / 100, h[7] / na / 100, h[3] / nb / 100, h[9] / nb / 100, h[10] / nb / 100,
+             h[1] / (na + nb + h[12]) / 100, h[12], tot / grid / 100, 100.0 * (h[1] + h[2] + h[3]) / tot);
     }
 #endif
     CK(hipFree(d_prof));
     (void)verbose;
     CK(hipFree(ctl));
   };
-  const int slots_log2 = getenv("TUNE_SLOTS_LOG2") ? atoi(getenv("TUNE_SLOTS_LOG2")) : 3;
+  const int slots_log2 = getenv("TUNE_SLOTS") ? atoi(getenv("TUNE_SLOTS")) : 8;
   const int lag = getenv("TUNE_LAG") ? atoi(getenv("TUNE_LAG")) : 3;
   const int look = getenv("TUNE_LOOKAHEAD") ? atoi(getenv("TUNE_LOOKAHEAD")) : 4;
   const int wpc = getenv("TUNE_WG_PER_CU") ? atoi(getenv("TUNE_WG_PER_CU")) : 0;
   run(slots_log2, lag, look, wpc, true);
   if (getenv("TUNE_SWEEP")) {
-    for (int w : {2, 3, 4}) for (int sl : {2, 3, 4}) for (int lg : {1, 2, 3, 5, 8, 12}) {
-      if (lg >= (1 << sl)) continue;  // a stage-B ticket `lag` behind needs its slot still intact
-      run(sl, lg, look, w, true);
-    }
+    const int pts[][2] = {{3, 2}, {4, 2}, {4, 3}, {5, 3}, {5, 4}, {6, 4}, {6, 5}, {8, 5}, {8, 7}, {12, 8}, {16, 8}};
+    for (int w : {2, 3, 4}) for (auto& pt : pts) run(pt[0], pt[1], look, w, true);  // slots > lag
   }
   return 0;
 }
