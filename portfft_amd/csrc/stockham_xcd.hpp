@@ -155,8 +155,8 @@ constexpr unsigned XCD_UNKNOWN = 0xFFFFFFFFu;  // a claim-map entry that was not
 ///
 /// Control traffic stays off the tasks' critical path: thread 0 keeps the work-group TWO tickets ahead -- while ticket
 /// t is processed it already knows t' (the next one), looks up t' 's claim-map entry and hand-off counter (memory round
-/// trips of 0.5-1.6 us under load), takes t'' and publishes {t', transform, counter value} in LDS behind pass 0's
-/// barrier.  A wave polls for itself only when the published value was not yet sufficient.  A stage-A task waits for
+/// trips of 0.5-1.6 us under load) BEHIND the task's own pass-0 loads, takes t'' and publishes {t', transform, counter
+/// value} in LDS behind pass 0's barrier.  A wave polls for itself only when the published value was not yet sufficient.  A stage-A task waits for
 /// its slot only in front of its LAST pass (the stores), so a slot's previous occupant may still be read while the
 /// task loads and computes: the ring needs lag + 1 slots, not lag + (task length in ticket batches).
 template <typename CfgA_, typename CfgB_, bool BWD, int STW, int TIN, int FREERUN = 0, int OCCX = CfgA_::OCC>
@@ -243,24 +243,30 @@ __global__ __launch_bounds__(CfgA_::WG, OCCX) void stockham_xcd_fourstep_kernel(
       int k;
       decode(t, &kl, &r, &is_a, &k);
       const bool has_next = left != 1;  // a further iteration follows (its ticket is t_next)
-      // ---- thread 0: take the ticket two ahead, look up the next one's claim and counter (used in duties())
+      // ---- thread 0: take the ticket two ahead, look up the next one's claim and counter (used in duties()).  Issued
+      // BEHIND the task's own pass-0 loads: a wave's memory operations return in order, and these go to the memory side
+      // (0.5-2 us under load) -- in front of the loads they set the floor of wave 0's wait for its data (measured, fp32
+      // 256 x 256: 1.90 -> 1.49 ms; tools/probes/xcd_ci.sh).  Keeping the work-group three tickets ahead and issuing
+      // them one task early costs more in carried registers than it saves (1.49 -> 1.68 ms).
       unsigned t2 = 0;
       xcd_u4 e1 = {0u, 0u, 0u, 0u};
       unsigned d1 = 0, k1u = 0;
       bool real1 = false;
-      if (threadIdx.x == 0 && has_next) {
-        if (left < 0) t2 = xcd_take(ticket);
-        unsigned kl1, r1;
-        bool a1;
-        int k1;
-        decode(t_next, &kl1, &r1, &a1, &k1);
-        real1 = k1 >= 0;
-        if (real1 && FREERUN != 1) {
-          k1u = static_cast<unsigned>(k1);
-          e1 = xcd_map_load(map, M, k1u);
-          d1 = __hip_atomic_load(done + (k1u % S) * 64u + (a1 ? 32u : 0u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      auto control_issue = [&]() PFA_LAMBDA {
+        if (threadIdx.x == 0 && has_next) {
+          if (left < 0) t2 = xcd_take(ticket);
+          unsigned kl1, r1;
+          bool a1;
+          int k1;
+          decode(t_next, &kl1, &r1, &a1, &k1);
+          real1 = k1 >= 0;
+          if (real1 && FREERUN != 1) {
+            k1u = static_cast<unsigned>(k1);
+            e1 = xcd_map_load(map, M, k1u);
+            d1 = __hip_atomic_load(done + (k1u % S) * 64u + (a1 ? 32u : 0u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
         }
-      }
+      };
       // Duties of thread 0 in the middle of a task (a barrier follows): publish the next iteration's record, and -- the
       // first ticket of a batch -- claim the transform `lookahead` batches ahead.  Claims of a queue are chained: entry kc
       // is claimed after entry kc - 1 has been published, so "no transform left" is monotone in the local index (the
@@ -304,7 +310,12 @@ __global__ __launch_bounds__(CfgA_::WG, OCCX) void stockham_xcd_fourstep_kernel(
         long long c0, nlive;
         if (is_a) {
           const auto io = strided_group<CfgA, 0>(x.a, gid * TA + r, f, &live, &c0, &nlive, 0, sbase);
-          strided_pass<CfgA, BWD, STW, 0, decltype(io)>(io, x.a, f, tid, live, c0, lds, tw_a, nlive);
+          {
+            cx<T> cur[CfgA::bpt(0)][CfgA::Seq::r[0]];
+            strided_pass0_load<CfgA, BWD>(io, x.a, f, tid, live, cur);
+            control_issue();
+            strided_pass0_compute<CfgA, 0, 0>(cur, f, tid, lds);
+          }
           PFA_XCD_STAMP(p_p0);
           PFA_XCD_ACC(4, p_claimed, p_p0);
           duties();
@@ -333,7 +344,15 @@ __global__ __launch_bounds__(CfgA_::WG, OCCX) void stockham_xcd_fourstep_kernel(
           PFA_XCD_STAMP(p_dep);
           PFA_XCD_ACC(3, p_claimed, p_dep);
           const auto io = strided_group<CfgB, 0>(x.b, gid * TB + (r - TA), f, &live, &c0, &nlive, sbase, 0);
-          strided_pass<CfgB, BWD, 0, 0, decltype(io), false, false, TIN>(io, x.b, f, tid, live, c0, lds, tw_b, nlive);
+          {
+            unsigned f0 = f, tid0 = tid;
+            bool live0 = live;
+            if constexpr (TIN != 0) tin_lanes<CfgB, TIN>(&f0, &tid0, &live0, nlive);
+            cx<T> cur[CfgB::bpt(0)][CfgB::Seq::r[0]];
+            strided_pass0_load<CfgB, BWD>(io, x.b, f0, tid0, live0, cur);
+            control_issue();
+            strided_pass0_compute<CfgB, TIN, 0>(cur, f0, tid0, lds);
+          }
           PFA_XCD_STAMP(p_p0);
           PFA_XCD_ACC(9, p_dep, p_p0);
           // behind pass 0's barrier every wave has its input in registers: the slot is read
@@ -345,6 +364,7 @@ __global__ __launch_bounds__(CfgA_::WG, OCCX) void stockham_xcd_fourstep_kernel(
           PFA_XCD_CNT(11);
         }
       } else {
+        control_issue();
         duties();
         __syncthreads();
         PFA_XCD_CNT(12);
