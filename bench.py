@@ -17,7 +17,8 @@ Timing: the K timed steps run back to back between barrier + synchronize on both
 on the plan's stream (-> `roofline.kernel_ms`, `roofline.achieved`), so the event records never sit in the timed region.
 
 --config selects the other single-GPU workloads with the same JSON fields: c3 / c5 (BASELINE configs[2] / [4]) and
-the reference's own bench set ref16 / ref256 / ref4096 / ref65536 (test/bench/portfft/bench_float.cpp:49-52).
+the reference's own bench set ref16 / ref256 / ref4096 / ref65536 (test/bench/portfft/bench_float.cpp:49-52), its
+odd-composite regression sizes ref9800 / ref15360 / ref68640 and the four-step sizes g32_* / g64_16.
 """
 import argparse
 import glob
@@ -46,6 +47,11 @@ WORKLOADS = {
     "ref256": ([256], 512 * 1024, "f32", "reference bench set medium_small_1d: fp32 N=256 batch=512Ki", 1),
     "ref4096": ([4096], 32 * 1024, "f32", "reference bench set medium_large_1d: fp32 N=4096 batch=32Ki", 1),
     "ref65536": ([65536], 2048, "f32", "reference bench set large_1d: fp32 N=65536 batch=2Ki", 2),
+    # the reference's odd-composite GLOBAL-tier regression sizes (test/unit_test/instantiate_fft_tests.hpp:153-157),
+    # 1 GiB per buffer
+    "ref9800": ([9800], 13312, "f32", "reference GlobalTest regression size: fp32 N=9800 (2^3 5^2 7^2) batch=13Ki", 1),
+    "ref15360": ([15360], 8704, "f32", "reference GlobalTest regression size: fp32 N=15360 (2^10 3 5) batch=8.5Ki", 1),
+    "ref68640": ([68640], 1920, "f32", "reference GlobalTest regression size: fp32 N=68640 (2^5 3 5 11 13) batch=1920", 2),
     # the reference's GLOBAL-tier sizes (test/unit_test/instantiate_fft_tests.hpp:147-151) and the fp32 four-step sizes
     # beyond them, 1 GiB per buffer
     "g32_15": ([32768], 4096, "f32", "fp32 four-step N=32768 batch=4Ki (reference GlobalTest size)", 2),
@@ -96,8 +102,9 @@ def cpu_baseline(n, sample_seconds=10.0):
     """CPU baselines on this host's cores, bounded samples of the headline workload (fp32 C2C forward, length n):
       value                  the oracle (oracle/: the reference's algorithm restated in C, kind 'port'), OpenMP over
                              transforms on every core.  It EMULATES the reference's sub-group lanes one by one (that is
-                             what makes it a faithful restatement), which costs ~100x per core against a tuned CPU FFT:
-                             it is the parity checker timed, not a statement about CPU FFT speed.
+                             what makes it a faithful restatement), which costs 15-20x against a tuned CPU FFT on the
+                             same cores (the JSON note carries the ratio of the run): it is the parity checker timed,
+                             not a statement about CPU FFT speed.
       numpy_allcore_gflops   NumPy's pocketfft on every core (a process pool over batch slices): what this host's
                              CPUs do on the same transforms with a production CPU library."""
     import multiprocessing as mp
@@ -138,8 +145,9 @@ def cpu_baseline(n, sample_seconds=10.0):
     return {"value": round(gflops, 3), "unit": "GFLOP/s", "cores": cores, "kind": "port",
             "numpy_1core_gflops": round(numpy_1, 3),
             "numpy_allcore_gflops": None if numpy_all is None else round(numpy_all, 3), "numpy_cores": workers,
-            "note": "oracle emulates the reference's sub-group lanes one by one (parity checker, ~100x slower per "
-                    "core than pocketfft); numpy_allcore_gflops is the credible CPU figure for this host",
+            "note": "oracle emulates the reference's sub-group lanes one by one (parity checker: %s as slow as pocketfft "
+                    "on the same cores in this run); numpy_allcore_gflops is the credible CPU figure for this host"
+                    % ("unknown" if not numpy_all else "%.0fx" % (numpy_all / max(gflops, 1e-9))),
             "sample": "oracle/ (reference algorithm restated in C, OpenMP over transforms), fp32 C2C forward N=%d, "
                       "batch=%d of the 65536 x %d passes, %.1f s; numpy: 256 transforms per worker, 3 s"
                       % (n, batch, reps, total)}
@@ -160,25 +168,36 @@ def kernel_label(plan, lengths):
 
 def spawn_ranks(args):
     """`python bench.py --gpus N` without a torch.distributed.run environment: start the N ranks as a CHILD process
-    (never exec: this process may not have touched the GPU yet, and must not be replaced either way) and relay."""
-    port = os.environ.get("PFFT_BENCH_PORT", str(29500 + (os.getpid() % 400)))
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
-           "--master-addr", "127.0.0.1", "--master-port", port, os.path.abspath(__file__), "--gpus", str(args.gpus),
-           "--steps", str(args.steps), "--warmup", str(args.warmup), "--config", args.config]
-    if args.no_cpu_baseline:
-        cmd.append("--no-cpu-baseline")
-    if args.manual is not None:
-        cmd += ["--manual", args.manual, "--precision", args.precision]
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
-    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
-    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
-    for ln in p.stdout.splitlines():
-        if not ln.startswith("{"):
-            print(ln, file=sys.stderr)
-    if lines:
-        print(lines[-1])
-    return p.returncode if p.returncode != 0 or lines else 1
+    (never exec: this process may not have touched the GPU yet, and must not be replaced either way) and relay.  A
+    rendezvous port that is taken (another job on the node) is retried with a fresh child on another port."""
+    base = int(os.environ.get("PFFT_BENCH_PORT", str(29500 + (os.getpid() % 400))))
+    rc = 1
+    for attempt in range(4):
+        port = str(base + 997 * attempt)
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", port, os.path.abspath(__file__), "--gpus", str(args.gpus),
+               "--steps", str(args.steps), "--warmup", str(args.warmup), "--config", args.config]
+        if args.no_cpu_baseline:
+            cmd.append("--no-cpu-baseline")
+        if args.manual is not None:
+            cmd += ["--manual", args.manual, "--precision", args.precision]
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+        lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+        sys.stderr.write(p.stderr)
+        for ln in p.stdout.splitlines():
+            if not ln.startswith("{"):
+                print(ln, file=sys.stderr)
+        if lines:
+            print(lines[-1])
+            return p.returncode
+        rc = p.returncode if p.returncode != 0 else 1
+        err = p.stderr.lower()
+        if not ("address already in use" in err or "eaddrinuse" in err or "errno: 98" in err):
+            break
+        print("bench.py: rendezvous port %s is taken, retrying on another one" % port, file=sys.stderr)
+    return rc
 
 
 def main():
@@ -189,8 +208,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--config", default="c2", choices=sorted(WORKLOADS),
                     help="c2 (default, the headline line); c3 / c5: the other single-GPU configs of BASELINE.json; "
-                         "ref16 / ref256 / ref4096 / ref65536: the reference's own bench set; g32_* / g64_16: four-step "
-                         "(GLOBAL tier) sizes")
+                         "ref16 / ref256 / ref4096 / ref65536: the reference's own bench set; ref9800 / ref15360 / "
+                         "ref68640: its odd-composite regression sizes; g32_* / g64_16: four-step (GLOBAL tier) sizes")
     ap.add_argument("--manual", metavar="KEY=VALUE,...",
                     help="any descriptor, in the grammar of the reference's bench_manual_float / bench_manual_double "
                          "(register_manual_bench.hpp), e.g. d=cpx,n=1024x1024,b=64,s=split,p=ip; overrides --config")
@@ -241,9 +260,14 @@ def main():
     # plumbing on a single-GPU box (every rank on device 0)
     one_device = os.environ.get("PFFT_BENCH_ONE_DEVICE") == "1"
     backend = os.environ.get("PFFT_BENCH_BACKEND", "nccl")
+    if distributed and not one_device and torch.cuda.device_count() < world:
+        sys.exit("bench.py: rank %d of %d, but this process sees %d GPU(s) (HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES?): "
+                 "one process per GPU needs WORLD_SIZE <= visible devices" % (rank, world, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank if (distributed and not one_device) else 0)
     dev = torch.device("cuda", torch.cuda.current_device())
     pg = process_group(backend, dev)  # RCCL communicator created and probed here, before any timing
+    if pg.fallback_reason:
+        print("bench.py rank %d: control collectives fall back from RCCL: %s" % (rank, pg.fallback_reason), file=sys.stderr)
     # weak scaling: the global batch is batch_per_gpu * world transforms, sharded contiguously, no data-path collective
     lo, hi = shard_range(batch_per_gpu * world, world, rank)
     assert hi - lo == batch_per_gpu
@@ -365,6 +389,7 @@ def main():
         worst = max(worst, float(np.linalg.norm(got - ref) / np.linalg.norm(ref)))
     assert worst < 1e-4, "parity check failed: rel-L2 %g" % worst
 
+    straggler_exit = 0
     if rank == 0:
         flops_per_step = 5.0 * n * math.log2(n) * batch_per_gpu * world
         gflops = flops_per_step / (elapsed / args.steps) / 1e9
@@ -394,7 +419,9 @@ def main():
                        "per_rank_elapsed_ms": [round(r[0] * 1e3, 3) for r in per_rank],
                        "parity_rel_l2_vs_numpy": worst},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
+                         "frac": round(achieved / HBM_PEAK_GBS, 4),
+                         "frac_wall": round(alg_bytes / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 4),
+                         "traffic": traffic, "traffic_source": traffic_src,
                          "traffic_matches_plan": None if traffic_label is None else traffic_label == live_label,
                          "kernel": live_label, "hbm_passes_per_execute": launches,
                          "launches_per_execute": int(plan.info().launches[0]),
@@ -413,8 +440,19 @@ def main():
             result["config"]["rccl_fallback_reason"] = pg.fallback_reason
         if cpu is not None:
             result["cpu_baseline"] = cpu
+        # `value` is taken on the slowest rank; a straggler would hide in that max: name it
+        times = sorted(r[0] for r in per_rank)
+        median = times[len(times) // 2]
+        slow = [i for i, r in enumerate(per_rank) if r[0] > 1.15 * median]
+        if world > 1 and slow:
+            result["config"]["stragglers"] = {"ranks": slow, "median_ms": round(median * 1e3, 3)}
+            print("bench.py: rank(s) %s took more than 1.15x the median step time (%.3f ms)" % (slow, median * 1e3),
+                  file=sys.stderr)
+            straggler_exit = 3 if os.environ.get("PFFT_BENCH_STRAGGLER_FATAL") == "1" else 0
         print(json.dumps(result))
     pg.close()
+    if straggler_exit:
+        sys.exit(straggler_exit)
 
 
 if __name__ == "__main__":

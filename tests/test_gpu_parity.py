@@ -115,6 +115,14 @@ def test_reference_size_grid_all_layouts(prec, oracle):
                         d = _layout_desc(G, n, prec, batch, place, lin, lout, F, storage)
                         got, _ = G.transform_packed(d, pf.direction.FORWARD, x)
                         _check(got, y, n, dtype, ("fwd", prec, n, batch, place, lin, lout, storage))
+    # SubgroupRegressionTest (instantiate_fft_tests.hpp:114-118): in-place BATCH_INTERLEAVED, interleaved storage,
+    # lengths 80 / 100 x batches 44 / 100
+    for n in (80, 100):
+        for batch in (44, 100):
+            x, y = H.gen_fourier_data(batch, [n], dtype)
+            d = _layout_desc(G, n, prec, batch, 0, "BI", "BI", F, 0)
+            got, _ = G.transform_packed(d, pf.direction.FORWARD, x)
+            _check(got, y, n, dtype, ("subgroup regression", prec, n, batch))
     # oracle cross-check on a few mid sizes (seeded inputs, same data on both sides)
     for n, batch in [(64, 3), (1024, 3), (4096, 3), (8192, 1)]:
         x, _ = H.gen_fourier_data(batch, [n], dtype, seed=3)
@@ -327,18 +335,19 @@ def test_wave64_prime_factors(prec, oracle):
     _check(got.reshape(2, -1), y.reshape(2, -1), 41 * 53, dtype, ("wave64 primes 2-D", prec))
 
 
-def test_offsets():
-    """Offsets* suites (instantiate_fft_tests.hpp:187-218): data starts at an offset; everything before the
-    output offset must stay untouched"""
+@pytest.mark.parametrize("prec", ["f32", "f64"])
+def test_offsets(prec):
+    """Offsets* suites (instantiate_fft_tests.hpp:187-218; instantiated for float and double, :375-403): data starts at
+    an offset; everything before the output offset must stay untouched"""
     import gpu_utils as G
     pf = _pf()
-    dtype = np.complex64
+    dtype = np.complex64 if prec == "f32" else np.complex128
     for (fo, bo) in [(8, 8), (67, 67), (0, 2049), (2049, 0), (2047, 2049)]:
         for direction in (F, B):
             for place, lin, lout in ([(1, "P", "P"), (1, "P", "BI"), (1, "BI", "BI"), (1, "BI", "P")] +
                                      ([(0, "P", "P"), (0, "BI", "BI")] if fo == bo else [])):
                 x, y = H.gen_fourier_data(33, [2048], dtype)
-                d = _layout_desc(G, 2048, "f32", 33, place, lin, lout, direction, 0)
+                d = _layout_desc(G, 2048, prec, 33, place, lin, lout, direction, 0)
                 d.forward_offset, d.backward_offset = fo, bo
                 src, ref = (x, y) if direction == F else (y, x.astype(np.complex128) * 2048)
                 got, raw = G.transform_packed(d, pf.direction(direction), src)
@@ -348,16 +357,16 @@ def test_offsets():
                     assert np.all(raw[:out_off] == H.PADDING_VALUE), "padding before the offset was written"
     # OffsetsWIErrorRegressionTest / OffsetsMDErrorRegressionTest
     x, y = H.gen_fourier_data(33000, [8], dtype)
-    d = G.make_descriptor([8], batch=33000, fwd_offset=2047, bwd_offset=2049)
+    d = G.make_descriptor([8], prec, batch=33000, fwd_offset=2047, bwd_offset=2049)
     got, _ = G.transform_packed(d, pf.direction.FORWARD, x)
     _check(got, y, 8, dtype, "offsets wi")
     x, y = H.gen_fourier_data(2, [4, 4], dtype)
-    d = G.make_descriptor([4, 4], batch=2, fwd_offset=2, bwd_offset=0)
+    d = G.make_descriptor([4, 4], prec, batch=2, fwd_offset=2, bwd_offset=0)
     got, _ = G.transform_packed(d, pf.direction.FORWARD, x)
     _check(got.reshape(2, -1), y.reshape(2, -1), 16, dtype, "offsets md")
     x, y = H.gen_fourier_data(33, [16, 512], dtype)
     for place in (0, 1):
-        d = G.make_descriptor([16, 512], batch=33, placement=place, fwd_offset=67, bwd_offset=67)
+        d = G.make_descriptor([16, 512], prec, batch=33, placement=place, fwd_offset=67, bwd_offset=67)
         got, _ = G.transform_packed(d, pf.direction.FORWARD, x)
         _check(got.reshape(33, -1), y.reshape(33, -1), 8192, dtype, "offsets nd")
 
@@ -384,14 +393,16 @@ def _default_dist(lengths, strides):
     return int(np.prod([l * s for l, s in zip(lengths, strides)]))
 
 
-def test_strided_layouts():
-    """strided / UNPACKED suites (instantiate_fft_tests.hpp:237-319), both directions, both storages"""
+@pytest.mark.parametrize("prec", ["f32", "f64"])
+def test_strided_layouts(prec):
+    """strided / UNPACKED suites (instantiate_fft_tests.hpp:237-319) at the reference's own batch counts (1, 3, 33000),
+    both directions, both storages, float and double (:375-403)"""
     import gpu_utils as G
     pf = _pf()
-    dtype = np.complex64
-    cases = ([(c, (1, 3, 3300), 1) for c in H.STRIDED_OOP_CASES] +
+    dtype = np.complex64 if prec == "f32" else np.complex128
+    cases = ([(c, (1, 3, 33000), 1) for c in H.STRIDED_OOP_CASES] +
              [(c, (1, 10, 33), 1) for c in H.STRIDED_OOP_BATCH_INTERLEAVED_LIKE] +
-             [(c, (1, 3, 3300), 0) for c in H.STRIDED_IP_CASES] +
+             [(c, (1, 3, 33000), 0) for c in H.STRIDED_IP_CASES] +
              [(([3], [66], [66], 2, 2), (1, 3, 33), 0), (([6], [40], [40], 1, 1), (1, 3, 33), 0),
               (([75], [66], [66], 2, 2), (1, 3, 33), 0), (([96], [40], [40], 1, 1), (1, 3, 33), 0),
               (([8], [2], [2], 2, 2), (1,), 1), (([8], [1], [1], 1, 1), (1,), 0),
@@ -403,10 +414,10 @@ def test_strided_layouts():
         for batch in batches:
             x, y = H.gen_fourier_data(batch, lengths, dtype)
             for storage in (0, 1):
-                d = G.make_descriptor(lengths, "f32", batch=batch, storage=storage, placement=place, fwd_strides=fs,
+                d = G.make_descriptor(lengths, prec, batch=batch, storage=storage, placement=place, fwd_strides=fs,
                                       bwd_strides=bs, fwd_distance=fd, bwd_distance=bd)
                 got, _ = G.transform_packed(d, pf.direction.FORWARD, x)
-                _check(got, y, n, dtype, ("strided fwd", lengths, fs, bs, fd, bd, batch, storage))
+                _check(got, y, n, dtype, ("strided fwd", prec, lengths, fs, bs, fd, bd, batch, storage))
                 got, _ = G.transform_packed(d, pf.direction.BACKWARD, y)
                 _check(got, x.astype(np.complex128) * n, n, dtype, ("strided bwd", lengths, fs, bs, fd, bd, batch))
 
@@ -477,7 +488,10 @@ def test_unpacked_layouts_any_length():
     pf = _pf()
     cases = [("f32", 4096, 1, 4160, 1, 4160), ("f32", 4096, 1, 4160, 1, 4096), ("f32", 4096, 2, 8200, 1, 4096),
              ("f32", 1200, 1, 1280, 3, 3700), ("f32", 64, 1, 80, 1, 80), ("f32", 16, 3, 50, 1, 16),
-             ("f64", 4096, 1, 4100, 1, 4100), ("f64", 625, 2, 1300, 1, 640), ("f32", 8192, 1, 8200, 1, 8200)]
+             ("f32", 16, 1, 20, 1, 20),
+             ("f64", 4096, 1, 4100, 1, 4100), ("f64", 625, 2, 1300, 1, 640), ("f32", 8192, 1, 8200, 1, 8200),
+             ("f64", 4096, 1, 4160, 1, 4096), ("f64", 4096, 2, 8200, 1, 4096), ("f64", 1200, 1, 1280, 3, 3700),
+             ("f64", 64, 1, 80, 1, 80), ("f64", 16, 3, 50, 1, 16), ("f64", 16, 1, 20, 1, 20)]
     for prec, n, fs, fd, bs, bd in cases:
         dtype = np.complex64 if prec == "f32" else np.complex128
         for batch in (1, 6, 33):
