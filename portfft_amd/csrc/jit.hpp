@@ -33,7 +33,20 @@ struct wg_params {
 /// Planner of the packed work-group tier for an arbitrary length: radix sequence (fewest LDS exchanges, balanced
 /// radices), lanes per FFT (least idle lanes in ragged passes), FFTs per work-group, padding, I/O staging.
 /// Returns false when `n` has a prime factor above 31 or does not fit `max_lds`.
-bool choose_spec_params(int precision, long long n, size_t max_lds, wg_params* out);
+/// forced_radices (measured planning, below): that radix sequence instead of the planner's own (product n, every radix a
+/// supported butterfly, at most MAX_PASSES of them -- otherwise ignored)
+bool choose_spec_params(int precision, long long n, size_t max_lds, wg_params* out,
+                        const std::vector<int>* forced_radices = nullptr);
+
+/// Measured planning (opt-in, PFFT_PLAN_MEASURE=1; the reference's rule is static, committed_descriptor_impl.hpp:210-313):
+/// the radix sequences the planner ranks highest for a packed length, in the orders worth timing -- the planner's own
+/// choice first.  plan.cpp times them on the plan's stream at commit and records the winner.
+std::vector<std::vector<int>> spec_radix_candidates(int precision, long long n, size_t max_lds, int max_candidates = 14);
+bool plan_measure_enabled();
+/// the recorded choice for (arch, precision, n): process table, then the JIT cache directory
+/// (`choice_<arch>_<f32|f64>_<n>.txt`, next to the code objects); empty when there is none
+std::vector<int> plan_choice_lookup(const std::string& arch, int precision, long long n);
+void plan_choice_store(const std::string& arch, int precision, long long n, const std::vector<int>& radices);
 
 /// Same for the strided tier (FPW adjacent FFTs side by side); `inner_count` is the number of adjacent FFTs the
 /// stage offers (narrow stages get narrower groups).
@@ -90,7 +103,9 @@ bool jit_enabled();
 /// plan_only: return the entry with its parameters without compiling the packed form (other forms of the same
 /// configuration are built from it: jit_unpacked_kernel).
 const spec_kernel* jit_spec_kernel(int precision, long long n, bool split, size_t max_lds, std::string* why,
-                                   bool plan_only = false);
+                                   bool plan_only = false, const std::vector<int>* forced_radices = nullptr);
+/// gfx name of the current device ("gfx950"), as the runtime compiler targets it
+std::string jit_device_arch();
 
 /// Runtime-compiled strided kernel; `store_modifier` / `split_mode` select the variant to make available
 /// (split_mode: 0 interleaved, 1 split on both sides, 2 split input + store modifier (four-step stage A on

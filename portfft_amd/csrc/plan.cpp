@@ -561,9 +561,110 @@ struct plan_t {
   const spec_kernel* get_spec(long long n) {
     if (const spec_kernel* k = find_spec(n)) return k;
     std::string why;
-    const spec_kernel* k = jit_spec_kernel(desc.precision, n, desc.complex_storage == PFFT_SPLIT_COMPLEX, max_lds, &why);
+    const bool split = desc.complex_storage == PFFT_SPLIT_COMPLEX;
+    if (plan_measure_enabled() && jit_enabled() && getenv("PFFT_JIT_SPEC_RADICES") == nullptr) {
+      const std::vector<int> choice = measured_radices(n);
+      if (!choice.empty()) {
+        if (const spec_kernel* k = jit_spec_kernel(desc.precision, n, split, max_lds, &why, false, &choice)) return k;
+      }
+    }
+    const spec_kernel* k = jit_spec_kernel(desc.precision, n, split, max_lds, &why);
     if (k == nullptr) jit_note("packed", n, why);
     return k;
+  }
+
+  /// Measured planning (PFFT_PLAN_MEASURE=1; the reference's rule is static, committed_descriptor_impl.hpp:210-313): the
+  /// radix sequence of a runtime-specialised packed length is the fastest of the planner's top candidates
+  /// (jit.cpp: spec_radix_candidates), timed here on the plan's stream over 256 MiB of random data, and recorded next to
+  /// the code objects in the JIT cache -- later commits (this process or another) read the record instead of measuring.
+  std::vector<int> measured_radices(long long n) {
+    const std::string arch = jit_device_arch();
+    std::vector<int> choice = plan_choice_lookup(arch, desc.precision, n);
+    if (!choice.empty()) return choice;
+    const std::vector<std::vector<int>> cands = spec_radix_candidates(desc.precision, n, max_lds);
+    if (cands.empty()) return choice;
+    if (cands.size() == 1) {
+      plan_choice_store(arch, desc.precision, n, cands[0]);
+      return cands[0];
+    }
+    const size_t eb = elem_bytes();
+    const long long batch = std::max<long long>(1, static_cast<long long>((size_t{256} << 20) / (static_cast<size_t>(n) * eb)));
+    const size_t bytes = static_cast<size_t>(batch) * static_cast<size_t>(n) * eb;
+    void *in = nullptr, *out = nullptr;
+    if (hipMalloc(&in, bytes) != hipSuccess || hipMalloc(&out, bytes) != hipSuccess) {
+      if (in != nullptr) (void)hipFree(in);
+      return choice;  // no room to measure: the static rule
+    }
+    {  // uniform(-1, 1) data: a 1 MiB host block replicated by doubling copies
+      const size_t block = std::min<size_t>(bytes, size_t{1} << 20);
+      std::vector<unsigned char> h(block);
+      unsigned long long z = 0x9E3779B97F4A7C15ull;
+      const size_t scalars = block / static_cast<size_t>(scalar_bytes());
+      for (size_t i = 0; i < scalars; ++i) {
+        z = z * 6364136223846793005ull + 1442695040888963407ull;
+        const double v = static_cast<double>(z >> 11) * (2.0 / 9007199254740992.0) - 1.0;
+        if (scalar_bytes() == 8) {
+          reinterpret_cast<double*>(h.data())[i] = v;
+        } else {
+          reinterpret_cast<float*>(h.data())[i] = static_cast<float>(v);
+        }
+      }
+      hip_check(hipMemcpyAsync(in, h.data(), block, hipMemcpyHostToDevice, stream), "hipMemcpy");
+      hip_check(hipStreamSynchronize(stream), "hipStreamSynchronize");
+      for (size_t have = block; have < bytes; have *= 2) {
+        hip_check(hipMemcpyAsync(static_cast<char*>(in) + have, in, std::min(have, bytes - have), hipMemcpyDeviceToDevice, stream),
+                  "hipMemcpy");
+      }
+    }
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    hip_check(hipEventCreate(&e0), "hipEventCreate");
+    hip_check(hipEventCreate(&e1), "hipEventCreate");
+    double best_ms = 1e30;
+    for (const std::vector<int>& r : cands) {
+      std::string why;
+      const spec_kernel* k = jit_spec_kernel(desc.precision, n, false, max_lds, &why, false, &r);
+      if (k == nullptr) continue;
+      void* tw = nullptr;
+      {
+        std::vector<char> host;
+        if (desc.precision == PFFT_PRECISION_F64) {
+          const auto t = host_twiddles<double>(r);
+          host.assign(reinterpret_cast<const char*>(t.data()), reinterpret_cast<const char*>(t.data() + t.size()));
+        } else {
+          const auto t = host_twiddles<float>(r);
+          host.assign(reinterpret_cast<const char*>(t.data()), reinterpret_cast<const char*>(t.data() + t.size()));
+        }
+        if (hipMalloc(&tw, host.size()) != hipSuccess) continue;
+        hip_check(hipMemcpy(tw, host.data(), host.size(), hipMemcpyHostToDevice), "hipMemcpy(twiddles)");
+      }
+      const long long groups = (batch + k->fpw - 1) / k->fpw;
+      const unsigned grid = persistent_grid(nullptr, k->mfn[0], k->wg, k->lds_bytes, groups, k->groups_per_wg);
+      float ms = 0.f;
+      bool ok = true;
+      for (int rep = 0; rep < 11 && ok; ++rep) {
+        if (rep == 3) ok = hipEventRecord(e0, stream) == hipSuccess;
+        ok = ok && jit_launch_spec(k, stream, grid, in, out, tw, batch, 1.0, 0) == hipSuccess;
+      }
+      ok = ok && hipEventRecord(e1, stream) == hipSuccess && hipEventSynchronize(e1) == hipSuccess &&
+           hipEventElapsedTime(&ms, e0, e1) == hipSuccess;
+      (void)hipFree(tw);
+      if (getenv("PFFT_JIT_VERBOSE") != nullptr) {
+        std::string rs;
+        for (int x : r) rs += std::to_string(x) + ".";
+        std::fprintf(stderr, "[portfft_amd plan] n=%lld radices %s %.3f ms per %lld transforms%s\n", n, rs.c_str(), ms / 8,
+                     batch, ok ? "" : " (failed)");
+      }
+      if (ok && ms < best_ms) {
+        best_ms = ms;
+        choice = r;
+      }
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    (void)hipFree(in);
+    (void)hipFree(out);
+    if (!choice.empty()) plan_choice_store(arch, desc.precision, n, choice);
+    return choice;
   }
 
   /// work-group loop trips of a strided stage (stockham_strided.hpp: strided_ngroups)

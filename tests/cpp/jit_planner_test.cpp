@@ -154,6 +154,35 @@ int main(int argc, char** argv) {
       }
     }
   }
+  // measured planning (PFFT_PLAN_MEASURE): the candidates start with the planner's own choice, each is a valid plan of
+  // the length, and a recorded choice (process table / cache directory) is found again and honoured by the planner
+  {
+    for (long long n : {3000ll, 6000ll, 10080ll, 625ll, 15625ll}) {
+      pfa::wg_params base;
+      EXPECT(pfa::choose_spec_params(0, n, max_lds, &base), "n=%lld planned", n);
+      const auto cands = pfa::spec_radix_candidates(0, n, max_lds);
+      EXPECT(!cands.empty() && cands[0] == base.radices, "n=%lld first candidate is the static choice", n);
+      EXPECT(cands.size() >= 2 && cands.size() <= 14, "n=%lld %zu candidates", n, cands.size());
+      for (const auto& r : cands) {
+        long long prod = 1;
+        for (int x : r) prod *= x;
+        pfa::wg_params q;
+        EXPECT(prod == n && pfa::choose_spec_params(0, n, max_lds, &q, &r) && q.radices == r &&
+                   pfa::spec_lds_bytes(q) <= max_lds,
+               "n=%lld candidate", n);
+      }
+    }
+    const std::vector<int> pick = {24, 25, 10};
+    EXPECT(pfa::plan_choice_lookup("gfx000", 0, 6000).empty(), "no record yet");
+    pfa::plan_choice_store("gfx000", 0, 6000, pick);
+    EXPECT(pfa::plan_choice_lookup("gfx000", 0, 6000) == pick, "recorded choice found");
+    EXPECT(pfa::plan_choice_lookup("gfx000", 1, 6000).empty() && pfa::plan_choice_lookup("gfx000", 0, 3000).empty(),
+           "records are per precision and length");
+    pfa::wg_params q;
+    EXPECT(pfa::choose_spec_params(0, 6000, max_lds, &q, &pick) && q.radices == pick, "forced radices honoured");
+    const std::vector<int> bad = {24, 25, 11};
+    EXPECT(pfa::choose_spec_params(0, 6000, max_lds, &q, &bad) && q.radices != bad, "a sequence of another length is ignored");
+  }
   {
     long long compiled = 0, from_disk = 0;
     pfa::jit_stats(&compiled, &from_disk);

@@ -12,7 +12,10 @@ EXE = os.path.join(ROOT, "build", "facade_test")
 REF_SHAPE_EXE = os.path.join(ROOT, "build", "ref_shape_test")
 
 
-def _build(exe=EXE, source="facade_test.cpp"):
+MULTI_DEVICE_EXE = os.path.join(ROOT, "build", "multi_device_test")
+
+
+def _build(exe=EXE, source="facade_test.cpp", extra=()):
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     os.makedirs(os.path.dirname(exe), exist_ok=True)
     src = os.path.join(ROOT, "tests", "cpp", source)
@@ -20,7 +23,7 @@ def _build(exe=EXE, source="facade_test.cpp"):
             os.path.join(ROOT, "portfft_amd", "libportfft_amd.so")]
     if os.path.exists(exe) and os.path.getmtime(exe) > max(os.path.getmtime(d) for d in deps):
         return
-    subprocess.run([hipcc, "-std=c++17", "-O1", "-I", os.path.join(ROOT, "include"), src, "-L",
+    subprocess.run([hipcc, "-std=c++17", "-O1", *extra, "-I", os.path.join(ROOT, "include"), src, "-L",
                     os.path.join(ROOT, "portfft_amd"), "-lportfft_amd", "-Wl,-rpath," + os.path.join(ROOT, "portfft_amd"),
                     "-o", exe], check=True)
 
@@ -54,3 +57,27 @@ def test_reference_call_shapes_on_gpu():
     p = subprocess.run([REF_SHAPE_EXE], capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stdout + p.stderr
     assert "ref shape OK" in p.stdout
+
+
+def test_host_threads_race_through_the_host_api_and_the_runtime_compiler(tmp_path):
+    """tests/cpp/multi_device_test.cpp, "host" mode (no device): four threads at once through the descriptor entry
+    points, the thread-local error messages and the runtime compiler with a cold on-disk cache
+    (tools/sanitize_tsan.sh runs the same under ThreadSanitizer)"""
+    _build(MULTI_DEVICE_EXE, "multi_device_test.cpp", ("-pthread", "--offload-arch=gfx950"))
+    env = dict(os.environ, PFFT_JIT_CACHE_DIR=str(tmp_path))
+    p = subprocess.run([MULTI_DEVICE_EXE, "host"], capture_output=True, text=True, timeout=600, env=env)
+    assert p.returncode == 0, p.stdout + p.stderr
+    assert "multi device host OK" in p.stdout
+
+
+@pytest.mark.gpu
+def test_one_host_thread_per_device(tmp_path):
+    """SURVEY.md 8(e): per-GPU plans driven by their own host thread from ONE process -- one std::thread per visible
+    device (on a 1-GPU box: 4 threads x 4 streams of device 0), concurrent commits (hiprtc + a cold disk cache + the
+    XCD census), executes between barriers, sampled transforms against a host DFT, copies of every plan"""
+    _build(MULTI_DEVICE_EXE, "multi_device_test.cpp", ("-pthread", "--offload-arch=gfx950"))
+    env = dict(os.environ, PFFT_JIT_CACHE_DIR=str(tmp_path), PFFT_XCD_CHECK="1")
+    p = subprocess.run([MULTI_DEVICE_EXE], capture_output=True, text=True, timeout=900, env=env)
+    assert p.returncode == 0, p.stdout + p.stderr
+    assert "multi device OK" in p.stdout
+    print(p.stdout)

@@ -1,0 +1,72 @@
+"""Opt-in measured planning (PFFT_PLAN_MEASURE=1; plan.cpp measured_radices, jit.cpp spec_radix_candidates): the radix
+sequence of a runtime-specialised packed length is timed at commit and recorded in the JIT cache directory.  The
+reference's rule is static (src/portfft/committed_descriptor_impl.hpp:210-313); with the knob off nothing changes.
+Every case runs in a process of its own: the kernel and choice tables are per process."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+CHILD = r"""
+import json, sys
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import numpy as np, torch
+import gpu_utils as G, helpers as H
+n, batch = int(sys.argv[1]), 64
+plan = G.make_descriptor([n], "f32", batch=batch).commit()
+d = plan.info().dims[0]
+g = torch.Generator(device="cuda").manual_seed(1)
+x = torch.empty(batch * n, dtype=torch.complex64, device="cuda")
+torch.view_as_real(x).uniform_(-1, 1, generator=g)
+y = torch.empty_like(x)
+plan.compute_forward(x, y).wait()
+ref = np.fft.fft(x.view(batch, n)[5].cpu().numpy().astype(np.complex128))
+print(json.dumps({"factors": [int(d.factors[i]) for i in range(d.n_factors)], "tier": int(d.tier),
+                  "err": float(H.rel_l2(y.view(batch, n)[5].cpu().numpy(), ref))}))
+""" % (ROOT, os.path.join(ROOT, "tests"))
+
+
+def _commit(n, cache, measure, verbose=False):
+    env = dict(os.environ, PFFT_JIT_CACHE_DIR=str(cache))
+    env.pop("PFFT_PLAN_MEASURE", None)
+    if measure:
+        env["PFFT_PLAN_MEASURE"] = "1"
+    if verbose:
+        env["PFFT_JIT_VERBOSE"] = "1"
+    p = subprocess.run([sys.executable, "-c", CHILD, str(n)], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout + p.stderr
+    out = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    assert out["err"] <= 2e-6, out
+    return out["factors"], p.stderr
+
+
+def test_measured_choice_is_recorded_and_honoured(tmp_path):
+    n = 6000
+    static, _ = _commit(n, tmp_path / "a", measure=False)
+    assert not list((tmp_path / "a").glob("choice_*")), "nothing is recorded with the knob off"
+    measured, log = _commit(n, tmp_path / "b", measure=True, verbose=True)
+    assert log.count("[portfft_amd plan] n=%d" % n) >= 2, "the candidates were timed: " + log[-400:]
+    record = tmp_path / "b" / ("choice_gfx950_f32_%d.txt" % n)
+    assert record.exists() and [int(v) for v in record.read_text().split()] == measured
+    # another process, same cache directory: the record is read, nothing is timed, nothing is compiled
+    again, log2 = _commit(n, tmp_path / "b", measure=True, verbose=True)
+    assert again == measured and "[portfft_amd plan]" not in log2 and "[portfft_amd jit]" not in log2, log2[-400:]
+    # the knob off: the static rule, whatever the directory holds
+    off, _ = _commit(n, tmp_path / "b", measure=False)
+    assert off == static
+    # a hand-written record is honoured (this is the planner test of the cached choice on a device)
+    d = tmp_path / "c"
+    d.mkdir(mode=0o700)
+    rec = d / ("choice_gfx950_f32_%d.txt" % n)
+    rec.write_text("10 10 10 6\n")
+    rec.chmod(0o600)
+    forced, _ = _commit(n, d, measure=True)
+    assert forced == [10, 10, 10, 6]
+    rec.write_text("7 7 7\n")  # a record of another length is ignored
+    ignored, _ = _commit(n, d, measure=False)
+    assert ignored == static
