@@ -1,0 +1,54 @@
+#!/bin/bash
+# End-of-round artefacts (run through gpurun): bench lines of every config, rocprofv3 kernel stats and PMC traffic of the
+# multi-launch / four-step configs, the survey tables, commit latency.  Copy gpurun_out/final_r4/* into profiles/ with
+# tools/collect_r4.sh.
+set -u
+cd "$GRAFT_REPO_ROOT" || exit 1
+export TMPDIR=/tmp
+out=gpurun_out/final_r4; mkdir -p $out
+ALL="c3 c5 ref16 ref256 ref4096 ref65536 ref9800 ref15360 ref68640 g32_15 g32_17 g32_18 g32_20 g32_21 g32_22 g32_24 g64_16"
+PMC="c2 c3 c5 ref65536 g32_15 g32_17 g32_18 g32_20 g32_22 g64_16"
+python bench.py > $out/r4_bench_c2.json 2> $out/c2.err
+for c in $ALL; do python bench.py --config $c --no-cpu-baseline > $out/r4_bench_$c.json 2> $out/$c.err; done
+for c in c2 $ALL; do
+  rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_$c -- python3 bench.py --config $c --steps 20 --warmup 3 --no-cpu-baseline > $out/stats_$c.log 2>&1
+  f=$(ls $out/stats_$c/*/*kernel_stats.csv 2>/dev/null | head -1)
+  [ -n "$f" ] && cp "$f" $out/r4_${c}_kernel_stats.csv
+  rm -rf $out/stats_$c
+done
+for c in $PMC; do tools/run_pmc.sh $c $out/pmc_$c > $out/pmc_$c.log 2>&1; done
+sum() {  # config kernels alg-bytes launches label
+  local t=$out/r4_pmc_traffic_$1.json; [ $1 = c2 ] && t=$out/r4_pmc_traffic.json
+  python3 tools/summarize_pmc.py $out/pmc_$1 $t --config $1 --kernels "$2" --alg-bytes $3 --launches-per-execute $4 --label "$5" > $out/pmc_$1.sum 2>&1
+  python3 - $out/r4_bench_$1.json $t <<'PY'
+import json, sys
+b = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+t = json.load(open(sys.argv[2]))
+t["bench_kernel_label"] = b["roofline"]["kernel"]
+json.dump(t, open(sys.argv[2], "w"), indent=1)
+PY
+}
+sum c2 stockham_wg 4294967296 1 "C2 fp32 N=4096 x 65536, one launch"
+sum c3 stockham_strided 4294967296 8 "C3 fp64 N=2^20 x 128: four-step, 8 chunks of 256 MiB; FETCH_SIZE counts Infinity-Cache hits"
+sum c5 stockham_rows2d,stockham_strided 4294967296 8 "C5 fp32 1024x1024 x 256: two-pass 2-D plan, 8 chunks of 256 MiB"
+sum ref65536 stockham_strided 2147483648 4 "fp32 N=65536 x 2048: four-step, 4 chunks of 256 MiB"
+sum g32_15 stockham_strided 2147483648 4 "fp32 N=32768 x 4096: four-step (128 x 256), 4 chunks of 256 MiB"
+sum g32_17 stockham_strided 2147483648 4 "fp32 N=2^17 x 1024: four-step, 4 chunks of 256 MiB"
+sum g32_18 stockham_xcd_fourstep 2147483648 1 "fp32 N=2^18 x 512: XCD-local single launch (512 x 512), slot rings of 12 transforms per XCD"
+sum g32_20 stockham_strided 2147483648 4 "fp32 N=2^20 x 128: four-step, 4 chunks of 256 MiB"
+sum g32_22 stockham_strided 2147483648 4 "fp32 N=2^22 x 32: four-step, 4 chunks of 256 MiB"
+sum g64_16 stockham_strided 2147483648 4 "fp64 N=65536 x 1024: four-step (128 x 512), 4 chunks of 256 MiB"
+cp $out/r4_pmc_traffic*.json profiles/ 2>/dev/null
+for c in $PMC; do
+  if [ $c = c2 ]; then python bench.py > $out/r4_bench_c2.json 2> $out/c2.err; else python bench.py --config $c --no-cpu-baseline > $out/r4_bench_$c.json 2> $out/$c.err; fi
+done
+rm -rf $out/pmc_*/FETCH_SIZE $out/pmc_*/WRITE_SIZE $out/pmc_*/stats
+export HSA_ENABLE_IPC_MODE_LEGACY=0
+PFFT_BENCH_FORCE_DIST=1 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 1 --steps 20 --warmup 3 --no-cpu-baseline > $out/r4_bench_rccl_world1.json 2> $out/rccl_w1.err
+PFFT_BENCH_ONE_DEVICE=1 python bench.py --gpus 8 --steps 10 --warmup 2 --no-cpu-baseline > $out/r4_bench_8rank_one_device.json 2> $out/8rank.err
+python tools/commit_latency.py > $out/r4_commit_latency.txt 2>&1
+tools/survey.sh $out/survey > $out/survey.log 2>&1
+for f in $out/r4_bench_*.json; do python3 -c "
+import json,sys
+d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1]); r=d['roofline']
+print(sys.argv[1].split('/')[-1], d['value'], d['ms_per_step'], r['kernel_ms'], r['frac'], r.get('frac_wall'), r.get('traffic'), (r.get('copy_probe') or {}).get('gbs'))" $f; done

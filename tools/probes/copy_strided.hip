@@ -86,6 +86,14 @@ int main() {
     }
     return 0;
   }
+  if (getenv("COPY_PITCH") != nullptr) {  // BATCH_INTERLEAVED N = 1024: 128-byte segments, 1024 rows, the row pitch = batch x 8 B
+    for (long long rb : {65536ll, 262144ll, 1048576ll, 2097152ll}) {
+      run<128, 1024, 0, 1024, 8>("BI N=1024 shape, 8 B/lane", in, out, bytes, rb, cus);
+      run<128, 512, 0, 1024, 16>("BI N=1024 shape, 16 B/lane", in, out, bytes, rb, cus);
+      run<256, 1024, 0, 1024, 8>("32 columns, 8 B/lane", in, out, bytes, rb, cus);
+    }
+    return 0;
+  }
   for (long long rb : {16384ll, 8192ll}) {
     run<64, 256, 0, 1024>("strided->strided", in, out, bytes, rb, cus);
     run<128, 512, 0, 1024>("strided->strided", in, out, bytes, rb, cus);
