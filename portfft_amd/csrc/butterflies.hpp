@@ -26,13 +26,6 @@ struct int_tag {
 /// unevaluated-operand helper
 template <typename T>
 T&& declval_of() noexcept;
-/// std::enable_if without the standard library (these headers also compile under hiprtc)
-template <bool B>
-struct enable_if_t_ {};
-template <>
-struct enable_if_t_<true> {
-  using type = void;
-};
 
 #define PFA_DEV __host__ __device__ __forceinline__
 #define PFA_LAMBDA __attribute__((always_inline))

@@ -273,7 +273,6 @@ struct unpacked_io {
     const long long first = g * FPW;
     const long long left = nfft - first;
     const unsigned live = static_cast<unsigned>(left < FPW ? left : FPW);
-    live_ffts = live;
     const unsigned ibytes = ((live - 1) * id + (N - 1) * is + 1) * ES;
     const unsigned obytes = ((live - 1) * od + (N - 1) * os + 1) * ES;
     const long long ioff = first * static_cast<long long>(id) * ES, ooff = first * static_cast<long long>(od) * ES;
@@ -295,16 +294,6 @@ struct unpacked_io {
   PFA_DEV unsigned out_step(int k) const { return static_cast<unsigned>(k) * os * ES; }
   PFA_DEV unsigned in_elem(unsigned e) const { return ((e / N) * id + (e % N) * is) * ES; }
   PFA_DEV unsigned out_elem(unsigned e) const { return ((e / N) * od + (e % N) * os) * ES; }
-  /// Rows of a padded matrix (stride 1, N <= dist <= 2 N) copied HBM <-> LDS as ONE contiguous span, padding included:
-  /// lanes walk consecutive addresses, so every wave-instruction moves whole lines instead of N-element pieces that
-  /// straddle them (fp32 N = 16, ld = 20: 128-byte pieces at a 160-byte pitch; STAGED kernels only, stockham_wg_body).
-  /// The padding is read and dropped on the way in and skipped (lanes masked) on the way out.
-  static constexpr bool HAS_SPAN = true;
-  unsigned live_ffts = 0;
-  PFA_DEV bool span_in() const { return is == 1 && id <= 2 * N; }
-  PFA_DEV bool span_out() const { return os == 1 && od <= 2 * N; }
-  PFA_DEV unsigned span_in_elems() const { return (live_ffts - 1) * id + N; }
-  PFA_DEV unsigned span_out_elems() const { return (live_ffts - 1) * od + N; }
   PFA_DEV cx<T> load(unsigned voff, unsigned soff) const {
     if constexpr (SPLIT) {
       return {buf_load_scalar<T, AUX>(rin, voff, soff), buf_load_scalar<T, AUX>(rin_im, voff, soff)};
@@ -320,16 +309,6 @@ struct unpacked_io {
       buf_store<T, AUX>(v, rout, voff, soff);
     }
   }
-};
-
-/// io objects that can copy their group as one contiguous span (unpacked_io: rows of a padded matrix)
-template <typename IO, typename = void>
-struct io_has_span {
-  static constexpr bool value = false;
-};
-template <typename IO>
-struct io_has_span<IO, typename enable_if_t_<IO::HAS_SPAN>::type> {
-  static constexpr bool value = true;
 };
 
 template <typename Cfg, bool BWD, int P, typename IO>
@@ -614,36 +593,15 @@ PFA_DEV void stockham_wg_body(MakeIO&& make_io, const cx<typename Cfg::T>* __res
       constexpr int CH = Cfg::FPW * Cfg::N;
       constexpr int EPT = (CH + Cfg::WG - 1) / Cfg::WG;
       cx<T>* all = reinterpret_cast<cx<T>*>(pfa_smem);
-      bool spanned = false;
-      if constexpr (io_has_span<decltype(io)>::value) {
-        if (io.span_in()) {  // (uniform) padded rows: one contiguous span, whole lines per wave-instruction
-          spanned = true;
-          const unsigned total = io.span_in_elems(), qd = Cfg::WG / io.id, rm = Cfg::WG % io.id;
-          unsigned fft = threadIdx.x / io.id, el = threadIdx.x % io.id;
-          for (unsigned e = threadIdx.x; e < total; e += Cfg::WG) {
-            cx<T> x = io.load(e * decltype(io)::ES, 0);
-            if constexpr (BWD) x.im = -x.im;
-            if (el < static_cast<unsigned>(Cfg::N)) all[fft * Cfg::LDS_PER_FFT + lds_pad<Cfg>(static_cast<int>(el))] = x;
-            fft += qd;
-            el += rm;
-            if (el >= io.id) {
-              el -= io.id;
-              ++fft;
-            }
-          }
+      sfor<0, EPT>([&](auto k_) PFA_LAMBDA {
+        constexpr int k = decltype(k_)::value;
+        const unsigned e = threadIdx.x + k * Cfg::WG;
+        if (CH % Cfg::WG == 0 || e < CH) {
+          cx<T> x = io.load(io.in_elem(e), 0);
+          if constexpr (BWD) x.im = -x.im;
+          all[(e / Cfg::N) * Cfg::LDS_PER_FFT + lds_pad<Cfg>(e % Cfg::N)] = x;
         }
-      }
-      if (!spanned) {
-        sfor<0, EPT>([&](auto k_) PFA_LAMBDA {
-          constexpr int k = decltype(k_)::value;
-          const unsigned e = threadIdx.x + k * Cfg::WG;
-          if (CH % Cfg::WG == 0 || e < CH) {
-            cx<T> x = io.load(io.in_elem(e), 0);
-            if constexpr (BWD) x.im = -x.im;
-            all[(e / Cfg::N) * Cfg::LDS_PER_FFT + lds_pad<Cfg>(e % Cfg::N)] = x;
-          }
-        });
-      }
+      });
       __syncthreads();
     }
     const cx<T>* twp = tw;
@@ -656,42 +614,17 @@ PFA_DEV void stockham_wg_body(MakeIO&& make_io, const cx<typename Cfg::T>* __res
       constexpr int CH = Cfg::FPW * Cfg::N;
       constexpr int EPT = (CH + Cfg::WG - 1) / Cfg::WG;
       const cx<T>* all = reinterpret_cast<const cx<T>*>(pfa_smem);
-      bool spanned = false;
-      if constexpr (io_has_span<decltype(io)>::value) {
-        if (io.span_out()) {  // padded rows: lanes walk the span, the lanes that fall on padding store nothing
-          spanned = true;
-          const unsigned total = io.span_out_elems(), qd = Cfg::WG / io.od, rm = Cfg::WG % io.od;
-          unsigned fft = threadIdx.x / io.od, el = threadIdx.x % io.od;
-          for (unsigned e = threadIdx.x; e < total; e += Cfg::WG) {
-            if (el < static_cast<unsigned>(Cfg::N)) {
-              cx<T> y = all[fft * Cfg::LDS_PER_FFT + lds_pad<Cfg>(static_cast<int>(el))];
-              if constexpr (BWD) y.im = -y.im;
-              y.re *= scale;
-              y.im *= scale;
-              io.store(y, e * decltype(io)::ES, 0);
-            }
-            fft += qd;
-            el += rm;
-            if (el >= io.od) {
-              el -= io.od;
-              ++fft;
-            }
-          }
+      sfor<0, EPT>([&](auto k_) PFA_LAMBDA {
+        constexpr int k = decltype(k_)::value;
+        const unsigned e = threadIdx.x + k * Cfg::WG;
+        if (CH % Cfg::WG == 0 || e < CH) {
+          cx<T> y = all[(e / Cfg::N) * Cfg::LDS_PER_FFT + lds_pad<Cfg>(e % Cfg::N)];
+          if constexpr (BWD) y.im = -y.im;
+          y.re *= scale;
+          y.im *= scale;
+          io.store(y, io.out_elem(e), 0);
         }
-      }
-      if (!spanned) {
-        sfor<0, EPT>([&](auto k_) PFA_LAMBDA {
-          constexpr int k = decltype(k_)::value;
-          const unsigned e = threadIdx.x + k * Cfg::WG;
-          if (CH % Cfg::WG == 0 || e < CH) {
-            cx<T> y = all[(e / Cfg::N) * Cfg::LDS_PER_FFT + lds_pad<Cfg>(e % Cfg::N)];
-            if constexpr (BWD) y.im = -y.im;
-            y.re *= scale;
-            y.im *= scale;
-            io.store(y, io.out_elem(e), 0);
-          }
-        });
-      }
+      });
       __syncthreads();  // the next group's copy-in overwrites the images
     }
   }

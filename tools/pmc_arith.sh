@@ -7,12 +7,12 @@
 set -u
 out=$1; mkdir -p "$out"
 export TMPDIR=/tmp PFFT_JIT_CACHE_DIR=/tmp/pmc_arith_cache
-GROUPS=("SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM"
+CTR_GROUPS=("SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM"
         "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_VMEM"
         "GRBM_GUI_ACTIVE")
 run_case() {  # tag n batch prec
   local tag=$1 n=$2 b=$3 prec=$4 i=0
-  for grp in "${GROUPS[@]}"; do
+  for grp in "${CTR_GROUPS[@]}"; do
     i=$((i+1))
     rocprofv3 --pmc $grp --kernel-trace --output-format csv -d "$out/$tag/g$i" -- python3 tools/probes/one_desc.py $n $b $prec 3 > "$out/$tag.g$i.log" 2>&1
   done
