@@ -46,6 +46,7 @@ bool plan_measure_enabled();
 /// the recorded choice for (arch, precision, n): process table, then the JIT cache directory
 /// (`choice_<arch>_<f32|f64>_<n>.txt`, next to the code objects); empty when there is none
 std::vector<int> plan_choice_lookup(const std::string& arch, int precision, long long n);
+/// (an empty sequence forgets the record)
 void plan_choice_store(const std::string& arch, int precision, long long n, const std::vector<int>& radices);
 
 /// Same for the strided tier (FPW adjacent FFTs side by side); `inner_count` is the number of adjacent FFTs the

@@ -182,6 +182,8 @@ int main(int argc, char** argv) {
     EXPECT(pfa::choose_spec_params(0, 6000, max_lds, &q, &pick) && q.radices == pick, "forced radices honoured");
     const std::vector<int> bad = {24, 25, 11};
     EXPECT(pfa::choose_spec_params(0, 6000, max_lds, &q, &bad) && q.radices != bad, "a sequence of another length is ignored");
+    pfa::plan_choice_store("gfx000", 0, 6000, {});  // forget it again: the cache directory may be a shared one
+    EXPECT(pfa::plan_choice_lookup("gfx000", 0, 6000).empty(), "record forgotten");
   }
   {
     long long compiled = 0, from_disk = 0;
