@@ -18,7 +18,7 @@ on the plan's stream (-> `roofline.kernel_ms`, `roofline.achieved`), so the even
 
 --config selects the other single-GPU workloads with the same JSON fields: c3 / c5 (BASELINE configs[2] / [4]) and
 the reference's own bench set ref16 / ref256 / ref4096 / ref65536 (test/bench/portfft/bench_float.cpp:49-52), its
-odd-composite regression sizes ref9800 / ref15360 / ref68640 and the four-step sizes g32_* / g64_16.
+odd-composite regression sizes ref9800 / ref15360 / ref68640 and the four-step sizes g32_* / g64_*.
 """
 import argparse
 import glob
@@ -57,11 +57,14 @@ WORKLOADS = {
     "g32_15": ([32768], 4096, "f32", "fp32 four-step N=32768 batch=4Ki (reference GlobalTest size)", 2),
     "g32_17": ([131072], 1024, "f32", "fp32 four-step N=131072 batch=1Ki (reference GlobalTest size)", 2),
     "g32_18": ([1 << 18], 512, "f32", "fp32 four-step N=2^18 batch=512", 2),
+    "g32_19": ([1 << 19], 256, "f32", "fp32 four-step N=2^19 batch=256", 2),
     "g32_20": ([1 << 20], 128, "f32", "fp32 four-step N=2^20 batch=128", 2),
     "g32_21": ([1 << 21], 64, "f32", "fp32 four-step N=2^21 batch=64 (stage B reads tiles twice its group width)", 2),
     "g32_22": ([1 << 22], 32, "f32", "fp32 four-step N=2^22 batch=32", 2),
     "g32_24": ([1 << 24], 8, "f32", "fp32 three-stage N=2^24 batch=8", 3),
     "g64_16": ([65536], 1024, "f64", "fp64 four-step N=65536 batch=1Ki (reference GlobalTest size)", 2),
+    "g64_17": ([131072], 512, "f64", "fp64 four-step N=131072 batch=512 (reference GlobalTest size)", 2),
+    "g64_18": ([1 << 18], 256, "f64", "fp64 four-step N=2^18 batch=256", 2),
 }
 
 
@@ -209,7 +212,7 @@ def main():
     ap.add_argument("--config", default="c2", choices=sorted(WORKLOADS),
                     help="c2 (default, the headline line); c3 / c5: the other single-GPU configs of BASELINE.json; "
                          "ref16 / ref256 / ref4096 / ref65536: the reference's own bench set; ref9800 / ref15360 / "
-                         "ref68640: its odd-composite regression sizes; g32_* / g64_16: four-step (GLOBAL tier) sizes")
+                         "ref68640: its odd-composite regression sizes; g32_* / g64_*: four-step (GLOBAL tier) sizes")
     ap.add_argument("--manual", metavar="KEY=VALUE,...",
                     help="any descriptor, in the grammar of the reference's bench_manual_float / bench_manual_double "
                          "(register_manual_bench.hpp), e.g. d=cpx,n=1024x1024,b=64,s=split,p=ip; overrides --config")

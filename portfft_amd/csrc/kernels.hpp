@@ -142,14 +142,18 @@ const rows2d_kernel* rows2d_kernels(int* count);
 struct xcd_kernel {
   int precision;
   int n1, n2;
-  int wg, fpw;
-  size_t lds_bytes;  // the stage configuration's own (image + leading twiddle tables); the launch adds the
-                     // store-modifier tables and XCD_LDS_CTL_BYTES of control words
-  int n_radices;
-  int radices[8];
+  int wg, fpw;        // lanes of the launch's work-groups; columns (stage A) / rows (stage B) of a group
+  int tasks_a, tasks_b;  // tickets of a transform per stage (a task = wg / stage-wg groups side by side)
+  /// LDS layout (bytes from the dynamic base, xcd_layout): the leading twiddle tables of the two stages, the
+  /// store-modifier tables; the launch adds those tables (16-byte rounded) and XCD_LDS_CTL_BYTES of control words
+  unsigned twl_a_off, twl_b_off, stw_off;
+  int n_radices_a, n_radices_b;
+  int radices_a[8], radices_b[8];
   const void* fn[2];  // [backward]
   hipError_t (*launch)(hipStream_t stream, unsigned grid, size_t lds, const xcd_args& args, int backward);
   int slots, lag, lookahead;  // tuned schedule (xcd_args)
+  int wg_per_cu;              // work-groups per CU the launch is padded to (0: as many as fit)
+  int min_mib;                // MiB of data per execute from which the launch beats the two-launch plan
 };
 const xcd_kernel* xcd_kernels(int* count);
 /// XCC ids the device hands to work-groups (0: the census failed)

@@ -276,7 +276,12 @@ struct plan_t {
   void alloc_xcd_ctl() {
     if (xcd_ctl_bytes == 0 || xcd_ctl != nullptr) return;
     hip_check(hipMalloc(&xcd_ctl, xcd_ctl_bytes), "hipMalloc(control block)");
-    hip_check(hipMemset(xcd_ctl, 0, xcd_ctl_bytes), "hipMemset(control block)");
+    // On the plan's own stream and waited for.  hipMemset is not: it returns before the fill has run, the fill sits on
+    // the null stream, and a launch on a non-blocking stream does not wait for it -- with more host threads than
+    // hardware queues the fill was seen to land in the middle of the plan's first launch
+    // (tests/cpp/multi_device_test.cpp with MDT_THREADS=8: counters back at zero, hand-off waits that never end).
+    hip_check(hipMemsetAsync(xcd_ctl, 0, xcd_ctl_bytes, stream), "hipMemsetAsync(control block)");
+    hip_check(hipStreamSynchronize(stream), "hipStreamSynchronize");
   }
 
   void* upload(const void* host, size_t bytes) {
@@ -1367,7 +1372,9 @@ struct plan_t {
     const int n_queues = xcd_queue_count();
     if (n_queues <= 0) return false;
     // A queue needs transforms to run ahead of: below that the two launches win (measured: profiles/r4_xcd_local.md)
-    long long min_batch = 16ll * n_queues;
+    // (the persistent launch has a fixed start-up; the crossovers are measured per entry, kernels_xcd.hip)
+    long long min_batch = static_cast<long long>(std::max(24, 2 * k->slots)) * n_queues;
+    min_batch = std::max<long long>(min_batch, (static_cast<long long>(k->min_mib) << 20) / (n * static_cast<long long>(elem_bytes())));
     if (const char* e = getenv("PFFT_XCD_MIN_BATCH")) min_batch = std::atoll(e);
     if (count < min_batch) return false;
     const long long n1 = k->n1, n2 = k->n2;
@@ -1380,13 +1387,19 @@ struct plan_t {
     if (slots < 2 || lag < 1 || lag >= slots || slots > 64) return false;
     // store-modifier tables W_N^(k1 * c) behind the kernel's own LDS (same shape rule as the two-launch stage A)
     strided_kernel shape{};
-    shape.lds_bytes = k->lds_bytes + XCD_LDS_CTL_BYTES;
+    shape.lds_bytes = k->stw_off + XCD_LDS_CTL_BYTES;
     shape.stw_mode = 1;
     int levels = 0, shift = 0;
     store_table_shape(&shape, n, &levels, &shift);
     const size_t stw_bytes = (static_cast<size_t>(levels) << shift) * elem_bytes();
-    const size_t own = ((k->lds_bytes + stw_bytes + 15) & ~static_cast<size_t>(15)) + XCD_LDS_CTL_BYTES;
+    const size_t own = ((k->stw_off + stw_bytes + 15) & ~static_cast<size_t>(15)) + XCD_LDS_CTL_BYTES;
     if (levels > 4 || own > max_lds) return false;
+    // the LDS request of a launch tuned for fewer work-groups per CU than would fit is padded until no more fit
+    size_t lds = own;
+    if (k->wg_per_cu > 0) {
+      const size_t fits_one_more = (max_lds / static_cast<size_t>(k->wg_per_cu + 1) + 16 + 15) & ~static_cast<size_t>(15);
+      if (fits_one_more <= max_lds / static_cast<size_t>(k->wg_per_cu)) lds = std::max(own, fits_one_more);
+    }
     stage s;
     s.xcd = k;
     s.n = static_cast<int>(std::min<long long>(n, 0x7fffffff));
@@ -1396,12 +1409,15 @@ struct plan_t {
     s.in_addr = ia;
     s.out_addr = oa;
     s.backward = backward;
-    s.lds_bytes = own;
-    const void* tw = upload_twiddles(std::vector<int>(k->radices, k->radices + k->n_radices));
+    s.lds_bytes = lds;
+    const void* tw_a = upload_twiddles(std::vector<int>(k->radices_a, k->radices_a + k->n_radices_a));
+    const void* tw_b = upload_twiddles(std::vector<int>(k->radices_b, k->radices_b + k->n_radices_b));
     xcd_args& x = s.xa;
     // stage A: for every transform and column c: length-n1 FFT over rows (stride n2), x W_N^(k1 * c), group-major tiles out
     strided_args& a = x.a;
-    a.tw = tw;
+    a.tw = tw_a;
+    a.twl_lds_off = k->twl_a_off;
+    a.stw_lds_off = k->stw_off;
     a.total = count * n2;
     a.inner = n2;
     a.in_dist_outer = n;
@@ -1418,7 +1434,9 @@ struct plan_t {
     a.out_fdist = 1;
     // stage B: for every transform and row k1: length-n2 FFT read from the tiles, output X[k1 + n1 * k2]
     strided_args& b = x.b;
-    b.tw = tw;
+    b.tw = tw_b;
+    b.twl_lds_off = k->twl_b_off;
+    b.stw_lds_off = k->stw_off;
     b.total = count * n1;
     b.inner = n1;
     b.in_dist_outer = 0;
@@ -1436,11 +1454,11 @@ struct plan_t {
     x.lag = lag;
     x.lookahead = lookahead;
     // claim map: must outlast every ticket in flight -- slots + lag + lookahead batches plus three tickets per work-group
-    const long long tpt = n2 / t + n1 / t;
+    const long long tpt = k->tasks_a + k->tasks_b;
     int per_cu = 0;
-    hip_check(hipFuncSetAttribute(k->fn[backward], hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(own)),
+    hip_check(hipFuncSetAttribute(k->fn[backward], hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)),
               "hipFuncSetAttribute");
-    hip_check(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k->fn[backward], k->wg, own), "occupancy query");
+    hip_check(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k->fn[backward], k->wg, lds), "occupancy query");
     per_cu = std::max(per_cu, 1);
     s.grid = static_cast<unsigned>(per_cu * n_cus);
     // (sized for the largest grid the device could hold, not for this direction's: forward and backward share the block)
@@ -1464,7 +1482,7 @@ struct plan_t {
       info->factors[1] = static_cast<int>(n2);
       info->workgroup_size = k->wg;
       info->ffts_per_workgroup = k->fpw;
-      info->lds_bytes = own;
+      info->lds_bytes = lds;
     }
     return true;
   }
@@ -2172,6 +2190,7 @@ struct plan_t {
       x.b.in = scratch;
       x.b.out = static_cast<char*>(out_re) + static_cast<size_t>(s.out_addr.offset) * elem_bytes();
       x.ctl = static_cast<unsigned*>(xcd_ctl);
+      x.keep_on_timeout = getenv("PFFT_XCD_DUMP") != nullptr ? 1 : 0;
       hip_check(s.xcd->launch(stream, s.grid, s.lds_bytes, x, s.backward), "kernel launch");
       if (xcd_check_enabled()) check_xcd_timeouts();
       return;
@@ -2451,6 +2470,24 @@ struct plan_t {
     unsigned h[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     hip_check(hipMemcpy(h, static_cast<unsigned*>(xcd_ctl) + XCD_W_TIMEOUT, sizeof h, hipMemcpyDeviceToHost), "hipMemcpy");
     if (h[0] != 0) {
+      if (getenv("PFFT_XCD_DUMP") != nullptr) {  // the control block as the failed launch left it
+        std::vector<unsigned> w(xcd_ctl_bytes / sizeof(unsigned));
+        hip_check(hipMemcpy(w.data(), xcd_ctl, xcd_ctl_bytes, hipMemcpyDeviceToHost), "hipMemcpy");
+        std::fprintf(stderr, "xcd ctl %p: next %u exit %u epoch %u polls %u\n", xcd_ctl, w[XCD_W_NEXT], w[XCD_W_EXIT], w[XCD_W_EPOCH], h[5]);
+        for (const stage& st : stages[0]) {
+          if (st.xcd == nullptr) continue;
+          const unsigned qw = xcd_queue_words(st.xa.slots, st.xa.map_log2);
+          for (int q = 0; q < st.xa.n_queues; ++q) {
+            const unsigned* qb = w.data() + XCD_W_QUEUES + q * qw;
+            std::fprintf(stderr, " queue %d: ticket %u | done_a/done_b per slot:", q, qb[0]);
+            for (int sl = 0; sl < st.xa.slots; ++sl) {
+              const unsigned* d = qb + 32 + (4u << st.xa.map_log2) + 64 * sl;
+              std::fprintf(stderr, " %u/%u", d[0], d[32]);
+            }
+            std::fprintf(stderr, "\n");
+          }
+        }
+      }
       fail(PFFT_INTERNAL_ERROR, "XCD-local four-step launch: ", h[0], " hand-off waits gave up (first: site ", h[1],
            ", local transform ", h[2], ", wanted ", h[3], ", saw ", h[4], ")");
     }

@@ -59,8 +59,9 @@ constexpr int strided_pitch() {
 /// (IMGDIV: the kernel's image holds 1 / IMGDIV of the group -- 2 for the half-exchange kernel of
 /// stockham_strided_hx.hpp, the first radix for the experiment of tools/probes/stockham_strided_sfr.hpp)
 template <typename Cfg, int IMGDIV = 1>
-PFA_DEV cx<typename Cfg::T>* stw_lds_tables() {
+PFA_DEV cx<typename Cfg::T>* stw_lds_tables(const strided_args& a) {
   extern __shared__ __attribute__((aligned(16))) char pfa_smem_strided[];
+  if (a.stw_lds_off != 0) return reinterpret_cast<cx<typename Cfg::T>*>(pfa_smem_strided + a.stw_lds_off);
   constexpr size_t image = size_t(Cfg::N) * Cfg::FPW / IMGDIV;
   constexpr size_t own = Cfg::NP > 1 ? image + Cfg::TWL_ELEMS : 0;
   return reinterpret_cast<cx<typename Cfg::T>*>(pfa_smem_strided) + own;
@@ -69,7 +70,7 @@ PFA_DEV cx<typename Cfg::T>* stw_lds_tables() {
 /// W_M^m as the product of one entry per level
 template <typename Cfg, int IMGDIV = 1>
 PFA_DEV cx<typename Cfg::T> stw_from_lds(const strided_args& a, unsigned m) {
-  const cx<typename Cfg::T>* tab = stw_lds_tables<Cfg, IMGDIV>();
+  const cx<typename Cfg::T>* tab = stw_lds_tables<Cfg, IMGDIV>(a);
   const unsigned sh = static_cast<unsigned>(a.stw_lshift);
   const unsigned mask = (1u << sh) - 1u;
   cx<typename Cfg::T> w = tab[m & mask];
@@ -83,7 +84,7 @@ PFA_DEV cx<typename Cfg::T> stw_from_lds(const strided_args& a, unsigned m) {
 template <typename Cfg, int STW, int IMGDIV = 1>
 PFA_DEV void strided_copy_stw(const strided_args& a) {
   if constexpr (STW == 1) {
-    cx<typename Cfg::T>* dst = stw_lds_tables<Cfg, IMGDIV>();
+    cx<typename Cfg::T>* dst = stw_lds_tables<Cfg, IMGDIV>(a);
     const cx<typename Cfg::T>* src = static_cast<const cx<typename Cfg::T>*>(a.stw_tab);
     const int n = a.stw_levels << a.stw_lshift;
     for (int i = threadIdx.x; i < n; i += Cfg::WG) dst[i] = src[i];
@@ -228,6 +229,12 @@ PFA_DEV void strided_pass(const IO& io, const strided_args& a, unsigned f,
     tid = (lane / (TW * Cfg::FPW)) * TW + tin_jl;
     live = static_cast<long long>(f) < nlive;
   }
+  // LDS copy of the leading twiddle tables: behind the image, unless the launch says otherwise (strided_args::twl_lds_off)
+  [[maybe_unused]] const cx<T>* twl = lds + N * FPW;
+  if constexpr (P != 0 && P <= Cfg::TWL && !ROW_IN && !ROW_OUT) {
+    extern __shared__ __attribute__((aligned(16))) char pfa_smem_strided[];
+    if (a.twl_lds_off != 0) twl = reinterpret_cast<const cx<T>*>(pfa_smem_strided + a.twl_lds_off);
+  }
   cx<T> v[BPT][R];
   sfor<0, BPT>([&](auto i_) PFA_LAMBDA {
     constexpr int i = decltype(i_)::value;
@@ -279,7 +286,7 @@ PFA_DEV void strided_pass(const IO& io, const strided_args& a, unsigned f,
           constexpr int t = decltype(t_)::value;
           cx<T> w;
           if constexpr (P <= Cfg::TWL && !ROW_IN && !ROW_OUT) {
-            w = (lds + N * FPW + Seq::tw_off(P) + (t - 1) * Ns)[q];  // LDS copy behind the image (wg_cfg TWL)
+            w = (twl + Seq::tw_off(P) + (t - 1) * Ns)[q];  // LDS copy behind the image (wg_cfg TWL)
           } else {
             w = (tw + Seq::tw_off(P) + (t - 1) * Ns)[q];
           }

@@ -146,41 +146,67 @@ struct xcd_with_aux<wg_cfg<T, Seq, WG, FPW, PADS, PADW, TWM, OCC, AUX, STAGED, T
 
 constexpr unsigned XCD_UNKNOWN = 0xFFFFFFFFu;  // a claim-map entry that was not yet published when it was looked at
 
-/// CfgA / CfgB: the strided configurations of the two stages (lengths n1 = CfgA::N, n2 = CfgB::N).  This first form
-/// takes pairs with equal work-group size, group width and radix sequence (the registered square pairs: fp32 256 x 256,
-/// 512 x 512, fp64 256 x 256): one LDS image, one copy of the leading twiddle tables.
+/// LDS layout of the launch (elements of cx<T>, from the dynamic base): the image region shared by the two stages --
+/// HA stage-A images side by side or HB stage-B images --, stage A's leading twiddle tables, stage B's (one copy when the
+/// stages share a configuration), the store-modifier tables, the control words.
+template <typename CfgA, typename CfgB, int WG>
+struct xcd_layout {
+  static constexpr int HA = WG / CfgA::WG, HB = WG / CfgB::WG;  // groups a work-group runs side by side per task
+  static constexpr size_t IMG_A = size_t(CfgA::N) * CfgA::FPW, IMG_B = size_t(CfgB::N) * CfgB::FPW;
+  static constexpr size_t IMAGE = (HA * IMG_A > HB * IMG_B) ? HA * IMG_A : HB * IMG_B;
+  static constexpr bool SAME_TW = CfgA::N == CfgB::N && CfgA::TWL == CfgB::TWL && CfgA::NP == CfgB::NP;  // (same radices: checked below)
+  static constexpr size_t TWL_A = IMAGE, TWL_B = SAME_TW ? IMAGE : IMAGE + CfgA::TWL_ELEMS;
+  static constexpr size_t STW = TWL_B + CfgB::TWL_ELEMS;
+  static constexpr size_t bytes(size_t stw_bytes) {
+    return ((STW * sizeof(cx<typename CfgA::T>) + stw_bytes + 15) & ~static_cast<size_t>(15)) + XCD_LDS_CTL_BYTES;
+  }
+};
+
+/// CfgA / CfgB: the strided configurations of the two stages (lengths n1 = CfgA::N, n2 = CfgB::N); WG: lanes of the
+/// launch's work-groups, a multiple of both configurations' -- a task is WG / Cfg::WG groups side by side, each on its own
+/// LDS image with its own lanes (the passes' barriers are the work-group's: every lane runs the same pass sequence).
+/// fp32 256 x 512 runs 512 lanes: two 256-lane stage-A groups (2 x 32 KiB) or one 512-lane stage-B group (64 KiB) per task.
 /// STW: store modifier W_N^(k1 * c) on stage A's stores (1: tables in LDS, 2: global tables).  TIN: stage B's
-/// tiled-input form (1 = tiles of its own group width).  FREERUN (tuner only; results are garbage): 1 no claims and no hand-off waits -- the
-/// bound of the task structure; 2 no waits; 3 static transform map instead of claims, waits kept.  OCCX: waves per SIMD the register allocator must leave room for.
+/// tiled-input form (1 = tiles of its own group width; the two group widths are equal).  FREERUN (tuner only; results
+/// are garbage): 1 no claims and no hand-off waits -- the bound of the task structure; 2 no waits; 3 static transform map
+/// instead of claims, waits kept.  OCCX: waves per SIMD the register allocator must leave room for.
 ///
 /// Control traffic stays off the tasks' critical path: thread 0 keeps the work-group TWO tickets ahead -- while ticket
 /// t is processed it already knows t' (the next one), looks up t' 's claim-map entry and hand-off counter (memory round
 /// trips of 0.5-1.6 us under load) BEHIND the task's own pass-0 loads, takes t'' and publishes {t', transform, counter
-/// value} in LDS behind pass 0's barrier.  A wave polls for itself only when the published value was not yet sufficient.  A stage-A task waits for
-/// its slot only in front of its LAST pass (the stores), so a slot's previous occupant may still be read while the
-/// task loads and computes: the ring needs lag + 1 slots, not lag + (task length in ticket batches).
-template <typename CfgA_, typename CfgB_, bool BWD, int STW, int TIN, int FREERUN = 0, int OCCX = CfgA_::OCC>
-__global__ __launch_bounds__(CfgA_::WG, OCCX) void stockham_xcd_fourstep_kernel(const xcd_args x) {
+/// value} in LDS behind pass 0's barrier.  A wave polls for itself only when the published value was not yet sufficient.
+/// A stage-A task waits for its slot only in front of its LAST pass (the stores), so a slot's previous occupant may still
+/// be read while the task loads and computes.
+template <typename CfgA_, typename CfgB_, bool BWD, int STW, int TIN, int FREERUN = 0, int OCCX = CfgA_::OCC,
+          int WG = (CfgA_::WG > CfgB_::WG ? CfgA_::WG : CfgB_::WG)>
+__global__ __launch_bounds__(WG, OCCX) void stockham_xcd_fourstep_kernel(const xcd_args x) {
   using CfgA = typename xcd_with_aux<CfgA_, XCD_AUX_A>::type;
   using CfgB = typename xcd_with_aux<CfgB_, XCD_AUX_B>::type;
   using T = typename CfgA::T;
-  static_assert(CfgA::WG == CfgB::WG && CfgA::FPW == CfgB::FPW && CfgA::N == CfgB::N && CfgA::TWL == CfgB::TWL,
-                "this form takes square pairs on one configuration");
+  using L = xcd_layout<CfgA, CfgB, WG>;
+  static_assert(WG % CfgA::WG == 0 && WG % CfgB::WG == 0 && WG % 64 == 0, "whole groups and whole waves per work-group");
+  static_assert(CfgA::FPW == CfgB::FPW, "the intermediate's tiles are FPW wide on both sides");
   static_assert(CfgA::NP >= 2 && CfgB::NP >= 2, "two passes at least (the LDS exchange carries the ticket)");
-  static_assert(CfgA::WG % 64 == 0, "whole waves");
-  constexpr unsigned NW = CfgA::WG / 64;
-  constexpr unsigned TA = CfgB::N / CfgA::FPW;  // stage-A tasks of a transform: n2 columns in groups of FPW
-  constexpr unsigned TB = CfgA::N / CfgB::FPW;  // stage-B tasks: n1 rows in groups of FPW
+  constexpr int HA = L::HA, HB = L::HB;
+  constexpr unsigned NW = WG / 64;
+  static_assert((CfgB::N / CfgA::FPW) % HA == 0 && (CfgA::N / CfgB::FPW) % HB == 0, "whole tasks");
+  constexpr unsigned GA = CfgB::N / CfgA::FPW, GB = CfgA::N / CfgB::FPW;  // groups of a transform per stage
+  constexpr unsigned TA = GA / HA;  // stage-A tasks of a transform
+  constexpr unsigned TB = GB / HB;  // stage-B tasks
   constexpr unsigned TPT = TA + TB;
-  static_assert(CfgB::N % CfgA::FPW == 0 && CfgA::N % CfgB::FPW == 0, "whole groups");
   extern __shared__ __attribute__((aligned(16))) char pfa_smem_strided[];
-  cx<T>* lds = reinterpret_cast<cx<T>*>(pfa_smem_strided);
+  cx<T>* const lds0 = reinterpret_cast<cx<T>*>(pfa_smem_strided);
   // control words behind everything else in the dynamic region (XCD_LDS_CTL_BYTES): [4 p .. 4 p + 2], p = 0 / 1: the
   // record {ticket, transform + 1 or XCD_UNKNOWN, hand-off counter value} of the iteration with parity p; [8] stage-A
   // arrivals of the work-group's waves; [9] "this work-group clears the control block"
   unsigned* const s_ctl = reinterpret_cast<unsigned*>(pfa_smem_strided + x.lds_ctl_off);
-  const unsigned f = threadIdx.x % CfgA::FPW;
-  const unsigned tid = threadIdx.x / CfgA::FPW;
+  // lanes of a group inside the work-group, per stage
+  const unsigned half_a = threadIdx.x / CfgA::WG, lane_a = threadIdx.x % CfgA::WG;
+  const unsigned half_b = threadIdx.x / CfgB::WG, lane_b = threadIdx.x % CfgB::WG;
+  const unsigned f_a = lane_a % CfgA::FPW, tid_a = lane_a / CfgA::FPW;
+  const unsigned f_b = lane_b % CfgB::FPW, tid_b = lane_b / CfgB::FPW;
+  cx<T>* const lds_a = lds0 + half_a * L::IMG_A;
+  cx<T>* const lds_b = lds0 + half_b * L::IMG_B;
   const cx<T>* __restrict__ tw_a = static_cast<const cx<T>*>(x.a.tw);
   const cx<T>* __restrict__ tw_b = static_cast<const cx<T>*>(x.b.tw);
   xcd_gu32* const ctl = (xcd_gu32*)x.ctl;
@@ -191,8 +217,18 @@ __global__ __launch_bounds__(CfgA_::WG, OCCX) void stockham_xcd_fourstep_kernel(
     s_ctl[8] = 0u;
     s_ctl[9] = 0u;
   }
-  strided_copy_twiddles<CfgA>(lds, tw_a);
-  strided_copy_stw<CfgA, STW>(x.a);
+  // once per work-group lifetime: the leading twiddle tables of both stages and the store-modifier tables into LDS
+  // (x.a / x.b carry the offsets: strided_args::twl_lds_off / stw_lds_off)
+  for (int i = threadIdx.x; i < CfgA::TWL_ELEMS; i += WG) lds0[L::TWL_A + i] = tw_a[i];
+  if constexpr (!L::SAME_TW) {
+    for (int i = threadIdx.x; i < CfgB::TWL_ELEMS; i += WG) lds0[L::TWL_B + i] = tw_b[i];
+  }
+  if constexpr (STW == 1) {
+    const cx<T>* src = static_cast<const cx<T>*>(x.a.stw_tab);
+    const int n = x.a.stw_levels << x.a.stw_lshift;
+    for (int i = threadIdx.x; i < n; i += WG) lds0[L::STW + i] = src[i];
+  }
+  __syncthreads();
   if (q < static_cast<unsigned>(x.n_queues)) {  // (an id the census did not see: nothing claimed, nothing lost)
     xcd_gu32* const qb = ctl + XCD_W_QUEUES + q * xcd_queue_words(x.slots, x.map_log2);
     xcd_gu32* const ticket = qb;
@@ -309,56 +345,63 @@ __global__ __launch_bounds__(CfgA_::WG, OCCX) void stockham_xcd_fourstep_kernel(
         bool live;
         long long c0, nlive;
         if (is_a) {
-          const auto io = strided_group<CfgA, 0>(x.a, gid * TA + r, f, &live, &c0, &nlive, 0, sbase);
+          const auto io = strided_group<CfgA, 0>(x.a, gid * GA + r * HA + half_a, f_a, &live, &c0, &nlive, 0, sbase);
           {
             cx<T> cur[CfgA::bpt(0)][CfgA::Seq::r[0]];
-            strided_pass0_load<CfgA, BWD>(io, x.a, f, tid, live, cur);
+            strided_pass0_load<CfgA, BWD>(io, x.a, f_a, tid_a, live, cur);
             control_issue();
-            strided_pass0_compute<CfgA, 0, 0>(cur, f, tid, lds);
+            strided_pass0_compute<CfgA, 0, 0>(cur, f_a, tid_a, lds_a);
           }
           PFA_XCD_STAMP(p_p0);
           PFA_XCD_ACC(4, p_claimed, p_p0);
           duties();
-          strided_passes_range<CfgA, BWD, STW, 1, CfgA::NP - 1, decltype(io)>(io, x.a, f, tid, live, c0, lds, tw_a, nlive);
+          strided_passes_range<CfgA, BWD, STW, 1, CfgA::NP - 1, decltype(io)>(io, x.a, f_a, tid_a, live, c0, lds_a, tw_a, nlive);
           PFA_XCD_STAMP(p_mid);
           PFA_XCD_ACC(5, p_p0, p_mid);
           // the slot's previous occupant must have been read before this task's stores (the last pass)
-          if ((FREERUN == 0 || FREERUN == 3) && depv < rnd * TB) xcd_wait_ge(done_b, rnd * TB, tmo, 1u, static_cast<unsigned>(k));
+          if ((FREERUN == 0 || FREERUN == 3) && depv < rnd * GB) xcd_wait_ge(done_b, rnd * GB, tmo, 1u, static_cast<unsigned>(k));
           PFA_XCD_STAMP(p_dep);
           PFA_XCD_ACC(2, p_mid, p_dep);
-          strided_pass<CfgA, BWD, STW, CfgA::NP - 1, decltype(io)>(io, x.a, f, tid, live, c0, lds, tw_a, nlive);
+          strided_pass<CfgA, BWD, STW, CfgA::NP - 1, decltype(io)>(io, x.a, f_a, tid_a, live, c0, lds_a, tw_a, nlive);
           PFA_XCD_STAMP(p_st);
           PFA_XCD_ACC(6, p_dep, p_st);
-          // every storing wave waits for its stores to reach the L2; the wave that arrives last signals
+          // every storing wave waits for its stores to reach the L2; the wave that arrives last signals (HA groups)
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
           PFA_XCD_STAMP(p_dr);
           PFA_XCD_ACC(7, p_st, p_dr);
           PFA_XCD_CNT(8);
           if (threadIdx.x % 64u == 0u) {
             const unsigned old = __hip_atomic_fetch_add(&s_ctl[8], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if ((old + 1u) % NW == 0u) xcd_add(done_a, 1u);
+            if ((old + 1u) % NW == 0u) xcd_add(done_a, static_cast<unsigned>(HA));
           }
         } else {
-          // all of the transform's stage-A tasks have stored
-          if ((FREERUN == 0 || FREERUN == 3) && depv < (rnd + 1u) * TA) xcd_wait_ge(done_a, (rnd + 1u) * TA, tmo, 2u, static_cast<unsigned>(k));
+          // all of the transform's stage-A groups have stored
+          if ((FREERUN == 0 || FREERUN == 3) && depv < (rnd + 1u) * GA) {
+            xcd_wait_ge(done_a, (rnd + 1u) * GA, tmo, 2u, static_cast<unsigned>(k));
+          }
           PFA_XCD_STAMP(p_dep);
           PFA_XCD_ACC(3, p_claimed, p_dep);
-          const auto io = strided_group<CfgB, 0>(x.b, gid * TB + (r - TA), f, &live, &c0, &nlive, sbase, 0);
+          const auto io = strided_group<CfgB, 0>(x.b, gid * GB + (r - TA) * HB + half_b, f_b, &live, &c0, &nlive, sbase, 0);
           {
-            unsigned f0 = f, tid0 = tid;
+            unsigned f0 = f_b, tid0 = tid_b;
             bool live0 = live;
-            if constexpr (TIN != 0) tin_lanes<CfgB, TIN>(&f0, &tid0, &live0, nlive);
+            if constexpr (TIN != 0) {  // lanes element-fastest inside the FPW x TW input tiles (tin_lanes, on the group's own lanes)
+              constexpr unsigned TW = tin_width<CfgB, TIN>();
+              f0 = (lane_b / TW) % CfgB::FPW;
+              tid0 = (lane_b / (TW * CfgB::FPW)) * TW + lane_b % TW;
+              live0 = static_cast<long long>(f0) < nlive;
+            }
             cx<T> cur[CfgB::bpt(0)][CfgB::Seq::r[0]];
             strided_pass0_load<CfgB, BWD>(io, x.b, f0, tid0, live0, cur);
             control_issue();
-            strided_pass0_compute<CfgB, TIN, 0>(cur, f0, tid0, lds);
+            strided_pass0_compute<CfgB, TIN, 0>(cur, f0, tid0, lds_b);
           }
           PFA_XCD_STAMP(p_p0);
           PFA_XCD_ACC(9, p_dep, p_p0);
-          // behind pass 0's barrier every wave has its input in registers: the slot is read
-          if (threadIdx.x == 0) xcd_add(done_b, 1u);
+          // behind pass 0's barrier every wave has its input in registers: the slot is read (HB groups)
+          if (threadIdx.x == 0) xcd_add(done_b, static_cast<unsigned>(HB));
           duties();
-          strided_passes_range<CfgB, BWD, 0, 1, CfgB::NP, decltype(io), TIN>(io, x.b, f, tid, live, c0, lds, tw_b, nlive);
+          strided_passes_range<CfgB, BWD, 0, 1, CfgB::NP, decltype(io), TIN>(io, x.b, f_b, tid_b, live, c0, lds_b, tw_b, nlive);
           PFA_XCD_STAMP(p_st);
           PFA_XCD_ACC(10, p_p0, p_st);
           PFA_XCD_CNT(11);
@@ -396,12 +439,12 @@ __global__ __launch_bounds__(CfgA_::WG, OCCX) void stockham_xcd_fourstep_kernel(
     s_ctl[9] = old == gridDim.x - 1u ? 1u : 0u;
   }
   __syncthreads();
-  if (s_ctl[9] != 0u) {
+  if (s_ctl[9] != 0u && !(x.keep_on_timeout != 0 && xcd_load(tmo) != 0u)) {
     // counters only: tickets, done_a / done_b, the launch-wide words.  The claim maps are left alone (xcd_args.hpp);
     // the epoch makes their entries invalid for the next launch.
     const unsigned qw = xcd_queue_words(x.slots, x.map_log2), mw = 4u << x.map_log2;
     const unsigned words = xcd_ctl_words(x.n_queues, x.slots, x.map_log2);
-    for (unsigned i = threadIdx.x; i < words; i += CfgA::WG) {
+    for (unsigned i = threadIdx.x; i < words; i += WG) {
       bool clear = i < XCD_W_EXIT + 1u;
       if (i >= XCD_W_QUEUES) {
         const unsigned o = (i - XCD_W_QUEUES) % qw;
@@ -413,10 +456,10 @@ __global__ __launch_bounds__(CfgA_::WG, OCCX) void stockham_xcd_fourstep_kernel(
   }
 }
 
-/// LDS bytes of the launch: the configuration's own, the store-modifier tables, the control words
-template <typename Cfg>
+/// LDS bytes of the launch (xcd_layout) and the table offsets the stage arguments carry
+template <typename CfgA, typename CfgB, int WG = (CfgA::WG > CfgB::WG ? CfgA::WG : CfgB::WG)>
 constexpr size_t xcd_lds_bytes(size_t stw_bytes) {
-  return ((strided_lds_bytes<Cfg>() + stw_bytes + 15) & ~static_cast<size_t>(15)) + XCD_LDS_CTL_BYTES;
+  return xcd_layout<CfgA, CfgB, WG>::bytes(stw_bytes);
 }
 
 }  // namespace pfa

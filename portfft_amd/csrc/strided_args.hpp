@@ -47,6 +47,10 @@ struct strided_args {
   long long outer_lo;
   long long in_dist_outer_hi, out_dist_outer_hi;
   int any_order;  // host side only: launch without the in-order barrier (pfa_launch)
+  /// byte offsets (from the kernel's dynamic LDS base) of the LDS copy of the leading twiddle tables and of the
+  /// store-modifier tables; 0 = the kernel's own layout (behind its image).  Set by launches whose LDS holds more than
+  /// one stage configuration (stockham_xcd.hpp).
+  unsigned twl_lds_off, stw_lds_off;
   /// 1: blocks b and b + 8 (one XCD, dispatched back to back) take neighbouring groups -- stages whose input segments
   /// are narrower than a 128-byte line (stockham_strided_kernel); the grid is then a multiple of 16
   int pair_xcd;

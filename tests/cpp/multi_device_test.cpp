@@ -15,6 +15,7 @@
 #include <complex>
 #include <condition_variable>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -100,6 +101,12 @@ __global__ void fill_kernel(float* p, size_t n, unsigned seed) {
   }
 }
 
+/// (experiments: MDT_XCD_BATCH, MDT_THREADS)
+std::size_t env_or(const char* name, std::size_t dflt) {
+  const char* e = std::getenv(name);
+  return e != nullptr ? static_cast<std::size_t>(std::atoll(e)) : dflt;
+}
+
 struct job {
   std::size_t n, batch;
   const char* what;
@@ -116,7 +123,7 @@ void worker(int tid, int device, int n_threads, barrier_t* bar, std::vector<doub
   portfft::queue q(stream);
   const job jobs[3] = {{4096, static_cast<std::size_t>(65536 / n_threads), "headline N=4096"},
                        {3000, 1024, "runtime-specialised N=3000"},
-                       {std::size_t{1} << 18, 128, "XCD-local N=2^18"}};
+                       {std::size_t{1} << 18, env_or("MDT_XCD_BATCH", 256), "XCD-local N=2^18"}};
   std::vector<portfft::committed_descriptor<float, portfft::domain::COMPLEX>> plans;
   bar->arrive_and_wait();  // every thread commits at the same time: hiprtc, the on-disk cache, the XCD census
   try {
@@ -224,7 +231,7 @@ int main(int argc, char** argv) {
     std::printf("no device\n");
     return 2;
   }
-  const int n_threads = n_dev > 1 ? n_dev : 4;
+  const int n_threads = n_dev > 1 ? n_dev : static_cast<int>(env_or("MDT_THREADS", 4));
   std::printf("%d device(s), %d host thread(s)%s\n", n_dev, n_threads, n_dev > 1 ? "" : " (4 streams of device 0)");
   barrier_t bar(n_threads);
   std::vector<double> ms(static_cast<std::size_t>(n_threads) * 3, 0.0);
@@ -232,8 +239,8 @@ int main(int argc, char** argv) {
   for (int t = 0; t < n_threads; ++t) th.emplace_back(worker, t, n_dev > 1 ? t : 0, n_threads, &bar, &ms);
   for (auto& t : th) t.join();
   for (int t = 0; t < n_threads; ++t) {
-    std::printf("thread %d (device %d): N=4096 x %d %.3f ms, N=3000 x 1024 %.3f ms, N=2^18 x 128 %.3f ms per execute\n", t,
-                n_dev > 1 ? t : 0, 65536 / n_threads, ms[3 * t], ms[3 * t + 1], ms[3 * t + 2]);
+    std::printf("thread %d (device %d): N=4096 x %d %.3f ms, N=3000 x 1024 %.3f ms, N=2^18 x %zu %.3f ms per execute\n", t,
+                n_dev > 1 ? t : 0, 65536 / n_threads, ms[3 * t], ms[3 * t + 1], env_or("MDT_XCD_BATCH", 256), ms[3 * t + 2]);
   }
   if (g_fail == 0) std::printf("multi device OK\n");
   return g_fail == 0 ? 0 : 1;

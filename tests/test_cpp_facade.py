@@ -81,3 +81,8 @@ def test_one_host_thread_per_device(tmp_path):
     assert p.returncode == 0, p.stdout + p.stderr
     assert "multi device OK" in p.stdout
     print(p.stdout)
+    # more host threads than hardware queues (streams share them): the run that caught the control block of a plan
+    # being cleared by a null-stream hipMemset that had not run yet when the plan's first launch started
+    p = subprocess.run([MULTI_DEVICE_EXE], capture_output=True, text=True, timeout=900, env=dict(env, MDT_THREADS="8"))
+    assert p.returncode == 0, p.stdout + p.stderr
+    assert "multi device OK" in p.stdout

@@ -1,5 +1,6 @@
 """The XCD-local single-launch four-step plan (portfft_amd/csrc/stockham_xcd.hpp, plan.cpp plan_xcd_local) through the
-C ABI on an MI355X: fp32 N = 2^18 (512 x 512), the reference's GLOBAL-tier size range
+C ABI on an MI355X: fp32 N = 2^16 ... 2^20 and fp64 N = 2^16, 2^17, 2^18, 2^20 (kernels_xcd.hip), the reference's
+GLOBAL-tier size range
 (ref: test/unit_test/instantiate_fft_tests.hpp:147-151, src/portfft/dispatcher/global_dispatcher.hpp:343-408).
 
 Every launch runs with PFFT_XCD_CHECK=1: the library waits for it and fails when one of the kernel's bounded hand-off
@@ -49,22 +50,58 @@ def _checked_launches():
         yield
 
 
-def _random(torch, count, seed=5):
+def _random(torch, count, seed=5, prec="f32"):
     g = torch.Generator(device="cuda").manual_seed(seed)
-    x = torch.empty(count, dtype=torch.complex64, device="cuda")
+    x = torch.empty(count, dtype=torch.complex64 if prec == "f32" else torch.complex128, device="cuda")
     torch.view_as_real(x).uniform_(-1, 1, generator=g)
     return x
 
 
-def _check_samples(x, y, batch, samples, scale=1.0):
+def _check_samples(x, y, batch, samples, scale=1.0, n=N, tol=TOL):
     for b in samples:
-        ref = np.fft.fft(x.view(batch, N)[b].cpu().numpy().astype(np.complex128)) * scale
-        assert H.rel_l2(y.view(batch, N)[b].cpu().numpy(), ref) <= TOL, ("transform", b)
+        ref = np.fft.fft(x.view(batch, n)[b].cpu().numpy().astype(np.complex128)) * scale
+        assert H.rel_l2(y.view(batch, n)[b].cpu().numpy(), ref) <= tol, ("transform", b)
+
+
+# every registered pair (kernels_xcd.hip): (precision, log2 N, a batch above the plan's threshold with a ragged tail)
+REGISTERED = [("f32", 16, 515), ("f32", 17, 301), ("f32", 19, 131), ("f32", 20, 67),
+              ("f64", 16, 387), ("f64", 17, 259), ("f64", 18, 133), ("f64", 19, 67)]
+
+
+@pytest.mark.parametrize("prec,log2n,batch", REGISTERED)
+def test_every_registered_pair_matches_numpy_and_the_two_launch_plan(prec, log2n, batch):
+    """mixed stage configurations, groups side by side in one work-group, one to three work-groups per CU"""
+    G, pf, torch = _mods()
+    n = 1 << log2n
+    tol = TOL if prec == "f32" else 5e-15
+    with _env(PFFT_XCD_MIN_BATCH="64"):  # (below the measured crossover of the entry: correctness does not depend on it)
+        plan = G.make_descriptor([n], prec, batch=batch).commit()
+    assert list(plan.info().launches) == [1, 1], "one launch per execute"
+    x = _random(torch, batch * n, seed=log2n, prec=prec)
+    y = torch.full_like(x, float("nan"))
+    for _ in range(3):  # (repeated launches find the control block clean)
+        plan.compute_forward(x, y).wait()
+    _check_samples(x, y, batch, (0, batch // 2, batch - 1), n=n, tol=tol)
+    ex = (x.view(batch, n).abs().double() ** 2).sum(dim=1)
+    ey = (y.view(batch, n).abs().double() ** 2).sum(dim=1)
+    assert float(((ey / (n * ex)) - 1).abs().max()) < (1e-5 if prec == "f32" else 1e-12)
+    with _env(PFFT_NO_XCD_LOCAL="1"):
+        plan2 = G.make_descriptor([n], prec, batch=batch).commit()
+    assert min(plan2.info().launches) >= 2
+    y2 = torch.empty_like(x)
+    plan2.compute_forward(x, y2).wait()
+    d = (y - y2).abs().double().pow(2).sum(dim=0).sqrt() / y2.abs().double().pow(2).sum(dim=0).sqrt()
+    assert float(d) <= tol, float(d)
+    del y2
+    z = torch.empty_like(x)
+    plan.compute_backward(y, z).wait()
+    err = (z.view(batch, n) / n - x.view(batch, n)).abs().double().pow(2).sum(dim=1).sqrt() / ex.sqrt()
+    assert float(err.max()) <= tol, float(err.max())
 
 
 def test_xcd_local_plan_is_taken_and_matches_numpy_and_the_two_launch_plan():
     G, pf, torch = _mods()
-    for batch in (128, 131, 515):  # the smallest batch that takes the plan on 8 XCDs, ragged counts
+    for batch in (256, 259, 515):  # the smallest batch that takes the plan (0.5 GiB of data), ragged counts
         for placement in (1, 0):
             desc = G.make_descriptor([N], "f32", batch=batch, placement=placement)
             plan = desc.commit()
@@ -97,9 +134,13 @@ def test_small_batches_keep_the_two_launch_plan():
     G, pf, torch = _mods()
     plan = G.make_descriptor([N], "f32", batch=16).commit()
     assert min(plan.info().launches) >= 2
-    # other lengths and precisions have no registered pair
-    assert min(G.make_descriptor([1 << 16], "f32", batch=512).commit().info().launches) >= 2
-    assert min(G.make_descriptor([N], "f64", batch=256).commit().info().launches) >= 2
+    assert min(G.make_descriptor([N], "f32", batch=128).commit().info().launches) >= 2  # (0.25 GiB of data)
+    assert min(G.make_descriptor([1 << 16], "f32", batch=1024).commit().info().launches) >= 2
+    assert list(G.make_descriptor([1 << 16], "f32", batch=1536).commit().info().launches) == [1, 1]
+    # other lengths have no registered pair
+    assert min(G.make_descriptor([1 << 20], "f64", batch=256).commit().info().launches) >= 2
+    assert min(G.make_descriptor([1 << 15], "f32", batch=4096).commit().info().launches) >= 2
+    assert min(G.make_descriptor([3 << 16], "f32", batch=512).commit().info().launches) >= 2
 
 
 def test_repeated_launches_offsets_scales_and_graph_replay():
@@ -109,7 +150,8 @@ def test_repeated_launches_offsets_scales_and_graph_replay():
     batch = 200
     off_f, off_b = 24, 8
     desc = G.make_descriptor([N], "f32", batch=batch, fwd_offset=off_f, bwd_offset=off_b, fwd_scale=0.5, bwd_scale=2.0 / N)
-    plan = desc.commit()
+    with _env(PFFT_XCD_MIN_BATCH="64"):
+        plan = desc.commit()
     assert list(plan.info().launches) == [1, 1]
     x = _random(torch, batch * N + off_f, seed=9)
     y = torch.full((batch * N + off_b,), 7.0, dtype=torch.complex64, device="cuda")
@@ -124,7 +166,8 @@ def test_repeated_launches_offsets_scales_and_graph_replay():
     assert err <= TOL, err
     # graph capture: one kernel node, no memset node -- replays leave the control block as they found it
     s1 = torch.cuda.Stream()
-    plan_s = G.make_descriptor([N], "f32", batch=batch).commit(s1)
+    with _env(PFFT_XCD_MIN_BATCH="64"):
+        plan_s = G.make_descriptor([N], "f32", batch=batch).commit(s1)
     xin = torch.zeros(batch * N, dtype=torch.complex64, device="cuda")
     out = torch.empty_like(xin)
     torch.cuda.synchronize()

@@ -2,8 +2,8 @@
 // production pair of the same stage kernels (Infinity-Cache-sized chunks, writer / reader policies), bit for bit.
 //
 //   hipcc -O3 -std=c++17 --offload-arch=gfx950 -DTUNE_CASE=<case> tools/tune_xcd.hip -o build/tune_xcd_<case>
-//   cases: 16 = fp32 65536 (256 x 256), 18 = fp32 2^18 (512 x 512), 116 = fp64 65536 (256 x 256), 118 = fp64 2^18 (512 x 512),
-//          120 = fp64 2^20 (1024 x 1024, BASELINE config 3)
+//   cases: 16 = fp32 65536 (256 x 256), 17 = fp32 2^17 (256 x 512), 18 = fp32 2^18 (512 x 512), 116 / 117 / 118 = fp64 65536 /
+//          2^17 / 2^18, 120 = fp64 2^20 (1024 x 1024, BASELINE config 3); -DTUNE_WG=512: work-groups of 512 lanes (groups side by side)
 //   env:   TUNE_BATCH, TUNE_SWEEP=1 (slots / lag / work-groups per CU sweep), TUNE_SLOTS, TUNE_LAG, TUNE_LOOKAHEAD,
 //          TUNE_WG_PER_CU, TUNE_REPS
 #include <hip/hip_runtime.h>
@@ -30,30 +30,75 @@ using namespace pfa;
 #ifndef TUNE_FREERUN
 #define TUNE_FREERUN 0  // 1: timing experiment without claims and hand-off waits (results are garbage)
 #endif
+#ifndef TUNE_WG
+#define TUNE_WG 0  // lanes of the fused launch's work-groups (0: the larger of the two configurations')
+#endif
 #if TUNE_CASE == 116
 using T = double;
-using Cfg = strided_cfg<double, radix_list<16, 16>, 128, 8, 2, PFA_AUX_NT>;
+using CfgA = strided_cfg<double, radix_list<16, 16>, 128, 8, 2, PFA_AUX_NT>;
+using CfgB = CfgA;
 constexpr long long DEF_BATCH = 2048;
 #elif TUNE_CASE == 118
 using T = double;
-using Cfg = strided_cfg<double, radix_list<8, 8, 8>, 512, 8, 2, PFA_AUX_NT>;
+using CfgA = strided_cfg<double, radix_list<8, 8, 8>, 512, 8, 2, PFA_AUX_NT>;
+using CfgB = CfgA;
 constexpr long long DEF_BATCH = 256;
 #elif TUNE_CASE == 120
 using T = double;
-using Cfg = strided_cfg<double, radix_list<16, 8, 8>, 512, 8, 2, PFA_AUX_NT>;
+using CfgA = strided_cfg<double, radix_list<16, 8, 8>, 512, 8, 2, PFA_AUX_NT>;
+using CfgB = CfgA;
 constexpr long long DEF_BATCH = 128;
 #elif TUNE_CASE == 18
 using T = float;
-using Cfg = strided_cfg<float, radix_list<8, 8, 8>, 512, 16, 2, PFA_AUX_NT>;
+using CfgA = strided_cfg<float, radix_list<8, 8, 8>, 512, 16, 2, PFA_AUX_NT>;
+using CfgB = CfgA;
+constexpr long long DEF_BATCH = 1024;
+#elif TUNE_CASE == 17  // fp32 2^17 = 256 x 512: two 256-lane stage-A groups or one 512-lane stage-B group per task
+using T = float;
+using CfgA = strided_cfg<float, radix_list<16, 16>, 256, 16, 2, PFA_AUX_NT>;
+using CfgB = strided_cfg<float, radix_list<8, 8, 8>, 512, 16, 2, PFA_AUX_NT>;
+constexpr long long DEF_BATCH = 2048;
+#elif TUNE_CASE == 19  // fp32 2^19 = 512 x 1024
+using T = float;
+using CfgA = strided_cfg<float, radix_list<8, 8, 8>, 512, 16, 2, PFA_AUX_NT>;
+using CfgB = strided_cfg<float, radix_list<32, 32>, 512, 16, 2, PFA_AUX_NT>;
+constexpr long long DEF_BATCH = 512;
+#elif TUNE_CASE == 20  // fp32 2^20 = 1024 x 1024
+using T = float;
+using CfgA = strided_cfg<float, radix_list<16, 8, 8>, 1024, 16, 4, PFA_AUX_NT>;
+using CfgB = CfgA;
+constexpr long long DEF_BATCH = 256;
+#elif TUNE_CASE == 15  // fp32 2^15 = 128 x 256
+using T = float;
+using CfgA = strided_cfg<float, radix_list<16, 8>, 128, 16, 2, PFA_AUX_NT>;
+using CfgB = strided_cfg<float, radix_list<16, 16>, 256, 16, 2, PFA_AUX_NT>;
+constexpr long long DEF_BATCH = 8192;
+#elif TUNE_CASE == 191  // fp32 2^19 = 1024 x 512: two 512-lane stage-B groups side by side
+using T = float;
+using CfgA = strided_cfg<float, radix_list<16, 8, 8>, 1024, 16, 4, PFA_AUX_NT>;
+using CfgB = strided_cfg<float, radix_list<8, 8, 8>, 512, 16, 2, PFA_AUX_NT>;
+constexpr long long DEF_BATCH = 512;
+#elif TUNE_CASE == 119  // fp64 2^19 = 512 x 1024
+using T = double;
+using CfgA = strided_cfg<double, radix_list<8, 8, 8>, 512, 8, 2, PFA_AUX_NT>;
+using CfgB = strided_cfg<double, radix_list<16, 8, 8>, 512, 8, 2, PFA_AUX_NT>;
+constexpr long long DEF_BATCH = 256;
+#elif TUNE_CASE == 117  // fp64 2^17 = 256 x 512
+using T = double;
+using CfgA = strided_cfg<double, radix_list<16, 16>, 128, 8, 2, PFA_AUX_NT>;
+using CfgB = strided_cfg<double, radix_list<8, 8, 8>, 512, 8, 2, PFA_AUX_NT>;
 constexpr long long DEF_BATCH = 1024;
 #else
 using T = float;
-using Cfg = strided_cfg<float, radix_list<16, 16>, 256, 16, 2, PFA_AUX_NT>;
+using CfgA = strided_cfg<float, radix_list<16, 16>, 256, 16, 2, PFA_AUX_NT>;
+using CfgB = CfgA;
 constexpr long long DEF_BATCH = 4096;
 #endif
-constexpr long long N1 = Cfg::N, N2 = Cfg::N, N = N1 * N2;
-using CfgW = typename xcd_with_aux<Cfg, PFA_AUX_WRITER>::type;
-using CfgR = typename xcd_with_aux<Cfg, PFA_AUX_READER>::type;
+constexpr int XWG = TUNE_WG != 0 ? TUNE_WG : (CfgA::WG > CfgB::WG ? CfgA::WG : CfgB::WG);
+using XL = xcd_layout<CfgA, CfgB, XWG>;
+constexpr long long N1 = CfgA::N, N2 = CfgB::N, N = N1 * N2;
+using CfgW = typename xcd_with_aux<CfgA, PFA_AUX_WRITER>::type;
+using CfgR = typename xcd_with_aux<CfgB, PFA_AUX_READER>::type;
 
 static long long g_batch = DEF_BATCH;
 static int g_cus = 256;
@@ -91,12 +136,13 @@ __global__ void xcc_census(unsigned* o) {
 
 static int g_stw_levels, g_stw_shift;
 static void* g_stw_tab;
-static cx<T>* g_tw;
+static cx<T>*g_tw_a, *g_tw_b;
 
 static strided_args args_a(const T* in, T* scratch, long long nb, bool slots) {
   strided_args a{};
-  const int t = Cfg::FPW;
-  a.in = in; a.out = scratch; a.tw = g_tw; a.total = nb * N2; a.inner = N2;
+  const int t = CfgA::FPW;
+  a.in = in; a.out = scratch; a.tw = g_tw_a; a.total = nb * N2; a.inner = N2;
+  if (slots) { a.twl_lds_off = (unsigned)(XL::TWL_A * sizeof(cx<T>)); a.stw_lds_off = (unsigned)(XL::STW * sizeof(cx<T>)); }
   a.in_dist_outer = N; a.out_dist_outer = slots ? 0 : N; a.in_stride = (unsigned)N2; a.in_fdist = 1;
   a.scale = 1.0; a.stw_tab = g_stw_tab; a.stw_levels = g_stw_levels; a.stw_lshift = g_stw_shift; a.stw_cdiv = 1;
   a.out_gdist = N1 * t; a.out_stride = (unsigned)t; a.out_fdist = 1;
@@ -104,8 +150,9 @@ static strided_args args_a(const T* in, T* scratch, long long nb, bool slots) {
 }
 static strided_args args_b(const T* scratch, T* out, long long nb, bool slots) {
   strided_args a{};
-  const int t = Cfg::FPW;
-  a.in = scratch; a.out = out; a.tw = g_tw; a.total = nb * N1; a.inner = N1;
+  const int t = CfgA::FPW;
+  a.in = scratch; a.out = out; a.tw = g_tw_b; a.total = nb * N1; a.inner = N1;
+  if (slots) { a.twl_lds_off = (unsigned)(XL::TWL_B * sizeof(cx<T>)); a.stw_lds_off = (unsigned)(XL::STW * sizeof(cx<T>)); }
   a.in_dist_outer = slots ? 0 : N; a.out_dist_outer = N; a.out_stride = (unsigned)N1; a.out_fdist = 1;
   a.scale = 1.0; a.stw_cdiv = 1;
   int sh = 0; while ((1 << sh) < t) ++sh;
@@ -149,7 +196,8 @@ int main() {
     }
     CK(hipMalloc(&g_stw_tab, tab.size() * sizeof(tab[0]))); CK(hipMemcpy(g_stw_tab, tab.data(), tab.size() * sizeof(tab[0]), hipMemcpyHostToDevice));
   }
-  g_tw = make_twiddles<typename Cfg::Seq>();
+  g_tw_a = make_twiddles<typename CfgA::Seq>();
+  g_tw_b = make_twiddles<typename CfgB::Seq>();
   const size_t stw_bytes = ((size_t)g_stw_levels << g_stw_shift) * sizeof(cx<T>);
   const double bytes = 2.0 * N * sizeof(cx<T>) * g_batch;
   printf("N = %lld x %lld, batch %lld, %s, %d CUs, transform %zu KiB\n", N1, N2, g_batch, sizeof(T) == 4 ? "fp32" : "fp64", g_cus, (size_t)(N * sizeof(cx<T>)) >> 10);
@@ -158,7 +206,7 @@ int main() {
   {
     const void* fa = (const void*)&stockham_strided_kernel<CfgW, false, 1>;
     const void* fb = (const void*)&stockham_strided_kernel<CfgR, false, 0, 0, 1>;
-    const size_t lds_a = strided_lds_bytes<Cfg>() + stw_bytes, lds_b = strided_lds_bytes<Cfg>();
+    const size_t lds_a = strided_lds_bytes<CfgA>() + stw_bytes, lds_b = strided_lds_bytes<CfgB>();
     CK(hipFuncSetAttribute(fa, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a));
     CK(hipFuncSetAttribute(fb, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b));
     const size_t per = (size_t)N * sizeof(cx<T>);
@@ -169,9 +217,9 @@ int main() {
       for (long long b0 = 0; b0 < g_batch; b0 += chunk) {
         const long long nb = std::min(chunk, g_batch - b0);
         const strided_args aa = args_a(in + 2 * b0 * N, scratch, nb, false);
-        hipLaunchKernelGGL((stockham_strided_kernel<CfgW, false, 1>), dim3(grid_of(fa, Cfg::WG, lds_a, nb * N2 / Cfg::FPW, 4)), dim3(Cfg::WG), lds_a, 0, aa);
+        hipLaunchKernelGGL((stockham_strided_kernel<CfgW, false, 1>), dim3(grid_of(fa, CfgA::WG, lds_a, nb * N2 / CfgA::FPW, 4)), dim3(CfgA::WG), lds_a, 0, aa);
         const strided_args ab = args_b(scratch, ref + 2 * b0 * N, nb, false);
-        hipLaunchKernelGGL((stockham_strided_kernel<CfgR, false, 0, 0, 1>), dim3(grid_of(fb, Cfg::WG, lds_b, nb * N1 / Cfg::FPW, 4)), dim3(Cfg::WG), lds_b, 0, ab);
+        hipLaunchKernelGGL((stockham_strided_kernel<CfgR, false, 0, 0, 1>), dim3(grid_of(fb, CfgB::WG, lds_b, nb * N1 / CfgB::FPW, 4)), dim3(CfgB::WG), lds_b, 0, ab);
       }
       CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
       float ms; CK(hipEventElapsedTime(&ms, e0, e1)); if (rep) tt.push_back(ms);
@@ -185,12 +233,12 @@ int main() {
   unsigned n_queues = 0; CK(hipMemcpy(&n_queues, d_census, 4, hipMemcpyDeviceToHost));
   printf("XCC ids seen: %u\n", n_queues);
   unsigned long long* d_diff; CK(hipMalloc(&d_diff, 8));
-  const void* fx = (const void*)&stockham_xcd_fourstep_kernel<Cfg, Cfg, false, 1, 1, TUNE_FREERUN, TUNE_OCCX>;
+  const void* fx = (const void*)&stockham_xcd_fourstep_kernel<CfgA, CfgB, false, 1, 1, TUNE_FREERUN, TUNE_OCCX, XWG>;
   hipFuncAttributes fattr; CK(hipFuncGetAttributes(&fattr, fx));
   printf("fused kernel: %d VGPRs, %d SGPRs... numRegs %d, static LDS %zu\n", fattr.numRegs, 0, fattr.numRegs, fattr.sharedSizeBytes);
   auto run = [&](int slots, int lag, int lookahead, int wg_per_cu, bool verbose) {
     const int map_log2 = 8;
-    const size_t own = xcd_lds_bytes<Cfg>(stw_bytes);
+    const size_t own = xcd_lds_bytes<CfgA, CfgB, XWG>(stw_bytes);
     // pad the LDS request so that exactly wg_per_cu work-groups fit a CU
     size_t lds = own;
     if (wg_per_cu > 0) {
@@ -199,7 +247,7 @@ int main() {
       if (want >= own) lds = std::max(own, std::min(want, (cu / (wg_per_cu + 1) + 16 + 15) & ~(size_t)15));
     }
     CK(hipFuncSetAttribute(fx, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    int per_cu = 0; CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fx, Cfg::WG, lds));
+    int per_cu = 0; CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fx, XWG, lds));
     const unsigned grid = (unsigned)(per_cu * g_cus);
     const unsigned words = xcd_ctl_words((int)n_queues, slots, map_log2);
     unsigned* ctl; CK(hipMalloc(&ctl, words * 4)); CK(hipMemset(ctl, 0, words * 4));
@@ -209,7 +257,7 @@ int main() {
     x.a = args_a(in, scratch, g_batch, true);
     x.b = args_b(scratch, out, g_batch, true);
     x.ctl = ctl; x.batch = g_batch; x.n_queues = (int)n_queues; x.slots = slots; x.map_log2 = map_log2;
-    x.lag = lag; x.lookahead = lookahead; x.max_iters = (unsigned)((g_batch + lag + lookahead + 2) * (N1 / Cfg::FPW + N2 / Cfg::FPW)); x.lds_ctl_off = (unsigned)(own - XCD_LDS_CTL_BYTES);
+    x.lag = lag; x.lookahead = lookahead; x.max_iters = (unsigned)((g_batch + lag + lookahead + 6) * (N1 / CfgA::FPW + N2 / CfgA::FPW)); x.lds_ctl_off = (unsigned)(own - XCD_LDS_CTL_BYTES);
     unsigned long long* d_prof; CK(hipMalloc(&d_prof, 128)); x.prof = d_prof;
     std::vector<double> tt;
     unsigned long long bad = 0; unsigned tmo = 0;
@@ -217,7 +265,7 @@ int main() {
       if (rep == 0) CK(hipMemset(out, 0xff, total * sizeof(T)));
       CK(hipMemset(d_prof, 0, 128));
       CK(hipEventRecord(e0));
-      hipLaunchKernelGGL((stockham_xcd_fourstep_kernel<Cfg, Cfg, false, 1, 1, TUNE_FREERUN, TUNE_OCCX>), dim3(grid), dim3(Cfg::WG), lds, 0, x);
+      hipLaunchKernelGGL((stockham_xcd_fourstep_kernel<CfgA, CfgB, false, 1, 1, TUNE_FREERUN, TUNE_OCCX, XWG>), dim3(grid), dim3(XWG), lds, 0, x);
       CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
       float ms; CK(hipEventElapsedTime(&ms, e0, e1)); if (rep) tt.push_back(ms);
       if (rep == 0) printf("   first launch %.3f ms\n", ms);
@@ -264,7 +312,7 @@ int main() {
   const int wpc = getenv("TUNE_WG_PER_CU") ? atoi(getenv("TUNE_WG_PER_CU")) : 0;
   run(slots_log2, lag, look, wpc, true);
   if (getenv("TUNE_SWEEP")) {
-    const int pts[][2] = {{3, 2}, {4, 2}, {4, 3}, {5, 3}, {5, 4}, {6, 4}, {6, 5}, {8, 5}, {8, 7}, {12, 8}, {16, 8}};
+    const int pts[][2] = {{3, 2}, {4, 2}, {4, 3}, {5, 3}, {5, 4}, {6, 4}, {6, 5}, {8, 5}, {8, 7}, {12, 8}, {16, 8}, {24, 12}, {32, 16}, {32, 24}};
     for (int w : {2, 3, 4}) for (auto& pt : pts) run(pt[0], pt[1], look, w, true);  // slots > lag
   }
   return 0;
