@@ -45,7 +45,7 @@ std::vector<std::vector<int>> spec_radix_candidates(int precision, long long n, 
 bool plan_measure_enabled();
 /// the recorded choice for (arch, precision, n): process table, then the JIT cache directory
 /// (`choice_<arch>_<f32|f64>_<n>.txt`, next to the code objects); empty when there is none
-std::vector<int> plan_choice_lookup(const std::string& arch, int precision, long long n);
+std::vector<int> plan_choice_lookup(const std::string& arch, int precision, long long n, int max_factor = 61);
 /// (an empty sequence forgets the record)
 void plan_choice_store(const std::string& arch, int precision, long long n, const std::vector<int>& radices);
 

@@ -223,6 +223,7 @@ struct plan_t {
   int device = 0;
   int n_cus = 0;
   size_t max_lds = 0;
+  long long forced_n1 = 0;
   std::vector<stage> stages[2];
   std::shared_ptr<shared_allocs> tables = std::make_shared<shared_allocs>();  // twiddles: shared by copies
   void* scratch = nullptr;                                                     // scratch: one per copy
@@ -578,6 +579,100 @@ struct plan_t {
     return k;
   }
 
+  /// Measured planning of the four-step split (PFFT_PLAN_MEASURE=1): every n1 x n2 with both factors in 32 ... 4096, no
+  /// more than 16 : 1 apart, that the strided tier can run -- the planner's own choice first -- is committed as a plan of its own (this descriptor, a batch
+  /// of 256 MiB, plan_t's forced_n1), timed forward on the plan's stream, and the winner is recorded next to the code
+  /// objects like the radix choices (`choice_<arch>_<f32|f64>_<n>.txt` holds "n1 n2").
+  long long measured_split(long long n, long long count, long long static_n1) {
+    const std::string arch = jit_device_arch();
+    const std::vector<int> rec = plan_choice_lookup(arch, desc.precision, n, 1 << 20);
+    if (rec.size() == 2 && strided_fpw(rec[0], rec[1]) > 0 && strided_fpw(rec[1], rec[0]) > 0) return rec[0];
+    std::vector<long long> cands{static_n1};
+    for (long long c = 32; c <= 4096; ++c) {
+      if (n % c != 0 || c == static_n1) continue;
+      const long long m = n / c;
+      if (m < 32 || m > 4096 || std::max(c, m) > 16 * std::min(c, m) || strided_fpw(c, m) <= 0 || strided_fpw(m, c) <= 0) continue;
+      cands.push_back(c);
+    }
+    if (cands.size() == 1) return static_n1;
+    const size_t eb = elem_bytes();
+    const size_t per = static_cast<size_t>(n) * eb;
+    const long long batch = std::max<long long>(1, std::min<long long>(count, static_cast<long long>((size_t{256} << 20) / per)));
+    const size_t bytes = static_cast<size_t>(batch) * per;
+    void *in = nullptr, *out = nullptr;
+    if (hipMalloc(&in, bytes) != hipSuccess || hipMalloc(&out, bytes) != hipSuccess) {
+      if (in != nullptr) (void)hipFree(in);
+      return static_n1;  // no room to measure: the static rule
+    }
+    fill_uniform(in, bytes);
+    pfft_desc_t d = desc;
+    d.number_of_transforms = static_cast<uint64_t>(batch);
+    d.placement = PFFT_OUT_OF_PLACE;
+    d.forward_offset = 0;
+    d.backward_offset = 0;
+    const size_t half = bytes / 2;  // (split storage: the two planes inside the same allocations)
+    const bool split = desc.complex_storage == PFFT_SPLIT_COMPLEX;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    hip_check(hipEventCreate(&e0), "hipEventCreate");
+    hip_check(hipEventCreate(&e1), "hipEventCreate");
+    long long best = static_n1;
+    double best_ms = 1e30;
+    for (long long c : cands) {
+      float ms = 0.f;
+      bool ok = true;
+      try {
+        plan_t sub(d, stream, c);
+        for (int rep = 0; rep < 7 && ok; ++rep) {
+          if (rep == 2) ok = hipEventRecord(e0, stream) == hipSuccess;
+          sub.execute(PFFT_FORWARD, in, split ? static_cast<char*>(in) + half : nullptr, out,
+                      split ? static_cast<char*>(out) + half : nullptr);
+        }
+        ok = ok && hipEventRecord(e1, stream) == hipSuccess && hipEventSynchronize(e1) == hipSuccess &&
+             hipEventElapsedTime(&ms, e0, e1) == hipSuccess;
+      } catch (const std::exception&) {
+        ok = false;
+        (void)hipStreamSynchronize(stream);
+      }
+      if (getenv("PFFT_JIT_VERBOSE") != nullptr) {
+        std::fprintf(stderr, "[portfft_amd plan] n=%lld split %lld x %lld %.3f ms per %lld transforms%s\n", n, c, n / c, ms / 5,
+                     batch, ok ? "" : " (failed)");
+      }
+      if (ok && ms < best_ms) {
+        best_ms = ms;
+        best = c;
+      }
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    (void)hipFree(in);
+    (void)hipFree(out);
+    if (best_ms < 1e30) plan_choice_store(arch, desc.precision, n, {static_cast<int>(best), static_cast<int>(n / best)});
+    return best;
+  }
+
+  /// uniform(-1, 1) scalars: a 1 MiB host block replicated by doubling copies on the plan's stream
+  void fill_uniform(void* dst, size_t bytes) {
+    const size_t block = std::min<size_t>(bytes, size_t{1} << 20);
+    std::vector<unsigned char> h(block);
+    unsigned long long z = 0x9E3779B97F4A7C15ull;
+    const size_t scalars = block / static_cast<size_t>(scalar_bytes());
+    for (size_t i = 0; i < scalars; ++i) {
+      z = z * 6364136223846793005ull + 1442695040888963407ull;
+      const double v = static_cast<double>(z >> 11) * (2.0 / 9007199254740992.0) - 1.0;
+      if (scalar_bytes() == 8) {
+        reinterpret_cast<double*>(h.data())[i] = v;
+      } else {
+        reinterpret_cast<float*>(h.data())[i] = static_cast<float>(v);
+      }
+    }
+    hip_check(hipMemcpyAsync(dst, h.data(), block, hipMemcpyHostToDevice, stream), "hipMemcpy");
+    hip_check(hipStreamSynchronize(stream), "hipStreamSynchronize");
+    for (size_t have = block; have < bytes; have *= 2) {
+      hip_check(hipMemcpyAsync(static_cast<char*>(dst) + have, dst, std::min(have, bytes - have), hipMemcpyDeviceToDevice, stream),
+                "hipMemcpy");
+    }
+  }
+
   /// Measured planning (PFFT_PLAN_MEASURE=1; the reference's rule is static, committed_descriptor_impl.hpp:210-313): the
   /// radix sequence of a runtime-specialised packed length is the fastest of the planner's top candidates
   /// (jit.cpp: spec_radix_candidates), timed here on the plan's stream over 256 MiB of random data, and recorded next to
@@ -600,27 +695,7 @@ struct plan_t {
       if (in != nullptr) (void)hipFree(in);
       return choice;  // no room to measure: the static rule
     }
-    {  // uniform(-1, 1) data: a 1 MiB host block replicated by doubling copies
-      const size_t block = std::min<size_t>(bytes, size_t{1} << 20);
-      std::vector<unsigned char> h(block);
-      unsigned long long z = 0x9E3779B97F4A7C15ull;
-      const size_t scalars = block / static_cast<size_t>(scalar_bytes());
-      for (size_t i = 0; i < scalars; ++i) {
-        z = z * 6364136223846793005ull + 1442695040888963407ull;
-        const double v = static_cast<double>(z >> 11) * (2.0 / 9007199254740992.0) - 1.0;
-        if (scalar_bytes() == 8) {
-          reinterpret_cast<double*>(h.data())[i] = v;
-        } else {
-          reinterpret_cast<float*>(h.data())[i] = static_cast<float>(v);
-        }
-      }
-      hip_check(hipMemcpyAsync(in, h.data(), block, hipMemcpyHostToDevice, stream), "hipMemcpy");
-      hip_check(hipStreamSynchronize(stream), "hipStreamSynchronize");
-      for (size_t have = block; have < bytes; have *= 2) {
-        hip_check(hipMemcpyAsync(static_cast<char*>(in) + have, in, std::min(have, bytes - have), hipMemcpyDeviceToDevice, stream),
-                  "hipMemcpy");
-      }
-    }
+    fill_uniform(in, bytes);
     hipEvent_t e0 = nullptr, e1 = nullptr;
     hip_check(hipEventCreate(&e0), "hipEventCreate");
     hip_check(hipEventCreate(&e1), "hipEventCreate");
@@ -1606,9 +1681,12 @@ struct plan_t {
         break;
       }
     }
-    if (const char* e = getenv("PFFT_GLOBAL_N1")) {  // experiments: force the first factor of the split
-      const long long c = std::atoll(e);
-      if (c >= 2 && n % c == 0 && strided_fpw(c, n / c) > 0 && strided_fpw(n / c, c) > 0) n1 = c;
+    long long want_n1 = forced_n1;
+    if (const char* e = getenv("PFFT_GLOBAL_N1")) want_n1 = std::atoll(e);  // experiments: force the first factor of the split
+    if (want_n1 >= 2 && n % want_n1 == 0 && strided_fpw(want_n1, n / want_n1) > 0 && strided_fpw(n / want_n1, want_n1) > 0) {
+      n1 = want_n1;
+    } else {
+      want_n1 = 0;
     }
     // ... otherwise the most balanced split whose two lengths both run on the generic tier
     for (long long c = static_cast<long long>(std::sqrt(static_cast<double>(n))); n1 == 0 && c >= 2; --c) {
@@ -1622,6 +1700,7 @@ struct plan_t {
            " (large prime factors are not supported)");
     }
     long long n2 = n / n1;
+    bool paired_split = false;
     // Stage pairs (below) need a registered stage-B entry for n2 and, for n1, a registered stage-A entry or a
     // runtime-specialised kernel of the same group width.  Among the splits that allow one, a SHORT stage A wins over
     // a balanced split -- several stage-A work-groups per CU, stage B on the best-tuned entries (n2 = 1024 / 512):
@@ -1635,7 +1714,7 @@ struct plan_t {
     // 0.375, on the registered 32-column entry 0.358; fp64 0.396 / 0.370).  A stage A narrower than a 128-byte line
     // never comes out of this search (5 * 2^18 as 640 x 2048 on 8 columns: 0.224 against 0.242), and stage-B entries whose
     // own output segments are that narrow (n2 = 2048 -- their tiles may still be a line wide, pair_tile) rank last.
-    if (desc.complex_storage == PFFT_INTERLEAVED_COMPLEX && jit_enabled() && getenv("PFFT_GLOBAL_N1") == nullptr &&
+    if (desc.complex_storage == PFFT_INTERLEAVED_COMPLEX && jit_enabled() && want_n1 == 0 &&
         getenv("PFFT_NO_FS_PAIRS") == nullptr && getenv("PFFT_NO_HALF_PAIRS") == nullptr &&
         getenv("PFFT_NO_TILED_SCRATCH") == nullptr && getenv("PFFT_NO_TILED_LANES") == nullptr &&
         getenv("PFFT_NO_PRECOMPILED") == nullptr && getenv("PFFT_DEBUG_GLOBAL") == nullptr) {
@@ -1681,7 +1760,41 @@ struct plan_t {
       if (above != 0 || below != 0) {
         n1 = above != 0 ? above : below;
         n2 = n / n1;
+        paired_split = true;
       }
+    }
+    // No registered entry pairs with any factor (10^5, 68640 = 2^5 3 5 11 13, ...): both stages are runtime-specialised and
+    // the balanced split is the worst shape for them -- two mid-sized stages, each alone on its CU behind three barriers.
+    // Measured over every divisor (tools/probes/split_sweep.py, fp32, fraction of the HBM peak, balanced -> best):
+    // 30000 0.247 -> 0.287, 40000 0.263 -> 0.307, 62500 0.229 -> 0.266, 68640 0.221 -> 0.299, 10^5 0.176 -> 0.270,
+    // 120000 0.158 -> 0.290, 250000 0.138 -> 0.256; a LONG stage A (400 ... 1000 points) in front of a SHORT stage B (60 ... 256)
+    // is at or within 10 % of the best of every one of them, n1 = 500 in front of n2 = 60 ... 240 at the very top of five.
+    // fp64 has no such pattern (68640: 260 x 264 0.373, 156 x 440 0.382, 480 x 143 0.282; 10^5: 500 x 200 0.364, 250 x 400
+    // 0.287): PFFT_PLAN_MEASURE=1 times the candidates instead (measured_split).
+    if (!paired_split && desc.precision == PFFT_PRECISION_F32 && desc.complex_storage == PFFT_INTERLEAVED_COMPLEX &&
+        jit_enabled() && want_n1 == 0 && getenv("PFFT_NO_SPLIT_RULE") == nullptr &&
+        getenv("PFFT_DEBUG_GLOBAL") == nullptr) {
+      long long best = 0;
+      double best_d = 0;
+      for (long long c = 384; c <= 1024; ++c) {
+        if (n % c != 0) continue;
+        const long long m = n / c;
+        if (m < 60 || m > 256 || strided_fpw(c, m) <= 0 || strided_fpw(m, c) <= 0) continue;
+        const double d = std::fabs(std::log(static_cast<double>(c) / 500.0));
+        if (best == 0 || d < best_d) {
+          best = c;
+          best_d = d;
+        }
+      }
+      if (best != 0) {
+        n1 = best;
+        n2 = n / best;
+      }
+    }
+    if (want_n1 == 0 && plan_measure_enabled() && jit_enabled() && in_buf == BUF_IN && out_buf == BUF_OUT &&
+        getenv("PFFT_DEBUG_GLOBAL") == nullptr) {
+      n1 = measured_split(n, count, n1);
+      n2 = n / n1;
     }
     // Chunking (the reference's num_batches_in_l2 idea, committed_descriptor_impl.hpp:603-611) bounds the scratch.
     // Measured on MI355X (profiles/r1_notes.md): cache-sized chunks (16-256 MiB) do NOT make stage B's reads hit the
@@ -2089,7 +2202,8 @@ struct plan_t {
     }
   }
 
-  plan_t(const pfft_desc_t& d, hipStream_t s) : desc(d), stream(s) {
+  /// `forced_n1`: the first factor of the four-step split (measured_split's candidates; 0: the planner's rules)
+  plan_t(const pfft_desc_t& d, hipStream_t s, long long forced_n1_ = 0) : desc(d), stream(s), forced_n1(forced_n1_) {
     validate(desc);
     hip_check(hipGetDevice(&device), "hipGetDevice");
     hipDeviceProp_t prop;

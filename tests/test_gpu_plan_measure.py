@@ -18,10 +18,11 @@ sys.path.insert(0, %r); sys.path.insert(0, %r)
 import numpy as np, torch
 import gpu_utils as G, helpers as H
 n, batch = int(sys.argv[1]), 64
-plan = G.make_descriptor([n], "f32", batch=batch).commit()
+prec = sys.argv[2] if len(sys.argv) > 2 else "f32"
+plan = G.make_descriptor([n], prec, batch=batch).commit()
 d = plan.info().dims[0]
 g = torch.Generator(device="cuda").manual_seed(1)
-x = torch.empty(batch * n, dtype=torch.complex64, device="cuda")
+x = torch.empty(batch * n, dtype=torch.complex64 if prec == "f32" else torch.complex128, device="cuda")
 torch.view_as_real(x).uniform_(-1, 1, generator=g)
 y = torch.empty_like(x)
 plan.compute_forward(x, y).wait()
@@ -31,17 +32,17 @@ print(json.dumps({"factors": [int(d.factors[i]) for i in range(d.n_factors)], "t
 """ % (ROOT, os.path.join(ROOT, "tests"))
 
 
-def _commit(n, cache, measure, verbose=False):
+def _commit(n, cache, measure, verbose=False, prec="f32"):
     env = dict(os.environ, PFFT_JIT_CACHE_DIR=str(cache))
     env.pop("PFFT_PLAN_MEASURE", None)
     if measure:
         env["PFFT_PLAN_MEASURE"] = "1"
     if verbose:
         env["PFFT_JIT_VERBOSE"] = "1"
-    p = subprocess.run([sys.executable, "-c", CHILD, str(n)], env=env, capture_output=True, text=True, timeout=600)
+    p = subprocess.run([sys.executable, "-c", CHILD, str(n), prec], env=env, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stdout + p.stderr
     out = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
-    assert out["err"] <= 2e-6, out
+    assert out["err"] <= (2e-6 if prec == "f32" else 5e-15), out
     return out["factors"], p.stderr
 
 
@@ -70,3 +71,30 @@ def test_measured_choice_is_recorded_and_honoured(tmp_path):
     rec.write_text("7 7 7\n")  # a record of another length is ignored
     ignored, _ = _commit(n, d, measure=False)
     assert ignored == static
+
+
+def test_measured_four_step_split_is_recorded_and_honoured(tmp_path):
+    """plan.cpp measured_split: the n1 x n2 of a GLOBAL-tier length without a registered stage pair"""
+    n = 30000
+    static, _ = _commit(n, tmp_path / "a", measure=False, prec="f64")
+    assert static[0] * static[1] == n
+    measured, log = _commit(n, tmp_path / "b", measure=True, verbose=True, prec="f64")
+    assert log.count("[portfft_amd plan] n=%d split" % n) >= 4, "the candidates were timed: " + log[-400:]
+    record = tmp_path / "b" / ("choice_gfx950_f64_%d.txt" % n)
+    assert record.exists() and [int(v) for v in record.read_text().split()] == measured[:2]
+    again, log2 = _commit(n, tmp_path / "b", measure=True, verbose=True, prec="f64")
+    assert again == measured and "split" not in log2, log2[-400:]
+    off, _ = _commit(n, tmp_path / "b", measure=False, prec="f64")
+    assert off == static
+    # a hand-written record is honoured; one whose product is another length is not
+    d = tmp_path / "c"
+    d.mkdir(mode=0o700)
+    rec = d / ("choice_gfx950_f64_%d.txt" % n)
+    rec.write_text("120 250\n")
+    rec.chmod(0o600)
+    forced, _ = _commit(n, d, measure=True, prec="f64")
+    assert forced[:2] == [120, 250]
+    rec.write_text("120 251\n")
+    # (the record is ignored and the split is measured again -- and recorded over it)
+    redone, _ = _commit(n, d, measure=True, prec="f64")
+    assert redone[0] * redone[1] == n
