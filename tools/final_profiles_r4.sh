@@ -6,8 +6,8 @@ set -u
 cd "$GRAFT_REPO_ROOT" || exit 1
 export TMPDIR=/tmp
 out=gpurun_out/final_r4; mkdir -p $out
-ALL="c3 c5 ref16 ref256 ref4096 ref65536 ref9800 ref15360 ref68640 g32_15 g32_17 g32_18 g32_20 g32_21 g32_22 g32_24 g64_16"
-PMC="c2 c3 c5 ref65536 g32_15 g32_17 g32_18 g32_20 g32_22 g64_16"
+ALL="c3 c5 ref16 ref256 ref4096 ref65536 ref9800 ref15360 ref68640 g32_15 g32_17 g32_18 g32_19 g32_20 g32_21 g32_22 g32_24 g64_16 g64_17 g64_18"
+PMC="c2 c3 c5 ref65536 g32_15 g32_17 g32_18 g32_19 g32_20 g32_22 g64_16 g64_17 g64_18"
 python bench.py > $out/r4_bench_c2.json 2> $out/c2.err
 for c in $ALL; do python bench.py --config $c --no-cpu-baseline > $out/r4_bench_$c.json 2> $out/$c.err; done
 for c in c2 $ALL; do
@@ -31,13 +31,16 @@ PY
 sum c2 stockham_wg 4294967296 1 "C2 fp32 N=4096 x 65536, one launch"
 sum c3 stockham_strided 4294967296 8 "C3 fp64 N=2^20 x 128: four-step, 8 chunks of 256 MiB; FETCH_SIZE counts Infinity-Cache hits"
 sum c5 stockham_rows2d,stockham_strided 4294967296 8 "C5 fp32 1024x1024 x 256: two-pass 2-D plan, 8 chunks of 256 MiB"
-sum ref65536 stockham_strided 2147483648 4 "fp32 N=65536 x 2048: four-step, 4 chunks of 256 MiB"
+sum ref65536 stockham_xcd_fourstep 2147483648 1 "fp32 N=65536 x 2048: XCD-local single launch (256 x 256), slot rings of 24 transforms per XCD"
 sum g32_15 stockham_strided 2147483648 4 "fp32 N=32768 x 4096: four-step (128 x 256), 4 chunks of 256 MiB"
-sum g32_17 stockham_strided 2147483648 4 "fp32 N=2^17 x 1024: four-step, 4 chunks of 256 MiB"
+sum g32_17 stockham_xcd_fourstep 2147483648 1 "fp32 N=2^17 x 1024: XCD-local single launch (256 x 512), slot rings of 24 transforms per XCD"
+sum g32_19 stockham_xcd_fourstep 2147483648 1 "fp32 N=2^19 x 256: XCD-local single launch (1024 x 512), slot rings of 6 transforms per XCD"
 sum g32_18 stockham_xcd_fourstep 2147483648 1 "fp32 N=2^18 x 512: XCD-local single launch (512 x 512), slot rings of 12 transforms per XCD"
 sum g32_20 stockham_strided 2147483648 4 "fp32 N=2^20 x 128: four-step, 4 chunks of 256 MiB"
 sum g32_22 stockham_strided 2147483648 4 "fp32 N=2^22 x 32: four-step, 4 chunks of 256 MiB"
-sum g64_16 stockham_strided 2147483648 4 "fp64 N=65536 x 1024: four-step (128 x 512), 4 chunks of 256 MiB"
+sum g64_16 stockham_xcd_fourstep 2147483648 1 "fp64 N=65536 x 1024: XCD-local single launch (256 x 256), slot rings of 16 transforms per XCD"
+sum g64_17 stockham_xcd_fourstep 2147483648 1 "fp64 N=2^17 x 512: XCD-local single launch (256 x 512), slot rings of 16 transforms per XCD"
+sum g64_18 stockham_xcd_fourstep 2147483648 1 "fp64 N=2^18 x 256: XCD-local single launch (512 x 512), slot rings of 4 transforms per XCD"
 cp $out/r4_pmc_traffic*.json profiles/ 2>/dev/null
 for c in $PMC; do
   if [ $c = c2 ]; then python bench.py > $out/r4_bench_c2.json 2> $out/c2.err; else python bench.py --config $c --no-cpu-baseline > $out/r4_bench_$c.json 2> $out/$c.err; fi
