@@ -11,6 +11,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -1543,6 +1544,7 @@ struct plan_t {
     if (map_log2 > 14) return false;
     x.map_log2 = map_log2;
     x.max_iters = static_cast<unsigned>(std::min<long long>((count + lag + lookahead + 6) * tpt, 0xFFFFFFF0ll));
+    if (const char* e = getenv("PFFT_XCD_MAX_ITERS")) x.max_iters = static_cast<unsigned>(std::atoll(e));  // tests: provoke a failed launch
     x.lds_ctl_off = static_cast<unsigned>(own - XCD_LDS_CTL_BYTES);
     x.prof = nullptr;
     const size_t ring = static_cast<size_t>(n_queues) * static_cast<size_t>(slots) * static_cast<size_t>(n) * elem_bytes();
@@ -2305,6 +2307,8 @@ struct plan_t {
       x.b.out = static_cast<char*>(out_re) + static_cast<size_t>(s.out_addr.offset) * elem_bytes();
       x.ctl = static_cast<unsigned*>(xcd_ctl);
       x.keep_on_timeout = getenv("PFFT_XCD_DUMP") != nullptr ? 1 : 0;
+      x.host_failures = xcd_failure_word();
+      xcd_ever_launched().store(true, std::memory_order_relaxed);
       hip_check(s.xcd->launch(stream, s.grid, s.lds_bytes, x, s.backward), "kernel launch");
       if (xcd_check_enabled()) check_xcd_timeouts();
       return;
@@ -2530,6 +2534,7 @@ struct plan_t {
       fail(PFFT_INVALID_CONFIGURATION, "Invalid direction ", direction);
     }
     if (in_re == nullptr || out_re == nullptr) fail(PFFT_INVALID_CONFIGURATION, "null data pointer");
+    if (xcd_ctl != nullptr) check_xcd_failures();
     device_guard dg(device);  // launches go to the device the plan was committed on, whatever is current
     const std::vector<stage>& st = stages[direction];
     bool rode = false;
@@ -2574,6 +2579,34 @@ struct plan_t {
     return rode;
   }
 
+  /// XCD-local launches never fail silently: every spin of the kernel is bounded, a launch in which one gave up (or whose
+  /// iteration bound ended a work-group early) has computed garbage, and its last work-group out adds 1 to this word of
+  /// pinned host memory (one per process, visible to every device).  The library reads it -- a host load -- at every
+  /// execute, plan / queue / event wait, and raises `internal_error` from then on.
+  static unsigned* xcd_failure_word() {
+    static unsigned* const w = [] {
+      void* p = nullptr;
+      if (hipHostMalloc(&p, 64, hipHostMallocPortable | hipHostMallocMapped) != hipSuccess) return static_cast<unsigned*>(nullptr);
+      std::memset(p, 0, 64);
+      return static_cast<unsigned*>(p);
+    }();
+    return w;
+  }
+  static void check_xcd_failures() {
+    const unsigned* w = xcd_failure_word();
+    if (w != nullptr && __atomic_load_n(w, __ATOMIC_RELAXED) != 0u) {
+      fail(PFFT_INTERNAL_ERROR, "an XCD-local four-step launch of this process gave up on a hand-off wait: the output of that ",
+           "execute is invalid (PFFT_XCD_CHECK=1 PFFT_XCD_DUMP=1 names the launch; PFFT_NO_XCD_LOCAL=1 avoids the plan)");
+    }
+  }
+  /// (event / queue waits: only once a plan of this process has launched such a kernel)
+  static std::atomic<bool>& xcd_ever_launched() {
+    static std::atomic<bool> f{false};
+    return f;
+  }
+  static void check_xcd_failures_if_any() {
+    if (xcd_ever_launched().load(std::memory_order_relaxed)) check_xcd_failures();
+  }
   /// PFFT_XCD_CHECK=1 (tests): wait for every XCD-local launch and fail when one of its bounded hand-off waits gave up
   static bool xcd_check_enabled() {
     const char* e = getenv("PFFT_XCD_CHECK");
@@ -2794,6 +2827,7 @@ pfft_status pfft_event_wait(void* event) {
     if (event == nullptr) return;
     const hipError_t e = hipEventSynchronize(static_cast<hipEvent_t>(event));
     if (e != hipSuccess) pfa::fail(PFFT_HIP_ERROR, "hipEventSynchronize: ", hipGetErrorString(e));
+    pfa::plan_t::check_xcd_failures_if_any();
   });
 }
 
@@ -2853,6 +2887,7 @@ pfft_status pfft_queue_wait(void* hip_stream) {
   return pfa::guarded([&] {
     const hipError_t e = hipStreamSynchronize(static_cast<hipStream_t>(hip_stream));
     if (e != hipSuccess) pfa::fail(PFFT_HIP_ERROR, "hipStreamSynchronize: ", hipGetErrorString(e));
+    pfa::plan_t::check_xcd_failures_if_any();
   });
 }
 
@@ -2871,6 +2906,7 @@ pfft_status pfft_plan_wait(pfft_plan_t* plan) {
     if (plan == nullptr) pfa::fail(PFFT_INVALID_CONFIGURATION, "null plan");
     const hipError_t e = hipStreamSynchronize(plan->impl->stream);
     if (e != hipSuccess) pfa::fail(PFFT_HIP_ERROR, "hipStreamSynchronize: ", hipGetErrorString(e));
+    if (plan->impl->xcd_ctl != nullptr) pfa::plan_t::check_xcd_failures();
   });
 }
 

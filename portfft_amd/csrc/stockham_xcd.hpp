@@ -420,6 +420,8 @@ __global__ __launch_bounds__(WG, OCCX) void stockham_xcd_fourstep_kernel(const x
       }
       par ^= 1u;
     }
+    // the iteration bound ended the loop with tickets still in hand: their tasks are not done -- say so (site 4)
+    if (more && left != 0 && threadIdx.x % 64u == 0u) xcd_give_up(tmo, 4u, s_ctl[0], x.max_iters, 0u, 0u);
 #ifdef PFA_XCD_PROF
     {
       PFA_XCD_STAMP(p_end);
@@ -439,6 +441,10 @@ __global__ __launch_bounds__(WG, OCCX) void stockham_xcd_fourstep_kernel(const x
     s_ctl[9] = old == gridDim.x - 1u ? 1u : 0u;
   }
   __syncthreads();
+  // a launch that gave up anywhere reports to the host: a word of pinned memory the library reads at its next call
+  if (s_ctl[9] != 0u && threadIdx.x == 0 && x.host_failures != nullptr && xcd_load(tmo) != 0u) {
+    __hip_atomic_fetch_add(x.host_failures, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
   if (s_ctl[9] != 0u && !(x.keep_on_timeout != 0 && xcd_load(tmo) != 0u)) {
     // counters only: tickets, done_a / done_b, the launch-wide words.  The claim maps are left alone (xcd_args.hpp);
     // the epoch makes their entries invalid for the next launch.

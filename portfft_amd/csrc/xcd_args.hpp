@@ -46,6 +46,7 @@ struct xcd_args {
   unsigned lds_ctl_off; // byte offset of the kernel's XCD_LDS_CTL_BYTES of control words in its dynamic LDS
   unsigned long long* prof;  // tuner builds (PFA_XCD_PROF) only: cycle sums of wave 0 of every work-group
   int keep_on_timeout;       // diagnosis (PFFT_XCD_DUMP): a launch with a wait that gave up leaves its counters as they were
+  unsigned* host_failures;   // pinned host word (or null): the last work-group out adds 1 when the launch's timeout word is set
 };
 
 }  // namespace pfa

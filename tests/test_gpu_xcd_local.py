@@ -215,3 +215,41 @@ def test_copies_run_concurrently_with_partial_residency():
     y3 = torch.empty_like(x1)
     p3.compute_forward(x1, y3).wait()
     assert torch.equal(y3, y1), "a copy of the plan computes the same bits"
+
+
+def test_a_launch_that_gives_up_fails_loudly():
+    """Every spin of the kernel is bounded; a launch that ran into a bound has computed garbage and must not pass for a
+    result.  PFFT_XCD_MAX_ITERS=3 ends every work-group after three tickets (the bound exists against a runaway loop):
+    the launch reports through a word of pinned host memory, and the wait on its event -- and every later execute and
+    wait of the process -- raises internal_error.  In a process of its own: the condition is sticky."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    child = r"""
+import sys
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import torch, gpu_utils as G, portfft_amd as pf
+n, batch = 1 << 18, 256
+plan = G.make_descriptor([n], "f32", batch=batch).commit()
+assert list(plan.info().launches) == [1, 1]
+x = torch.zeros(batch * n, dtype=torch.complex64, device="cuda")
+y = torch.empty_like(x)
+raised = 0
+try:
+    plan.compute_forward(x, y).wait()
+except pf.internal_error as e:
+    raised += 1
+    assert "XCD-local" in str(e), str(e)
+try:
+    plan.compute_forward(x, y)
+except pf.internal_error:
+    raised += 1
+print("raised", raised)
+""" % (root, os.path.join(root, "tests"))
+    env = dict(os.environ, PFFT_XCD_MAX_ITERS="3", PFFT_XCD_CHECK="0")
+    p = subprocess.run([sys.executable, "-c", child], env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0 and "raised 2" in p.stdout, p.stdout + p.stderr[-2000:]
+    # the same process without the bound: no failure, nothing raised
+    env.pop("PFFT_XCD_MAX_ITERS")
+    p = subprocess.run([sys.executable, "-c", child], env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0 and "raised 0" in p.stdout, p.stdout + p.stderr[-2000:]

@@ -83,6 +83,16 @@ using T = double;
 using CfgA = strided_cfg<double, radix_list<8, 8, 8>, 512, 8, 2, PFA_AUX_NT>;
 using CfgB = strided_cfg<double, radix_list<16, 8, 8>, 512, 8, 2, PFA_AUX_NT>;
 constexpr long long DEF_BATCH = 256;
+#elif TUNE_CASE == 121  // fp64 2^20 = 1024 x 1024 on 1024 lanes (16 waves per CU instead of 8): four passes
+using T = double;
+using CfgA = strided_cfg<double, radix_list<8, 8, 4, 4>, 1024, 8, 4, PFA_AUX_NT>;
+using CfgB = CfgA;
+constexpr long long DEF_BATCH = 128;
+#elif TUNE_CASE == 122  // the same, radices 4.4.8.8
+using T = double;
+using CfgA = strided_cfg<double, radix_list<4, 4, 8, 8>, 1024, 8, 4, PFA_AUX_NT>;
+using CfgB = CfgA;
+constexpr long long DEF_BATCH = 128;
 #elif TUNE_CASE == 117  // fp64 2^17 = 256 x 512
 using T = double;
 using CfgA = strided_cfg<double, radix_list<16, 16>, 128, 8, 2, PFA_AUX_NT>;
