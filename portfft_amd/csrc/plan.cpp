@@ -1770,7 +1770,8 @@ struct plan_t {
     // Measured over every divisor (tools/probes/split_sweep.py, fp32, fraction of the HBM peak, balanced -> best):
     // 30000 0.247 -> 0.287, 40000 0.263 -> 0.307, 62500 0.229 -> 0.266, 68640 0.221 -> 0.299, 10^5 0.176 -> 0.270,
     // 120000 0.158 -> 0.290, 250000 0.138 -> 0.256; a LONG stage A (400 ... 1000 points) in front of a SHORT stage B (60 ... 256)
-    // is at or within 10 % of the best of every one of them, n1 = 500 in front of n2 = 60 ... 240 at the very top of five.
+    // is at or within 10 % of the best of every one of them, n1 = 500 in front of n2 = 60 ... 240 at the very top of five:
+    // the n1 closest to 500 (from below rather than from above) with n2 in 60 ... 256.
     // fp64 has no such pattern (68640: 260 x 264 0.373, 156 x 440 0.382, 480 x 143 0.282; 10^5: 500 x 200 0.364, 250 x 400
     // 0.287): PFFT_PLAN_MEASURE=1 times the candidates instead (measured_split).
     if (!paired_split && desc.precision == PFFT_PRECISION_F32 && desc.complex_storage == PFFT_INTERLEAVED_COMPLEX &&
@@ -1782,7 +1783,8 @@ struct plan_t {
         if (n % c != 0) continue;
         const long long m = n / c;
         if (m < 60 || m > 256 || strided_fpw(c, m) <= 0 || strided_fpw(m, c) <= 0) continue;
-        const double d = std::fabs(std::log(static_cast<double>(c) / 500.0));
+        // (above 500 the distance counts three times: 68640 as 480 x 143 0.285, as 520 x 132 0.250)
+        const double d = std::fabs(std::log(static_cast<double>(c) / 500.0)) * (c > 500 ? 3.0 : 1.0);
         if (best == 0 || d < best_d) {
           best = c;
           best_d = d;
