@@ -322,7 +322,7 @@ int main() {
   const int wpc = getenv("TUNE_WG_PER_CU") ? atoi(getenv("TUNE_WG_PER_CU")) : 0;
   run(slots_log2, lag, look, wpc, true);
   if (getenv("TUNE_SWEEP")) {
-    const int pts[][2] = {{3, 2}, {4, 2}, {4, 3}, {5, 3}, {5, 4}, {6, 4}, {6, 5}, {8, 5}, {8, 7}, {12, 8}, {16, 8}, {24, 12}, {32, 16}, {32, 24}};
+    const int pts[][2] = {{3, 2}, {4, 2}, {4, 3}, {5, 3}, {5, 4}, {6, 4}, {6, 5}, {8, 5}, {8, 7}, {12, 8}, {16, 8}, {24, 12}, {32, 16}, {32, 24}, {48, 24}, {64, 32}};
     for (int w : {2, 3, 4}) for (auto& pt : pts) run(pt[0], pt[1], look, w, true);  // slots > lag
   }
   return 0;
