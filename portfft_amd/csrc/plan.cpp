@@ -575,6 +575,12 @@ struct plan_t {
         if (const spec_kernel* k = jit_spec_kernel(desc.precision, n, split, max_lds, &why, false, &choice)) return k;
       }
     }
+    if (jit_enabled() && getenv("PFFT_JIT_SPEC_RADICES") == nullptr) {  // the tuned table of this architecture
+      const std::vector<int> tuned = builtin_choice(jit_device_arch(), desc.precision, n, false);
+      if (!tuned.empty()) {
+        if (const spec_kernel* k = jit_spec_kernel(desc.precision, n, split, max_lds, &why, false, &tuned)) return k;
+      }
+    }
     const spec_kernel* k = jit_spec_kernel(desc.precision, n, split, max_lds, &why);
     if (k == nullptr) jit_note("packed", n, why);
     return k;
@@ -1803,6 +1809,14 @@ struct plan_t {
       if (best != 0) {
         n1 = best;
         n2 = n / best;
+      }
+    }
+    if (want_n1 == 0 && !paired_split && jit_enabled() && getenv("PFFT_DEBUG_GLOBAL") == nullptr &&
+        getenv("PFFT_NO_SPLIT_RULE") == nullptr) {  // the tuned table of this architecture
+      const std::vector<int> tuned = builtin_choice(jit_device_arch(), desc.precision, n, true);
+      if (tuned.size() == 2 && strided_fpw(tuned[0], tuned[1]) > 0 && strided_fpw(tuned[1], tuned[0]) > 0) {
+        n1 = tuned[0];
+        n2 = tuned[1];
       }
     }
     if (want_n1 == 0 && plan_measure_enabled() && jit_enabled() && in_buf == BUF_IN && out_buf == BUF_OUT &&

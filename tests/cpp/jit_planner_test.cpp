@@ -185,6 +185,34 @@ int main(int argc, char** argv) {
     pfa::plan_choice_store("gfx000", 0, 6000, {});  // forget it again: the cache directory may be a shared one
     EXPECT(pfa::plan_choice_lookup("gfx000", 0, 6000).empty(), "record forgotten");
   }
+  {  // the tuned table shipped with the library (tuned_gfx950.inc): every entry is a sequence the planner accepts
+    int entries = 0;
+    for (int prec = 0; prec < 2; ++prec) {
+      for (long long n = 2; n <= 1000000; n += (n < 21000 ? 1 : 4)) {
+        const std::vector<int> c = pfa::builtin_choice("gfx950", prec, n, false);
+        const std::vector<int> sp = pfa::builtin_choice("gfx950", prec, n, true);
+        if (!c.empty()) {
+          ++entries;
+          long long prod = 1;
+          for (int x : c) prod *= x;
+          pfa::wg_params q;
+          EXPECT(prod == n && pfa::choose_spec_params(prec, n, max_lds, &q, &c) && q.radices == c, "tuned radices of n=%lld prec=%d",
+                 n, prec);
+        }
+        if (!sp.empty()) {
+          ++entries;
+          EXPECT(sp.size() == 2 && static_cast<long long>(sp[0]) * sp[1] == n, "tuned split of n=%lld", n);
+        }
+        EXPECT(pfa::builtin_choice("gfx942", prec, n, false).empty() && pfa::builtin_choice("gfx942", prec, n, true).empty(),
+               "the table is for gfx950 only");
+      }
+    }
+    setenv("PFFT_NO_TUNED_TABLE", "1", 1);
+    EXPECT(pfa::builtin_choice("gfx950", 0, 6000, false).empty() && pfa::builtin_choice("gfx950", 0, 100000, true).empty(),
+           "PFFT_NO_TUNED_TABLE=1 turns the table off");
+    unsetenv("PFFT_NO_TUNED_TABLE");
+    std::printf("tuned table: %d entries checked\n", entries);
+  }
   {
     long long compiled = 0, from_disk = 0;
     pfa::jit_stats(&compiled, &from_disk);

@@ -551,12 +551,12 @@ def test_fused_multidimensional():
 
 def test_random_descriptors():
     """seeded random descriptors (rank, 31-smooth lengths, layouts, storages, placements, offsets, scales, precision,
-    direction) against NumPy -- the generator of tools/fuzz.py, 50 cases (the GPU suite's time budget; the 150-case and the
+    direction) against NumPy -- the generator of tools/fuzz.py, 40 cases (the GPU suite's time budget; the 150-case and the
     GLOBAL-tier runs are tools/fuzz.py's own, profiles/r4_notes.md)"""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    p = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz.py"), "11", "50"], capture_output=True,
+    p = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz.py"), "11", "40"], capture_output=True,
                        text=True, timeout=900)
     assert p.returncode == 0 and "0 failures" in p.stdout, p.stdout[-3000:] + p.stderr[-2000:]
 

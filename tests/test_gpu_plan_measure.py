@@ -98,3 +98,36 @@ def test_measured_four_step_split_is_recorded_and_honoured(tmp_path):
     # (the record is ignored and the split is measured again -- and recorded over it)
     redone, _ = _commit(n, d, measure=True, prec="f64")
     assert redone[0] * redone[1] == n
+
+
+def _tuned_entries():
+    import re
+    path = os.path.join(ROOT, "portfft_amd", "csrc", "tuned_gfx950.inc")
+    out = []
+    for ln in open(path):
+        m = re.match(r"\{PFFT_PRECISION_(F32|F64), (\d+), (\d), (\d+), \{([\d, ]+)\}\}", ln.strip())
+        if m:
+            out.append(("f32" if m.group(1) == "F32" else "f64", int(m.group(2)), m.group(3) == "1",
+                        [int(v) for v in m.group(5).split(",")]))
+    return out
+
+
+def test_the_tuned_table_is_used_by_default_and_can_be_turned_off(tmp_path):
+    """portfft_amd/csrc/tuned_gfx950.inc (tools/gen_tuned_table.py): measured choices shipped with the library.  A sample
+    of its entries: the default commit takes the entry's factors and computes the right answer; with
+    PFFT_NO_TUNED_TABLE=1 the static rule is back."""
+    entries = _tuned_entries()
+    if not entries:
+        pytest.skip("the table is empty")
+    packed = [e for e in entries if not e[2]]
+    splits = [e for e in entries if e[2]]
+    sample = packed[:2] + packed[-1:] + splits[:1] + splits[-1:]
+    for prec, n, is_split, factors in sample:
+        got, _ = _commit(n, tmp_path / "t", measure=False, prec=prec)
+        assert got[:len(factors)] == factors, (prec, n, got, factors)
+        os.environ["PFFT_NO_TUNED_TABLE"] = "1"
+        try:
+            static, _ = _commit(n, tmp_path / "t", measure=False, prec=prec)
+        finally:
+            del os.environ["PFFT_NO_TUNED_TABLE"]
+        assert static[:len(factors)] != factors, (prec, n, static)
