@@ -1811,8 +1811,8 @@ struct plan_t {
         n2 = n / best;
       }
     }
-    if (want_n1 == 0 && !paired_split && jit_enabled() && getenv("PFFT_DEBUG_GLOBAL") == nullptr &&
-        getenv("PFFT_NO_SPLIT_RULE") == nullptr) {  // the tuned table of this architecture
+    if (want_n1 == 0 && jit_enabled() && getenv("PFFT_DEBUG_GLOBAL") == nullptr &&
+        getenv("PFFT_NO_SPLIT_RULE") == nullptr) {  // the tuned table of this architecture (pairs included: it is measured)
       const std::vector<int> tuned = builtin_choice(jit_device_arch(), desc.precision, n, true);
       if (tuned.size() == 2 && strided_fpw(tuned[0], tuned[1]) > 0 && strided_fpw(tuned[1], tuned[0]) > 0) {
         n1 = tuned[0];
