@@ -20,6 +20,8 @@ for ln in open(os.path.join(ROOT, "portfft_amd", "csrc", "tuned_gfx950.inc")):
     if not m:
         continue
     prec, n = ("float" if m.group(1) == "F32" else "double"), int(m.group(2))
+    if os.environ.get("TUNED_AB_ONLY") and str(n) not in os.environ["TUNED_AB_ONLY"].split(","):
+        continue
     a, ka = run(prec, n, {})
     b, kb = run(prec, n, {"PFFT_NO_TUNED_TABLE": "1"})
     print("%s n=%d: table %.4f (%s)  static %.4f (%s)  %+.1f %%" % (prec, n, a, ka, b, kb, 100 * (a / b - 1) if b else 0), flush=True)
