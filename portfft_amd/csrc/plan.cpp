@@ -606,11 +606,9 @@ struct plan_t {
     const size_t per = static_cast<size_t>(n) * eb;
     const long long batch = std::max<long long>(1, std::min<long long>(count, static_cast<long long>((size_t{256} << 20) / per)));
     const size_t bytes = static_cast<size_t>(batch) * per;
-    void *in = nullptr, *out = nullptr;
-    if (hipMalloc(&in, bytes) != hipSuccess || hipMalloc(&out, bytes) != hipSuccess) {
-      if (in != nullptr) (void)hipFree(in);
-      return static_n1;  // no room to measure: the static rule
-    }
+    measure_scratch ms_;  // (freed on every way out, a throwing hip_check included)
+    if (!ms_.alloc(bytes)) return static_n1;  // no room to measure: the static rule
+    void *const in = ms_.in, *const out = ms_.out;
     fill_uniform(in, bytes);
     pfft_desc_t d = desc;
     d.number_of_transforms = static_cast<uint64_t>(batch);
@@ -619,9 +617,9 @@ struct plan_t {
     d.backward_offset = 0;
     const size_t half = bytes / 2;  // (split storage: the two planes inside the same allocations)
     const bool split = desc.complex_storage == PFFT_SPLIT_COMPLEX;
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    hip_check(hipEventCreate(&e0), "hipEventCreate");
-    hip_check(hipEventCreate(&e1), "hipEventCreate");
+    hip_check(hipEventCreate(&ms_.e0), "hipEventCreate");
+    hip_check(hipEventCreate(&ms_.e1), "hipEventCreate");
+    const hipEvent_t e0 = ms_.e0, e1 = ms_.e1;
     long long best = static_n1;
     double best_ms = 1e30;
     for (long long c : cands) {
@@ -649,13 +647,25 @@ struct plan_t {
         best = c;
       }
     }
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
-    (void)hipFree(in);
-    (void)hipFree(out);
     if (best_ms < 1e30) plan_choice_store(arch, desc.precision, n, {static_cast<int>(best), static_cast<int>(n / best)});
     return best;
   }
+
+  /// buffers and events of a measurement at commit
+  struct measure_scratch {
+    void *in = nullptr, *out = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    bool alloc(size_t bytes) { return hipMalloc(&in, bytes) == hipSuccess && hipMalloc(&out, bytes) == hipSuccess; }
+    measure_scratch() = default;
+    measure_scratch(const measure_scratch&) = delete;
+    measure_scratch& operator=(const measure_scratch&) = delete;
+    ~measure_scratch() {
+      if (e0 != nullptr) (void)hipEventDestroy(e0);
+      if (e1 != nullptr) (void)hipEventDestroy(e1);
+      if (in != nullptr) (void)hipFree(in);
+      if (out != nullptr) (void)hipFree(out);
+    }
+  };
 
   /// uniform(-1, 1) scalars: a 1 MiB host block replicated by doubling copies on the plan's stream
   void fill_uniform(void* dst, size_t bytes) {
@@ -697,15 +707,13 @@ struct plan_t {
     const size_t eb = elem_bytes();
     const long long batch = std::max<long long>(1, static_cast<long long>((size_t{256} << 20) / (static_cast<size_t>(n) * eb)));
     const size_t bytes = static_cast<size_t>(batch) * static_cast<size_t>(n) * eb;
-    void *in = nullptr, *out = nullptr;
-    if (hipMalloc(&in, bytes) != hipSuccess || hipMalloc(&out, bytes) != hipSuccess) {
-      if (in != nullptr) (void)hipFree(in);
-      return choice;  // no room to measure: the static rule
-    }
+    measure_scratch ms_;
+    if (!ms_.alloc(bytes)) return choice;  // no room to measure: the static rule
+    void *const in = ms_.in, *const out = ms_.out;
     fill_uniform(in, bytes);
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    hip_check(hipEventCreate(&e0), "hipEventCreate");
-    hip_check(hipEventCreate(&e1), "hipEventCreate");
+    hip_check(hipEventCreate(&ms_.e0), "hipEventCreate");
+    hip_check(hipEventCreate(&ms_.e1), "hipEventCreate");
+    const hipEvent_t e0 = ms_.e0, e1 = ms_.e1;
     double best_ms = 1e30;
     for (const std::vector<int>& r : cands) {
       std::string why;
@@ -746,10 +754,6 @@ struct plan_t {
         choice = r;
       }
     }
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
-    (void)hipFree(in);
-    (void)hipFree(out);
     if (!choice.empty()) plan_choice_store(arch, desc.precision, n, choice);
     return choice;
   }
