@@ -698,8 +698,37 @@ struct plan_t {
     const std::string arch = jit_device_arch();
     std::vector<int> choice = plan_choice_lookup(arch, desc.precision, n);
     if (!choice.empty()) return choice;
-    const std::vector<std::vector<int>> cands = spec_radix_candidates(desc.precision, n, max_lds);
+    std::vector<std::vector<int>> cands = spec_radix_candidates(desc.precision, n, max_lds);
     if (cands.empty()) return choice;
+    // A prime factor P of 17 ... 61 makes the lanes per transform a candidate too (a sequence ends in "0, lanes"): the
+    // prime's pass has n / P butterflies, and whether a transform should take that many lanes, twice or half as many,
+    // with the prime first or last, is not something a rule gets right below 37 (tools/probes/prime_rule2.sh: 31 x 32
+    // 0.53 -> 0.67 but 31 x 31 in fp64 0.53 -> 0.36 with the rule of the primes above)
+    {
+      int big = 0;
+      for (int r : cands[0]) big = std::max(big, r);
+      bool prime = big >= 17;
+      for (int q = 2; q * q <= big; ++q) prime = prime && big % q != 0;
+      const long long nb = n / std::max(big, 1);
+      if (prime && nb >= 8 && nb <= 128) {
+        int t0 = 16;
+        while (t0 < nb && t0 < 128) t0 *= 2;
+        std::vector<std::vector<int>> seqs(cands.begin(), cands.begin() + std::min<size_t>(cands.size(), 3));
+        if (nb <= 32) {
+          seqs.push_back({static_cast<int>(nb), big});
+          seqs.push_back({big, static_cast<int>(nb)});
+        }
+        for (const std::vector<int>& q : seqs) {
+          for (int t : {t0 / 2, t0, 2 * t0}) {
+            if (t < 16 || t > 256) continue;
+            std::vector<int> v = q;
+            v.push_back(0);
+            v.push_back(t);
+            cands.push_back(v);
+          }
+        }
+      }
+    }
     if (cands.size() == 1) {
       plan_choice_store(arch, desc.precision, n, cands[0]);
       return cands[0];
@@ -719,14 +748,15 @@ struct plan_t {
       std::string why;
       const spec_kernel* k = jit_spec_kernel(desc.precision, n, false, max_lds, &why, false, &r);
       if (k == nullptr) continue;
+      const std::vector<int> radices_only(k->radices, k->radices + k->n_radices);
       void* tw = nullptr;
       {
         std::vector<char> host;
         if (desc.precision == PFFT_PRECISION_F64) {
-          const auto t = host_twiddles<double>(r);
+          const auto t = host_twiddles<double>(radices_only);
           host.assign(reinterpret_cast<const char*>(t.data()), reinterpret_cast<const char*>(t.data() + t.size()));
         } else {
-          const auto t = host_twiddles<float>(r);
+          const auto t = host_twiddles<float>(radices_only);
           host.assign(reinterpret_cast<const char*>(t.data()), reinterpret_cast<const char*>(t.data() + t.size()));
         }
         if (hipMalloc(&tw, host.size()) != hipSuccess) continue;

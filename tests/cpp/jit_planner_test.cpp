@@ -182,6 +182,16 @@ int main(int argc, char** argv) {
     EXPECT(pfa::choose_spec_params(0, 6000, max_lds, &q, &pick) && q.radices == pick, "forced radices honoured");
     const std::vector<int> bad = {24, 25, 11};
     EXPECT(pfa::choose_spec_params(0, 6000, max_lds, &q, &bad) && q.radices != bad, "a sequence of another length is ignored");
+    {  // lanes per transform behind the radices: "0, lanes"
+      const std::vector<int> with_lanes = {16, 61, 0, 16};
+      pfa::wg_params w;
+      EXPECT(pfa::choose_spec_params(0, 976, max_lds, &w, &with_lanes) && w.radices == std::vector<int>({16, 61}) &&
+                 w.wg == 16 * w.fpw,
+             "forced lanes honoured: wg %d fpw %d", w.wg, w.fpw);
+      pfa::plan_choice_store("gfx000", 0, 976, with_lanes);
+      EXPECT(pfa::plan_choice_lookup("gfx000", 0, 976) == with_lanes, "a record with lanes is read back");
+      pfa::plan_choice_store("gfx000", 0, 976, {});
+    }
     pfa::plan_choice_store("gfx000", 0, 6000, {});  // forget it again: the cache directory may be a shared one
     EXPECT(pfa::plan_choice_lookup("gfx000", 0, 6000).empty(), "record forgotten");
   }
@@ -193,11 +203,18 @@ int main(int argc, char** argv) {
         const std::vector<int> sp = pfa::builtin_choice("gfx950", prec, n, true);
         if (!c.empty()) {
           ++entries;
+          std::vector<int> rad = c;  // (an entry may end in "0, lanes")
+          int lanes = 0;
+          if (rad.size() >= 3 && rad[rad.size() - 2] == 0) {
+            lanes = rad.back();
+            rad.resize(rad.size() - 2);
+          }
           long long prod = 1;
-          for (int x : c) prod *= x;
+          for (int x : rad) prod *= x;
           pfa::wg_params q;
-          EXPECT(prod == n && pfa::choose_spec_params(prec, n, max_lds, &q, &c) && q.radices == c, "tuned radices of n=%lld prec=%d",
-                 n, prec);
+          EXPECT(prod == n && pfa::choose_spec_params(prec, n, max_lds, &q, &c) && q.radices == rad &&
+                     (lanes == 0 || q.wg == lanes * q.fpw),
+                 "tuned radices of n=%lld prec=%d", n, prec);
         }
         if (!sp.empty()) {
           ++entries;

@@ -123,8 +123,13 @@ def test_the_tuned_table_is_used_by_default_and_can_be_turned_off(tmp_path):
     splits = [e for e in entries if e[2]]
     sample = packed[:2] + packed[-1:] + splits[:1] + splits[-1:]
     for prec, n, is_split, factors in sample:
+        with_lanes = len(factors) >= 3 and factors[-2] == 0  # (a packed entry may end in "0, lanes")
+        if with_lanes:
+            factors = factors[:-2]
         got, _ = _commit(n, tmp_path / "t", measure=False, prec=prec)
         assert got[:len(factors)] == factors, (prec, n, got, factors)
+        if with_lanes:
+            continue  # (the static rule may take the same radices on other lanes)
         os.environ["PFFT_NO_TUNED_TABLE"] = "1"
         try:
             static, _ = _commit(n, tmp_path / "t", measure=False, prec=prec)
