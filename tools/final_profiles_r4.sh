@@ -44,7 +44,7 @@ sum g32_18 stockham_xcd_fourstep 2147483648 1 "fp32 N=2^18 x 512: XCD-local sing
 sum g32_20 stockham_strided 2147483648 4 "fp32 N=2^20 x 128: four-step, 4 chunks of 256 MiB"
 sum g32_21 stockham_strided 2147483648 4 "fp32 N=2^21 x 64: four-step (1024 x 2048), 4 chunks of 256 MiB"
 sum g32_22 stockham_strided 2147483648 4 "fp32 N=2^22 x 32: four-step, 4 chunks of 256 MiB"
-sum g32_24 stockham_strided 2147483648 3 "fp32 N=2^24 x 8: three stages (256 x 256 x 256), 3 chunks"
+sum g32_24 stockham_strided 2147483648 1 "fp32 N=2^24 x 8: three stages (256 x 256 x 256): 4 + 4 chunked launches of stages 1-2, one launch of stage 3"
 sum ref9800 stockham_wg 2147483648 1 "fp32 N=9800 x 13312: one launch (tuned table: 7.8.7.5.5)"
 sum ref15360 stockham_wg 2147483648 1 "fp32 N=15360 x 8704: one launch (tuned table: 24.32.20)"
 sum ref68640 stockham_strided 2147483648 4 "fp32 N=68640 x 1920: four-step (104 x 660, tuned table), 4 chunks of 256 MiB"

@@ -47,7 +47,7 @@ def main():
     ap.add_argument("--cal-kernel", default="rows_copy")
     ap.add_argument("--cal-kib", type=float, default=2 * 1024 * 1024, help="KiB the calibration kernel reads (= writes)")
     ap.add_argument("--launches-per-execute", type=int, default=1,
-                    help="launches of EACH matching kernel per execute (plans that run chunk by chunk)")
+                    help="launches per execute of the LEAST-launched matching kernel (plans that run chunk by chunk)")
     a = ap.parse_args()
     subs = [s for s in a.kernels.split(",") if s]
     out = {"config": a.config, "label": a.label,
@@ -72,15 +72,21 @@ def main():
     write = per_kernel(a.src + "/WRITE_SIZE", "WRITE_SIZE")
     kernels = []
     read_b = write_b = 0.0
+    matching = [n for n in set(fetch) & set(write) if any(sub in n for sub in subs) and fetch[n] and write[n]]
+    least = min((len(fetch[n]) for n in matching), default=0)
     for name in sorted(set(fetch) | set(write)):
         if not any(s in name for s in subs):
             continue
         f, w = fetch.get(name, []), write.get(name, [])
         if not f or not w:
             continue
-        rb = sum(f) / len(f) * 1024 * fetch_corr * a.launches_per_execute
-        wb = sum(w) / len(w) * 1024 * write_corr * a.launches_per_execute
+        # kernels of one plan may run a different number of chunks (three-stage plan: 4 + 4 + 1 launches): a kernel
+        # sampled k times as often as the least-sampled one runs k times as many launches per execute
+        ratio = len(f) / float(least) if least else 1.0
+        rb = sum(f) / len(f) * 1024 * fetch_corr * a.launches_per_execute * ratio
+        wb = sum(w) / len(w) * 1024 * write_corr * a.launches_per_execute * ratio
         kernels.append({"kernel": short(name), "launches_sampled": [len(f), len(w)],
+                        "launches_per_execute": a.launches_per_execute * ratio,
                         "FETCH_SIZE_mean_KiB": sum(f) / len(f), "WRITE_SIZE_mean_KiB": sum(w) / len(w),
                         "hbm_read_bytes_per_execute": rb, "hbm_write_bytes_per_execute": wb})
         read_b += rb
