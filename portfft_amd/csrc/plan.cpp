@@ -284,6 +284,7 @@ struct plan_t {
     // (tests/cpp/multi_device_test.cpp with MDT_THREADS=8: counters back at zero, hand-off waits that never end).
     hip_check(hipMemsetAsync(xcd_ctl, 0, xcd_ctl_bytes, stream), "hipMemsetAsync(control block)");
     hip_check(hipStreamSynchronize(stream), "hipStreamSynchronize");
+    (void)xcd_failure_word();  // (allocated here, not at the first launch: that one may be inside a stream capture)
   }
 
   void* upload(const void* host, size_t bytes) {
