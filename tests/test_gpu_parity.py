@@ -551,8 +551,8 @@ def test_fused_multidimensional():
 
 def test_random_descriptors():
     """seeded random descriptors (rank, 31-smooth lengths, layouts, storages, placements, offsets, scales, precision,
-    direction) against NumPy -- the generator of tools/fuzz.py, 25 cases (the GPU suite's time budget; the 150-case and the
-    GLOBAL-tier runs are tools/fuzz.py's own, profiles/r4_notes.md)"""
+    direction) against NumPy -- the generator of tools/fuzz.py, 25 cases (the GPU suite's time budget; the 200-case run and the
+    GLOBAL-tier runs are tools/fuzz.py's own: profiles/r4_fuzz_*.txt)"""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
