@@ -100,6 +100,10 @@ typedef struct pfft_plan_info_t {
   pfft_dim_info_t dims[PFFT_MAX_RANK];
   int32_t launches[2]; /* kernel launches of one execute [forward, backward]; plans that run chunk by chunk
                           (intermediate sized to the Infinity Cache) count every chunk's launches */
+  int32_t xcd_local[2]; /* 1: that direction runs the GLOBAL tier as ONE persistent launch (per-XCD task queues) followed
+                           by its recovery launch, which does nothing unless a hand-off wait of the former gave up */
+  uint64_t xcd_recoveries; /* executes of this plan (copy) whose persistent launch gave up and were recomputed, in stream
+                              order, by the recovery launch: the result was valid whenever the execute's event completed */
 } pfft_plan_info_t;
 
 typedef struct pfft_plan_t pfft_plan_t; /* opaque: portfft::committed_descriptor */

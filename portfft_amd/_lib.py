@@ -56,6 +56,8 @@ class pfft_plan_info_t(C.Structure):
         ("scratch_bytes", C.c_uint64),
         ("dims", pfft_dim_info_t * MAX_RANK),
         ("launches", C.c_int32 * 2),
+        ("xcd_local", C.c_int32 * 2),
+        ("xcd_recoveries", C.c_uint64),
     ]
 
 

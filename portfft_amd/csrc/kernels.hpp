@@ -46,6 +46,9 @@ struct spec_kernel {
   /// 1: cross-lane variant of the length (stockham_xlane.hpp); only chosen when PFFT_XLANE is set (measurement:
   /// profiles/r2_notes.md)
   int xlane;
+  /// 1: register-resident form (stockham_wg_hx.hpp): the transform does not fit LDS, lds_bytes is its half image; the
+  /// wg_cfg fields above do not describe a configuration the other packed forms (UNPACKED layouts) could be built from
+  int hx;
 };
 
 /// One strided work-group kernel (stockham_strided.hpp): FPW FFTs side by side, any element stride / FFT distance.
@@ -151,6 +154,9 @@ struct xcd_kernel {
   int radices_a[8], radices_b[8];
   const void* fn[2];  // [backward]
   hipError_t (*launch)(hipStream_t stream, unsigned grid, size_t lds, const xcd_args& args, int backward);
+  /// the recovery launch that follows every launch (stockham_xcd_recover_kernel; phase: XCD_RECOVER_*, xcd_args.hpp)
+  const void* fn_recover[2];
+  hipError_t (*launch_recover)(hipStream_t stream, unsigned grid, size_t lds, const xcd_args& args, int backward, int phase);
   int slots, lag, lookahead;  // tuned schedule (xcd_args)
   int wg_per_cu;              // work-groups per CU the launch is padded to (0: as many as fit)
   int min_mib;                // MiB of data per execute from which the launch beats the two-launch plan

@@ -11,6 +11,7 @@
 #include "stockham_rows2d.hpp"
 #include "stockham_strided.hpp"
 #include "stockham_wg.hpp"
+#include "stockham_wg_hx.hpp"
 #include "stockham_xlane.hpp"
 
 #include <tuple>
@@ -190,6 +191,54 @@ spec_kernel make_spec_entry_xlane(int groups_per_wg = 1) {
   k.fn[1] = reinterpret_cast<const void*>(&stockham_wg_xlane_kernel<Cfg, true>);
   k.launch = &launch_spec_xlane<Cfg>;
   k.xlane = 1;
+  return k;
+}
+
+template <typename Cfg>
+hipError_t launch_spec_hx(hipStream_t stream, unsigned grid, const void* in, void* out, const void* tw, long long nfft,
+                          double scale, int backward) {
+  using T = typename Cfg::T;
+  const auto* i = static_cast<const cx<T>*>(in);
+  auto* o = static_cast<cx<T>*>(out);
+  const auto* t = static_cast<const cx<T>*>(tw);
+  constexpr size_t lds = wg_hx_lds_bytes<Cfg>();
+  if (backward) {
+    hipLaunchKernelGGL((stockham_wg_hx_kernel<Cfg, true>), dim3(grid), dim3(Cfg::WG), lds, stream, i, o, t, nfft, static_cast<T>(scale));
+  } else {
+    hipLaunchKernelGGL((stockham_wg_hx_kernel<Cfg, false>), dim3(grid), dim3(Cfg::WG), lds, stream, i, o, t, nfft, static_cast<T>(scale));
+  }
+  return hipGetLastError();
+}
+
+template <typename Cfg>
+hipError_t launch_spec_hx_split(hipStream_t stream, unsigned grid, const void* in_re, const void* in_im, void* out_re,
+                                void* out_im, const void* tw, long long nfft, double scale, int backward) {
+  using T = typename Cfg::T;
+  const auto* t = static_cast<const cx<T>*>(tw);
+  const dim3 g(grid), b(Cfg::WG);
+  constexpr size_t lds = wg_hx_lds_bytes<Cfg>();
+  if (backward) {
+    hipLaunchKernelGGL((stockham_wg_hx_split_kernel<Cfg, true>), g, b, lds, stream, static_cast<const T*>(in_re),
+                       static_cast<const T*>(in_im), static_cast<T*>(out_re), static_cast<T*>(out_im), t, nfft, static_cast<T>(scale));
+  } else {
+    hipLaunchKernelGGL((stockham_wg_hx_split_kernel<Cfg, false>), g, b, lds, stream, static_cast<const T*>(in_re),
+                       static_cast<const T*>(in_im), static_cast<T*>(out_re), static_cast<T*>(out_im), t, nfft, static_cast<T>(scale));
+  }
+  return hipGetLastError();
+}
+
+/// register-resident form (stockham_wg_hx.hpp) of a packed length beyond the CU's LDS
+template <typename Cfg>
+spec_kernel make_spec_entry_hx(int groups_per_wg = 0) {
+  spec_kernel k = make_spec_entry<Cfg>(groups_per_wg);
+  k.lds_bytes = wg_hx_lds_bytes<Cfg>();
+  k.fn[0] = reinterpret_cast<const void*>(&stockham_wg_hx_kernel<Cfg, false>);
+  k.fn[1] = reinterpret_cast<const void*>(&stockham_wg_hx_kernel<Cfg, true>);
+  k.launch = &launch_spec_hx<Cfg>;
+  k.fn_split[0] = reinterpret_cast<const void*>(&stockham_wg_hx_split_kernel<Cfg, false>);
+  k.fn_split[1] = reinterpret_cast<const void*>(&stockham_wg_hx_split_kernel<Cfg, true>);
+  k.launch_split = &launch_spec_hx_split<Cfg>;
+  k.hx = 1;
   return k;
 }
 

@@ -30,6 +30,17 @@ hipError_t launch_xcd(hipStream_t stream, unsigned grid, size_t lds, const xcd_a
   return hipGetLastError();
 }
 
+/// the recovery launch behind it (stockham_xcd_recover_kernel; `phase`: xcd_args.hpp)
+template <typename CfgA, typename CfgB, int OCCX, int WG>
+hipError_t launch_xcd_recover(hipStream_t stream, unsigned grid, size_t lds, const xcd_args& args, int backward, int phase) {
+  if (backward) {
+    hipLaunchKernelGGL((stockham_xcd_recover_kernel<CfgA, CfgB, true, 1, 1, OCCX, WG>), dim3(grid), dim3(WG), lds, stream, args, phase);
+  } else {
+    hipLaunchKernelGGL((stockham_xcd_recover_kernel<CfgA, CfgB, false, 1, 1, OCCX, WG>), dim3(grid), dim3(WG), lds, stream, args, phase);
+  }
+  return hipGetLastError();
+}
+
 /// CfgA x CfgB on work-groups of WG lanes; OCCX: waves per SIMD the register budget leaves room for (work-groups per
 /// CU x waves per work-group / 4)
 template <typename CfgA, typename CfgB, int OCCX, int WG = (CfgA::WG > CfgB::WG ? CfgA::WG : CfgB::WG)>
@@ -54,6 +65,9 @@ xcd_kernel make_xcd_entry(int slots, int lag, int lookahead, int min_mib = 512, 
   k.fn[0] = reinterpret_cast<const void*>(&stockham_xcd_fourstep_kernel<CfgA, CfgB, false, 1, 1, 0, OCCX, WG>);
   k.fn[1] = reinterpret_cast<const void*>(&stockham_xcd_fourstep_kernel<CfgA, CfgB, true, 1, 1, 0, OCCX, WG>);
   k.launch = &launch_xcd<CfgA, CfgB, OCCX, WG>;
+  k.fn_recover[0] = reinterpret_cast<const void*>(&stockham_xcd_recover_kernel<CfgA, CfgB, false, 1, 1, OCCX, WG>);
+  k.fn_recover[1] = reinterpret_cast<const void*>(&stockham_xcd_recover_kernel<CfgA, CfgB, true, 1, 1, OCCX, WG>);
+  k.launch_recover = &launch_xcd_recover<CfgA, CfgB, OCCX, WG>;
   k.slots = slots;
   k.lag = lag;
   k.lookahead = lookahead;

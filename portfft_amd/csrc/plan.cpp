@@ -64,6 +64,7 @@ struct stage {
   rows2d_args ra{};
   const xcd_kernel* xcd = nullptr;  // XCD-local four-step launch (stockham_xcd.hpp): both stages of N = n1 x n2
   xcd_args xa{};
+  unsigned recover_grid = 0;  // work-groups of the recovery launch behind it (stockham_xcd_recover_kernel)
   // two-pass 2-D plan: pass 1 permutes rows between distinct buffers (IN -> OUT), pass 2 works in place on OUT.
   // When the caller's buffers alias (in-place transform) the intermediate goes through scratch instead:
   // 1: this stage writes it (out_buf -> scratch), 2: this stage reads it (in_buf -> scratch)
@@ -232,6 +233,11 @@ struct plan_t {
   size_t twiddle_bytes = 0;
   void* xcd_ctl = nullptr;        // control block of the XCD-local four-step launch (xcd_args.hpp): one per copy
   size_t xcd_ctl_bytes = 0;
+  void* xcd_tmap = nullptr;       // ... its per-transform records (xcd_args::tmap), one per copy
+  size_t xcd_tmap_bytes = 0;
+  unsigned* xcd_report = nullptr;  // ... and the copy's host report (pinned; XCD_REPORT_WORDS words, xcd_args.hpp)
+  unsigned xcd_recoveries_seen = 0;  // PFFT_XCD_CHECK=1: report[0] at the last check
+  const bool xcd_check = xcd_check_enabled();  // fixed at commit
   void* alias_scratch = nullptr;  // intermediate of the two-pass 2-D plan for aliasing (in-place) executes
   size_t alias_scratch_bytes = 0;
   size_t two_pass_chunk_bytes = 0;  // bytes of one chunk of the two-pass 2-D plan (what an aliasing execute needs)
@@ -272,6 +278,8 @@ struct plan_t {
     if (scratch != nullptr) (void)hipFree(scratch);
     if (alias_scratch != nullptr) (void)hipFree(alias_scratch);
     if (xcd_ctl != nullptr) (void)hipFree(xcd_ctl);
+    if (xcd_tmap != nullptr) (void)hipFree(xcd_tmap);
+    if (xcd_report != nullptr) (void)hipHostFree(xcd_report);
   }
 
   /// the control block of the XCD-local launch: all zero before its first launch (the kernel keeps it that way)
@@ -283,8 +291,15 @@ struct plan_t {
     // hardware queues the fill was seen to land in the middle of the plan's first launch
     // (tests/cpp/multi_device_test.cpp with MDT_THREADS=8: counters back at zero, hand-off waits that never end).
     hip_check(hipMemsetAsync(xcd_ctl, 0, xcd_ctl_bytes, stream), "hipMemsetAsync(control block)");
+    hip_check(hipMalloc(&xcd_tmap, xcd_tmap_bytes), "hipMalloc(transform records)");
+    hip_check(hipMemsetAsync(xcd_tmap, 0, xcd_tmap_bytes, stream), "hipMemsetAsync(transform records)");
     hip_check(hipStreamSynchronize(stream), "hipStreamSynchronize");
-    (void)xcd_failure_word();  // (allocated here, not at the first launch: that one may be inside a stream capture)
+    // the copy's host report: what the recovery launch behind a launch that gave up tells the host (pfft_plan_get_info)
+    void* r = nullptr;
+    hip_check(hipHostMalloc(&r, XCD_REPORT_WORDS * sizeof(unsigned), hipHostMallocPortable | hipHostMallocMapped),
+              "hipHostMalloc(report)");
+    std::memset(r, 0, XCD_REPORT_WORDS * sizeof(unsigned));
+    xcd_report = static_cast<unsigned*>(r);
   }
 
   void* upload(const void* host, size_t bytes) {
@@ -471,8 +486,9 @@ struct plan_t {
     // PFFT_XLANE: prefer the cross-lane variant of a length (measurement / parity of stockham_xlane.hpp)
     const bool want_xlane = getenv("PFFT_XLANE") != nullptr && desc.complex_storage == PFFT_INTERLEAVED_COMPLEX;
     const spec_kernel* found = nullptr;
+    const bool no_regres = getenv("PFFT_NO_REGRES") != nullptr;  // A/B twin of the register-resident entries
     for (int i = 0; i < count; ++i) {
-      if (k[i].n != n || k[i].lds_bytes > max_lds) continue;
+      if (k[i].n != n || k[i].lds_bytes > max_lds || (k[i].hx != 0 && no_regres)) continue;
       if (k[i].xlane != 0) {
         if (want_xlane) return &k[i];
         continue;
@@ -1493,7 +1509,7 @@ struct plan_t {
     for (int i = 0; i < nk; ++i) {
       if (ks[i].precision == desc.precision && static_cast<long long>(ks[i].n1) * ks[i].n2 == n) k = &ks[i];
     }
-    if (k == nullptr || static_cast<unsigned long long>(n) * elem_bytes() >= 0xFFFFFFF0ull || count >= (1ll << 31)) {
+    if (k == nullptr || static_cast<unsigned long long>(n) * elem_bytes() >= 0xFFFFFFF0ull || count >= (1ll << 27)) {
       return false;
     }
     const int n_queues = xcd_queue_count();
@@ -1602,6 +1618,10 @@ struct plan_t {
     if (ring > global_chunk_bytes()) return false;
     scratch_bytes = std::max(scratch_bytes, ring);
     xcd_ctl_bytes = std::max(xcd_ctl_bytes, static_cast<size_t>(xcd_ctl_words(n_queues, slots, map_log2)) * sizeof(unsigned));
+    xcd_tmap_bytes = std::max(xcd_tmap_bytes, static_cast<size_t>(count) * 8);
+    // the recovery launch behind it: one work-group per ring slot at most (its private intermediate when it recomputes)
+    s.recover_grid = static_cast<unsigned>(std::min<long long>(static_cast<long long>(n_queues) * slots, 2ll * n_cus));
+    this->info.xcd_local[backward] = 1;
     out.push_back(s);
     if (info != nullptr) {
       info->tier = PFFT_TIER_GLOBAL;
@@ -1651,6 +1671,7 @@ struct plan_t {
       if (!packed_io && inner_count == count && row_like(ia) && row_like(oa) && (interleaved || user_bufs) &&
           !(ia.stride == 1 && ia.dist_inner == n && oa.stride == 1 && oa.dist_inner == n)) {
         const spec_kernel* k = find_spec(n);
+        if (k != nullptr && k->hx != 0) k = nullptr;  // (no UNPACKED form of the register-resident entries)
         if (k == nullptr) {
           std::string why;
           k = jit_spec_kernel(desc.precision, n, !interleaved, max_lds, &why, true);
@@ -2291,6 +2312,7 @@ struct plan_t {
         const long long batches = st.chunk_group < 0 ? 1 : st.count / std::max<long long>(1, st.ffts_per_batch);
         const long long per = std::max<long long>(1, st.chunk_batches);
         n += st.chunk_group < 0 ? 1 : (batches + per - 1) / per;
+        if (st.xcd != nullptr) ++n;  // its recovery launch (two when the execute's buffers alias)
       }
       info.launches[d] = static_cast<int32_t>(std::min<long long>(n, 0x7fffffff));
     }
@@ -2307,6 +2329,7 @@ struct plan_t {
     stages[0] = o.stages[0];
     stages[1] = o.stages[1];
     xcd_ctl_bytes = o.xcd_ctl_bytes;
+    xcd_tmap_bytes = o.xcd_tmap_bytes;
     device_guard dg(device);
     if (scratch_bytes > 0) hip_check(hipMalloc(&scratch, scratch_bytes), "hipMalloc(scratch)");
     alloc_xcd_ctl();
@@ -2368,11 +2391,23 @@ struct plan_t {
       x.b.in = scratch;
       x.b.out = static_cast<char*>(out_re) + static_cast<size_t>(s.out_addr.offset) * elem_bytes();
       x.ctl = static_cast<unsigned*>(xcd_ctl);
-      x.keep_on_timeout = getenv("PFFT_XCD_DUMP") != nullptr ? 1 : 0;
-      x.host_failures = xcd_failure_word();
-      xcd_ever_launched().store(true, std::memory_order_relaxed);
+      x.tmap = static_cast<unsigned*>(xcd_tmap);
+      x.report = xcd_report;
+      // The persistent launch, then its recovery launch: every work-group of the latter reads one word and leaves unless a
+      // hand-off wait of the former gave up, in which case it recomputes what is missing IN STREAM ORDER -- the
+      // submission's event (the stop event of the last launch) and everything queued behind the execute see valid data.
+      // Aliasing buffers: stage B from the slot rings first (the input of those transforms is already overwritten).
+      const hipEvent_t stop = take_stop_event();
       hip_check(s.xcd->launch(stream, s.grid, s.lds_bytes, x, s.backward), "kernel launch");
-      if (xcd_check_enabled()) check_xcd_timeouts();
+      const bool aliasing = in_re == out_re;
+      if (aliasing) {
+        hip_check(s.xcd->launch_recover(stream, s.recover_grid, s.lds_bytes, x, s.backward, XCD_RECOVER_STAGE_B), "kernel launch");
+      }
+      if (stop != nullptr) arm_stop_event(stop);
+      hip_check(s.xcd->launch_recover(stream, s.recover_grid, s.lds_bytes, x, s.backward,
+                                      aliasing ? XCD_RECOVER_REST : XCD_RECOVER_ALL),
+                "kernel launch");
+      if (xcd_check) check_xcd_recoveries();
       return;
     }
     if (s.rows2d != nullptr) {
@@ -2596,7 +2631,6 @@ struct plan_t {
       fail(PFFT_INVALID_CONFIGURATION, "Invalid direction ", direction);
     }
     if (in_re == nullptr || out_re == nullptr) fail(PFFT_INVALID_CONFIGURATION, "null data pointer");
-    if (xcd_ctl != nullptr) check_xcd_failures();
     device_guard dg(device);  // launches go to the device the plan was committed on, whatever is current
     const std::vector<stage>& st = stages[direction];
     bool rode = false;
@@ -2641,64 +2675,23 @@ struct plan_t {
     return rode;
   }
 
-  /// XCD-local launches never fail silently: every spin of the kernel is bounded, a launch in which one gave up (or whose
-  /// iteration bound ended a work-group early) has computed garbage, and its last work-group out adds 1 to this word of
-  /// pinned host memory (one per process, visible to every device).  The library reads it -- a host load -- at every
-  /// execute, plan / queue / event wait, and raises `internal_error` from then on.
-  static unsigned* xcd_failure_word() {
-    static unsigned* const w = [] {
-      void* p = nullptr;
-      if (hipHostMalloc(&p, 64, hipHostMallocPortable | hipHostMallocMapped) != hipSuccess) return static_cast<unsigned*>(nullptr);
-      std::memset(p, 0, 64);
-      return static_cast<unsigned*>(p);
-    }();
-    return w;
-  }
-  static void check_xcd_failures() {
-    const unsigned* w = xcd_failure_word();
-    if (w != nullptr && __atomic_load_n(w, __ATOMIC_RELAXED) != 0u) {
-      fail(PFFT_INTERNAL_ERROR, "an XCD-local four-step launch of this process gave up on a hand-off wait: the output of that ",
-           "execute is invalid (PFFT_XCD_CHECK=1 PFFT_XCD_DUMP=1 names the launch; PFFT_NO_XCD_LOCAL=1 avoids the plan)");
-    }
-  }
-  /// (event / queue waits: only once a plan of this process has launched such a kernel)
-  static std::atomic<bool>& xcd_ever_launched() {
-    static std::atomic<bool> f{false};
-    return f;
-  }
-  static void check_xcd_failures_if_any() {
-    if (xcd_ever_launched().load(std::memory_order_relaxed)) check_xcd_failures();
-  }
-  /// PFFT_XCD_CHECK=1 (tests): wait for every XCD-local launch and fail when one of its bounded hand-off waits gave up
+  /// PFFT_XCD_CHECK=1 (tests, fixed at commit): wait for every XCD-local execute and raise when it needed its recovery
+  /// launch -- a hand-off wait gave up.  Without the knob such an execute is simply recomputed in stream order and counted
+  /// (pfft_plan_info_t::xcd_recoveries); the tests want to know that it does not happen on a healthy device.
   static bool xcd_check_enabled() {
     const char* e = getenv("PFFT_XCD_CHECK");
     return e != nullptr && std::atoi(e) != 0;
   }
-  void check_xcd_timeouts() {
+  void check_xcd_recoveries() {
+    hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(stream, &capturing) != hipSuccess || capturing != hipStreamCaptureStatusNone) return;
     hip_check(hipStreamSynchronize(stream), "hipStreamSynchronize");
-    unsigned h[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    hip_check(hipMemcpy(h, static_cast<unsigned*>(xcd_ctl) + XCD_W_TIMEOUT, sizeof h, hipMemcpyDeviceToHost), "hipMemcpy");
-    if (h[0] != 0) {
-      if (getenv("PFFT_XCD_DUMP") != nullptr) {  // the control block as the failed launch left it
-        std::vector<unsigned> w(xcd_ctl_bytes / sizeof(unsigned));
-        hip_check(hipMemcpy(w.data(), xcd_ctl, xcd_ctl_bytes, hipMemcpyDeviceToHost), "hipMemcpy");
-        std::fprintf(stderr, "xcd ctl %p: next %u exit %u epoch %u polls %u\n", xcd_ctl, w[XCD_W_NEXT], w[XCD_W_EXIT], w[XCD_W_EPOCH], h[5]);
-        for (const stage& st : stages[0]) {
-          if (st.xcd == nullptr) continue;
-          const unsigned qw = xcd_queue_words(st.xa.slots, st.xa.map_log2);
-          for (int q = 0; q < st.xa.n_queues; ++q) {
-            const unsigned* qb = w.data() + XCD_W_QUEUES + q * qw;
-            std::fprintf(stderr, " queue %d: ticket %u | done_a/done_b per slot:", q, qb[0]);
-            for (int sl = 0; sl < st.xa.slots; ++sl) {
-              const unsigned* d = qb + 32 + (4u << st.xa.map_log2) + 64 * sl;
-              std::fprintf(stderr, " %u/%u", d[0], d[32]);
-            }
-            std::fprintf(stderr, "\n");
-          }
-        }
-      }
-      fail(PFFT_INTERNAL_ERROR, "XCD-local four-step launch: ", h[0], " hand-off waits gave up (first: site ", h[1],
-           ", local transform ", h[2], ", wanted ", h[3], ", saw ", h[4], ")");
+    const unsigned n = __atomic_load_n(xcd_report, __ATOMIC_RELAXED);
+    if (n != xcd_recoveries_seen) {
+      xcd_recoveries_seen = n;
+      fail(PFFT_INTERNAL_ERROR, "XCD-local four-step launch: ", xcd_report[1], " hand-off waits gave up (first: site ",
+           xcd_report[2], ", local transform ", xcd_report[3], ", wanted ", xcd_report[4], ", saw ", xcd_report[5],
+           "); the execute was recomputed by its recovery launch (PFFT_XCD_CHECK=1 reports this as an error)");
     }
   }
 
@@ -2826,6 +2819,7 @@ pfft_status pfft_plan_get_info(const pfft_plan_t* plan, pfft_plan_info_t* info) 
   return pfa::guarded([&] {
     if (plan == nullptr || info == nullptr) pfa::fail(PFFT_INVALID_CONFIGURATION, "null argument");
     *info = plan->impl->info;
+    if (plan->impl->xcd_report != nullptr) info->xcd_recoveries = __atomic_load_n(plan->impl->xcd_report, __ATOMIC_RELAXED);
   });
 }
 
@@ -2889,7 +2883,6 @@ pfft_status pfft_event_wait(void* event) {
     if (event == nullptr) return;
     const hipError_t e = hipEventSynchronize(static_cast<hipEvent_t>(event));
     if (e != hipSuccess) pfa::fail(PFFT_HIP_ERROR, "hipEventSynchronize: ", hipGetErrorString(e));
-    pfa::plan_t::check_xcd_failures_if_any();
   });
 }
 
@@ -2949,7 +2942,6 @@ pfft_status pfft_queue_wait(void* hip_stream) {
   return pfa::guarded([&] {
     const hipError_t e = hipStreamSynchronize(static_cast<hipStream_t>(hip_stream));
     if (e != hipSuccess) pfa::fail(PFFT_HIP_ERROR, "hipStreamSynchronize: ", hipGetErrorString(e));
-    pfa::plan_t::check_xcd_failures_if_any();
   });
 }
 
@@ -2968,7 +2960,6 @@ pfft_status pfft_plan_wait(pfft_plan_t* plan) {
     if (plan == nullptr) pfa::fail(PFFT_INVALID_CONFIGURATION, "null plan");
     const hipError_t e = hipStreamSynchronize(plan->impl->stream);
     if (e != hipSuccess) pfa::fail(PFFT_HIP_ERROR, "hipStreamSynchronize: ", hipGetErrorString(e));
-    if (plan->impl->xcd_ctl != nullptr) pfa::plan_t::check_xcd_failures();
   });
 }
 

@@ -53,7 +53,13 @@ __device__ __forceinline__ unsigned xcd_id() {
 #define PFA_XCD_CNT(i)
 #endif
 
-constexpr unsigned XCD_SPIN_LIMIT = 1u << 18;  // polls of ~170 ns: a stuck hand-off gives up after ~45 ms
+/// Bound of a hand-off wait: polls of >= 170 ns of the WAITING wave's own running time (s_sleep + one L2 round trip),
+/// i.e. at least 3 s -- a ticket holder that a co-tenant's queues de-schedule for a few time slices (CWSR) must not look
+/// like a lost task (round 4 gave up after 45 ms), and a waiter that is itself de-scheduled does not count the time it
+/// did not run.  (A wall-clock bound -- s_memrealtime in the loop -- was measured: the two live scalar registers cost the
+/// 256-lane stage bodies 0.6 % of the whole launch; profiles/r5_notes.md.)  A wait that does give up costs nothing but
+/// time: the launch is recomputed by the recovery launch behind it.
+constexpr unsigned XCD_SPIN_LIMIT = 1u << 24;
 
 __device__ __forceinline__ unsigned xcd_load(xcd_gu32* p) {
   return __builtin_amdgcn_readfirstlane(__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
@@ -69,8 +75,8 @@ __device__ __forceinline__ unsigned xcd_take(xcd_gu32* p) {
   return __builtin_amdgcn_atomic_inc32((unsigned*)p, 0xFFFFFFFFu, __ATOMIC_RELAXED, "agent");
 }
 
-/// a spin gave up: the first one records what it waited for behind the timeout word (tmo[1..7]; read by the tuner and
-/// by pfft_plan_check)
+/// a spin gave up: the first one records what it waited for behind the timeout word (tmo[1..5]; the recovery launch
+/// copies them to the plan's host report, the tuner reads them directly)
 __device__ __forceinline__ void xcd_give_up(xcd_gu32* tmo, unsigned site, unsigned a, unsigned b, unsigned c, unsigned d) {
   if (__hip_atomic_fetch_add(tmo, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u && (threadIdx.x % 64u) == 0u) {
     tmo[1] = site;
@@ -81,21 +87,46 @@ __device__ __forceinline__ void xcd_give_up(xcd_gu32* tmo, unsigned site, unsign
   }
 }
 
-/// wave-uniform bounded wait for *p >= want (cumulative counters far below 2^31)
-__device__ __forceinline__ void xcd_wait_ge(xcd_gu32* p, unsigned want, xcd_gu32* tmo, unsigned site, unsigned k) {
-  if (want == 0) return;
+/// a wait has run out of polls, or (looked at every 64th poll) the launch has already failed elsewhere
+__device__ __forceinline__ bool xcd_wait_expired(xcd_gu32* tmo, unsigned n) {
+  return n > XCD_SPIN_LIMIT || (n % 64u == 63u && xcd_load(tmo) != 0u);
+}
+
+/// Wave-uniform bounded wait for *p >= want (cumulative counters far below 2^31).  False: the wait gave up -- the
+/// caller's task must neither store nor signal (stockham_xcd_fourstep_kernel).
+/// Acquire side of a hand-off (the contract is written out in front of the kernel): the counter is polled with relaxed
+/// agent-scope atomics; the data it guards is read with sc1 loads that the compiler may not move in front of the poll --
+/// the empty asm with a memory clobber is that compiler barrier; the hardware issues a wave's memory operations in order.
+__device__ __forceinline__ bool xcd_wait_ge(xcd_gu32* p, unsigned want, xcd_gu32* tmo, unsigned site, unsigned k) {
+  if (want == 0) return true;
   unsigned v = xcd_load(p);
   for (unsigned n = 0; v < want; ++n) {
     __builtin_amdgcn_s_sleep(2);
-    if (n > XCD_SPIN_LIMIT || (n % 64u == 63u && xcd_load(tmo) != 0u)) {
+    if (xcd_wait_expired(tmo, n)) {
       xcd_give_up(tmo, site, k, want, v, n);
-      break;
+      return false;
     }
     v = xcd_load(p);
   }
+  asm volatile("" ::: "memory");
+  return true;
 }
 
 typedef unsigned xcd_u4 __attribute__((ext_vector_type(4)));
+typedef unsigned xcd_u2 __attribute__((ext_vector_type(2)));
+
+/// A wave whose hand-off wait gave up marks its work-group (control word [10]) and ENDS: it has stored nothing for the
+/// task at hand and takes part in nothing any more.  Barriers do not wait for ended waves (s_barrier counts the surviving
+/// waves of the group); the last arriver of a stage-A task and thread 0 of a stage-B task look at the mark before they
+/// signal, every wave looks at it at the top of its next iteration and leaves.  So a task is either complete -- all
+/// waves, all stores, then the signal -- or not signalled: what the recovery launch relies on.  Ending the wave (instead
+/// of carrying an "ok" flag through the stage bodies) keeps the verdict out of the stage bodies' registers: the flag
+/// cost the 256-lane bodies 1.2 % of the whole launch (profiles/r5_notes.md).
+__device__ __forceinline__ void xcd_wave_gives_up(unsigned* s_ctl) {
+  __hip_atomic_store(&s_ctl[10], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_endpgm();
+}
 
 /// claim-map entry {launch epoch, local transform + 1, claimed transform + 1, 0}: one 16-byte PLAIN store -- the line
 /// stays in this XCD's L2, where every reader of the queue finds it ...
@@ -122,12 +153,13 @@ __device__ __forceinline__ unsigned xcd_wait_claim(__amdgpu_buffer_rsrc_t map, u
     lo = __builtin_amdgcn_readfirstlane(v.z);
     if (ep == epoch && tag == k + 1u) break;
     __builtin_amdgcn_s_sleep(2);
-    if (n > XCD_SPIN_LIMIT || (n % 64u == 63u && xcd_load(tmo) != 0u)) {
+    if (xcd_wait_expired(tmo, n)) {
       xcd_give_up(tmo, 3u, k, tag, lo, n);
       lo = 0;
       break;
     }
   }
+  asm volatile("" ::: "memory");
   return lo;
 }
 
@@ -161,6 +193,23 @@ struct xcd_layout {
     return ((STW * sizeof(cx<typename CfgA::T>) + stw_bytes + 15) & ~static_cast<size_t>(15)) + XCD_LDS_CTL_BYTES;
   }
 };
+
+/// The last work-group out leaves the control block ready for the next launch: counters only -- tickets, done_a /
+/// done_b, the launch-wide words.  The claim maps are left alone (xcd_args.hpp); the epoch makes their entries and the
+/// per-transform records of this launch invalid for the next one.  `with_timeout`: the recovery launch's clear.
+__device__ __forceinline__ void xcd_clear_ctl(const xcd_args& x, xcd_gu32* ctl, unsigned wg, bool with_timeout) {
+  const unsigned qw = xcd_queue_words(x.slots, x.map_log2), mw = 4u << x.map_log2;
+  const unsigned words = xcd_ctl_words(x.n_queues, x.slots, x.map_log2);
+  for (unsigned i = threadIdx.x; i < words; i += wg) {
+    bool clear = i <= XCD_W_EXIT || i == XCD_W_REXIT || (with_timeout && i >= XCD_W_TIMEOUT && i < XCD_W_QUEUES);
+    if (i >= XCD_W_QUEUES) {
+      const unsigned o = (i - XCD_W_QUEUES) % qw;
+      clear = o < 32u || o >= 32u + mw;
+    }
+    if (clear) __hip_atomic_store(ctl + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  if (threadIdx.x == 0) xcd_add(ctl + XCD_W_EPOCH, 1u);
+}
 
 /// CfgA / CfgB: the strided configurations of the two stages (lengths n1 = CfgA::N, n2 = CfgB::N); WG: lanes of the
 /// launch's work-groups, a multiple of both configurations' -- a task is WG / Cfg::WG groups side by side, each on its own
@@ -198,7 +247,8 @@ __global__ __launch_bounds__(WG, OCCX) void stockham_xcd_fourstep_kernel(const x
   cx<T>* const lds0 = reinterpret_cast<cx<T>*>(pfa_smem_strided);
   // control words behind everything else in the dynamic region (XCD_LDS_CTL_BYTES): [4 p .. 4 p + 2], p = 0 / 1: the
   // record {ticket, transform + 1 or XCD_UNKNOWN, hand-off counter value} of the iteration with parity p; [8] stage-A
-  // arrivals of the work-group's waves; [9] "this work-group clears the control block"
+  // arrivals of the work-group's waves; [9] "this work-group clears the control block"; [10] sticky: a wave of this
+  // work-group gave up on a hand-off wait -- the work-group signals nothing from then on
   unsigned* const s_ctl = reinterpret_cast<unsigned*>(pfa_smem_strided + x.lds_ctl_off);
   // lanes of a group inside the work-group, per stage
   const unsigned half_a = threadIdx.x / CfgA::WG, lane_a = threadIdx.x % CfgA::WG;
@@ -216,6 +266,7 @@ __global__ __launch_bounds__(WG, OCCX) void stockham_xcd_fourstep_kernel(const x
   if (threadIdx.x == 0) {
     s_ctl[8] = 0u;
     s_ctl[9] = 0u;
+    s_ctl[10] = 0u;
   }
   // once per work-group lifetime: the leading twiddle tables of both stages and the store-modifier tables into LDS
   // (x.a / x.b carry the offsets: strided_args::twl_lds_off / stw_lds_off)
@@ -246,6 +297,13 @@ __global__ __launch_bounds__(WG, OCCX) void stockham_xcd_fourstep_kernel(const x
     };
     auto claim = [&](unsigned kc) PFA_LAMBDA {
       const unsigned g = xcd_add(ctl + XCD_W_NEXT, 1u);
+      // where the recovery launches would find this transform (xcd_args::tmap); read by another launch only
+      if (g < batch && x.tmap != nullptr) {
+        xcd_u2 rec;
+        rec.x = epoch + 1u;
+        rec.y = (q << 28) | (kc + 1u);
+        *reinterpret_cast<xcd_u2*>(x.tmap + 2ull * g) = rec;
+      }
       xcd_map_store(map, M, epoch, kc, g < batch ? g + 1u : 0u);
     };
     unsigned t_next = 0;  // thread 0: the ticket after the one being processed
@@ -271,6 +329,9 @@ __global__ __launch_bounds__(WG, OCCX) void stockham_xcd_fourstep_kernel(const x
     bool more = true;
     for (unsigned it = 0; more && it < x.max_iters; ++it) {
       PFA_XCD_STAMP(p_it0);
+      // a wave of this work-group has given up (xcd_wave_gives_up): its lanes are missing from every task from now on,
+      // nothing this work-group does would count -- the surviving waves leave (each at its own next iteration)
+      if (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&s_ctl[10], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) != 0u) break;
       const unsigned t = __builtin_amdgcn_readfirstlane(s_ctl[4 * par]);
       unsigned gid1 = __builtin_amdgcn_readfirstlane(s_ctl[4 * par + 1]);
       const unsigned depv = __builtin_amdgcn_readfirstlane(s_ctl[4 * par + 2]);
@@ -358,8 +419,11 @@ __global__ __launch_bounds__(WG, OCCX) void stockham_xcd_fourstep_kernel(const x
           strided_passes_range<CfgA, BWD, STW, 1, CfgA::NP - 1, decltype(io)>(io, x.a, f_a, tid_a, live, c0, lds_a, tw_a, nlive);
           PFA_XCD_STAMP(p_mid);
           PFA_XCD_ACC(5, p_p0, p_mid);
-          // the slot's previous occupant must have been read before this task's stores (the last pass)
-          if ((FREERUN == 0 || FREERUN == 3) && depv < rnd * GB) xcd_wait_ge(done_b, rnd * GB, tmo, 1u, static_cast<unsigned>(k));
+          // the slot's previous occupant must have been read before this task's stores (the last pass); a wave whose
+          // wait gave up ends here (xcd_wave_gives_up): it stores nothing, and its work-group signals nothing any more
+          if ((FREERUN == 0 || FREERUN == 3) && depv < rnd * GB && !xcd_wait_ge(done_b, rnd * GB, tmo, 1u, static_cast<unsigned>(k))) {
+            xcd_wave_gives_up(s_ctl);
+          }
           PFA_XCD_STAMP(p_dep);
           PFA_XCD_ACC(2, p_mid, p_dep);
           strided_pass<CfgA, BWD, STW, CfgA::NP - 1, decltype(io)>(io, x.a, f_a, tid_a, live, c0, lds_a, tw_a, nlive);
@@ -372,12 +436,16 @@ __global__ __launch_bounds__(WG, OCCX) void stockham_xcd_fourstep_kernel(const x
           PFA_XCD_CNT(8);
           if (threadIdx.x % 64u == 0u) {
             const unsigned old = __hip_atomic_fetch_add(&s_ctl[8], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if ((old + 1u) % NW == 0u) xcd_add(done_a, static_cast<unsigned>(HA));
+            if ((old + 1u) % NW == 0u && __hip_atomic_load(&s_ctl[10], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 0u) {
+              xcd_add(done_a, static_cast<unsigned>(HA));
+            }
           }
         } else {
-          // all of the transform's stage-A groups have stored
-          if ((FREERUN == 0 || FREERUN == 3) && depv < (rnd + 1u) * GA) {
-            xcd_wait_ge(done_a, (rnd + 1u) * GA, tmo, 2u, static_cast<unsigned>(k));
+          // all of the transform's stage-A groups have stored -- or this wave ends here, having read and stored nothing,
+          // and the work-group does not count the task as read
+          if ((FREERUN == 0 || FREERUN == 3) && depv < (rnd + 1u) * GA &&
+              !xcd_wait_ge(done_a, (rnd + 1u) * GA, tmo, 2u, static_cast<unsigned>(k))) {
+            xcd_wave_gives_up(s_ctl);
           }
           PFA_XCD_STAMP(p_dep);
           PFA_XCD_ACC(3, p_claimed, p_dep);
@@ -399,7 +467,9 @@ __global__ __launch_bounds__(WG, OCCX) void stockham_xcd_fourstep_kernel(const x
           PFA_XCD_STAMP(p_p0);
           PFA_XCD_ACC(9, p_dep, p_p0);
           // behind pass 0's barrier every wave has its input in registers: the slot is read (HB groups)
-          if (threadIdx.x == 0) xcd_add(done_b, static_cast<unsigned>(HB));
+          if (threadIdx.x == 0 && __hip_atomic_load(&s_ctl[10], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 0u) {
+            xcd_add(done_b, static_cast<unsigned>(HB));
+          }
           duties();
           strided_passes_range<CfgB, BWD, 0, 1, CfgB::NP, decltype(io), TIN>(io, x.b, f_b, tid_b, live, c0, lds_b, tw_b, nlive);
           PFA_XCD_STAMP(p_st);
@@ -432,34 +502,145 @@ __global__ __launch_bounds__(WG, OCCX) void stockham_xcd_fourstep_kernel(const x
     }
 #endif
   }
-  // Leave: every atomic of this work-group has completed before it counts itself out; the last one out clears the
-  // control block for the next launch (XCD_W_TIMEOUT stays).
+  // Leave: every atomic of this work-group has completed before it counts itself out; the last one out of a HEALTHY
+  // launch clears the control block for the next one.  A launch in which a wait gave up leaves the block as it is: the
+  // recovery launch behind it needs the counters, and clears the block itself.
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (threadIdx.x == 0) {
     const unsigned old = xcd_add(ctl + XCD_W_EXIT, 1u);
-    s_ctl[9] = old == gridDim.x - 1u ? 1u : 0u;
+    s_ctl[9] = (old == gridDim.x - 1u && xcd_load(tmo) == 0u) ? 1u : 0u;
   }
   __syncthreads();
-  // a launch that gave up anywhere reports to the host: a word of pinned memory the library reads at its next call
-  if (s_ctl[9] != 0u && threadIdx.x == 0 && x.host_failures != nullptr && xcd_load(tmo) != 0u) {
-    __hip_atomic_fetch_add(x.host_failures, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  if (s_ctl[9] != 0u) xcd_clear_ctl(x, ctl, WG, false);
+}
+
+/// Recovery launch: enqueued behind EVERY stockham_xcd_fourstep_kernel launch, on the same stream, same LDS layout.
+/// Behind a healthy launch (timeout word zero) every work-group reads that one word and leaves.  Behind a launch in
+/// which a hand-off wait gave up -- tasks were skipped, the output is incomplete -- it recomputes what is missing, so
+/// that whatever follows the execute in stream order (the submission's event included) sees a valid result:
+/// the reference's contract for the event its compute_* calls return (committed_descriptor.hpp:242-246).
+///
+/// What a failed launch leaves behind (the invariants stockham_xcd_fourstep_kernel keeps): a task either runs to the
+/// end or -- its wait gave up -- stores nothing and signals nothing, so for the transform with record {q, k}
+/// (xcd_args::tmap; slot = k % S, round = k / S) the counters of its slot say
+///   done_b >= (round + 1) * GB   every stage-B task has run: complete;
+///   done_a >= (round + 1) * GA   stage A is complete and the slot still holds the intermediate (a slot is handed to
+///                                its next occupant only when done_b is complete): stage B can be run again from it
+///                                -- any number of times, it writes the same values;
+///   otherwise (or no record)     no stage-B task has run: the user's input of that transform is untouched, also
+///                                when input and output are the same buffer.
+/// Phases (xcd_args.hpp): XCD_RECOVER_ALL recomputes every incomplete transform from the input (input and output do not
+/// alias); aliasing executes run XCD_RECOVER_STAGE_B (stage B from the rings) and then XCD_RECOVER_REST.  A recomputing
+/// work-group uses ring slot blockIdx.x as its private intermediate (grid <= queues * slots): no hand-offs, no waits.
+/// The last work-group out of the last phase writes the plan's host report and clears the control block.
+template <typename CfgA_, typename CfgB_, bool BWD, int STW, int TIN, int OCCX = CfgA_::OCC,
+          int WG = (CfgA_::WG > CfgB_::WG ? CfgA_::WG : CfgB_::WG)>
+__global__ __launch_bounds__(WG, OCCX) void stockham_xcd_recover_kernel(const xcd_args x, const int phase) {
+  xcd_gu32* const ctl = (xcd_gu32*)x.ctl;
+  xcd_gu32* const tmo = ctl + XCD_W_TIMEOUT;
+  if (xcd_load(tmo) == 0u) return;  // the launch in front was healthy
+  using CfgA = typename xcd_with_aux<CfgA_, XCD_AUX_A>::type;
+  using CfgB = typename xcd_with_aux<CfgB_, XCD_AUX_B>::type;
+  using T = typename CfgA::T;
+  using L = xcd_layout<CfgA, CfgB, WG>;
+  constexpr int HA = L::HA, HB = L::HB;
+  constexpr unsigned GA = CfgB::N / CfgA::FPW, GB = CfgA::N / CfgB::FPW;
+  constexpr unsigned TA = GA / HA, TB = GB / HB;
+  extern __shared__ __attribute__((aligned(16))) char pfa_smem_strided[];
+  cx<T>* const lds0 = reinterpret_cast<cx<T>*>(pfa_smem_strided);
+  unsigned* const s_ctl = reinterpret_cast<unsigned*>(pfa_smem_strided + x.lds_ctl_off);
+  const unsigned half_a = threadIdx.x / CfgA::WG, lane_a = threadIdx.x % CfgA::WG;
+  const unsigned half_b = threadIdx.x / CfgB::WG, lane_b = threadIdx.x % CfgB::WG;
+  const unsigned f_a = lane_a % CfgA::FPW, tid_a = lane_a / CfgA::FPW;
+  const unsigned f_b = lane_b % CfgB::FPW, tid_b = lane_b / CfgB::FPW;
+  cx<T>* const lds_a = lds0 + half_a * L::IMG_A;
+  cx<T>* const lds_b = lds0 + half_b * L::IMG_B;
+  const cx<T>* __restrict__ tw_a = static_cast<const cx<T>*>(x.a.tw);
+  const cx<T>* __restrict__ tw_b = static_cast<const cx<T>*>(x.b.tw);
+  for (int i = threadIdx.x; i < CfgA::TWL_ELEMS; i += WG) lds0[L::TWL_A + i] = tw_a[i];
+  if constexpr (!L::SAME_TW) {
+    for (int i = threadIdx.x; i < CfgB::TWL_ELEMS; i += WG) lds0[L::TWL_B + i] = tw_b[i];
   }
-  if (s_ctl[9] != 0u && !(x.keep_on_timeout != 0 && xcd_load(tmo) != 0u)) {
-    // counters only: tickets, done_a / done_b, the launch-wide words.  The claim maps are left alone (xcd_args.hpp);
-    // the epoch makes their entries invalid for the next launch.
-    const unsigned qw = xcd_queue_words(x.slots, x.map_log2), mw = 4u << x.map_log2;
-    const unsigned words = xcd_ctl_words(x.n_queues, x.slots, x.map_log2);
-    for (unsigned i = threadIdx.x; i < words; i += WG) {
-      bool clear = i < XCD_W_EXIT + 1u;
-      if (i >= XCD_W_QUEUES) {
-        const unsigned o = (i - XCD_W_QUEUES) % qw;
-        clear = o < 32u || o >= 32u + mw;
+  if constexpr (STW == 1) {
+    const cx<T>* src = static_cast<const cx<T>*>(x.a.stw_tab);
+    const int n = x.a.stw_levels << x.a.stw_lshift;
+    for (int i = threadIdx.x; i < n; i += WG) lds0[L::STW + i] = src[i];
+  }
+  __syncthreads();
+  const unsigned S = static_cast<unsigned>(x.slots);
+  const unsigned epoch = xcd_load(ctl + XCD_W_EPOCH);
+  const unsigned qw = xcd_queue_words(x.slots, x.map_log2), mw = 4u << x.map_log2;
+  const long long slot_elems = static_cast<long long>(CfgA::N) * CfgB::N;
+  auto stage_b = [&](long long g, long long sbase) PFA_LAMBDA {
+    for (unsigned r = 0; r < TB; ++r) {
+      bool live;
+      long long c0, nlive;
+      const auto io = strided_group<CfgB, 0>(x.b, g * GB + r * HB + half_b, f_b, &live, &c0, &nlive, sbase, 0);
+      {
+        // pass 0 as in the persistent launch: lanes element-fastest inside the input tiles, on the GROUP's own lanes
+        // (strided_pass' own TIN mapping takes the work-group's lane index: right only for one group per work-group)
+        unsigned f0 = f_b, tid0 = tid_b;
+        bool live0 = live;
+        if constexpr (TIN != 0) {
+          constexpr unsigned TW = tin_width<CfgB, TIN>();
+          f0 = (lane_b / TW) % CfgB::FPW;
+          tid0 = (lane_b / (TW * CfgB::FPW)) * TW + lane_b % TW;
+          live0 = static_cast<long long>(f0) < nlive;
+        }
+        cx<T> cur[CfgB::bpt(0)][CfgB::Seq::r[0]];
+        strided_pass0_load<CfgB, BWD>(io, x.b, f0, tid0, live0, cur);
+        strided_pass0_compute<CfgB, TIN, 0>(cur, f0, tid0, lds_b);
       }
-      if (clear) __hip_atomic_store(ctl + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      strided_passes_range<CfgB, BWD, 0, 1, CfgB::NP, decltype(io), TIN>(io, x.b, f_b, tid_b, live, c0, lds_b, tw_b, nlive);
     }
-    if (threadIdx.x == 0) xcd_add(ctl + XCD_W_EPOCH, 1u);
+  };
+  for (long long g = blockIdx.x; g < x.batch; g += gridDim.x) {
+    // 0: stage A not complete (or never claimed), 1: stage A complete, stage B not, 2: complete
+    int state = 0;
+    long long ring = 0;
+    {
+      const xcd_u2 rec = *reinterpret_cast<const xcd_u2*>(x.tmap + 2ull * g);
+      const unsigned ry = __builtin_amdgcn_readfirstlane(rec.y);
+      const unsigned rq = ry >> 28, rk1 = ry & 0x0FFFFFFFu;
+      if (static_cast<unsigned>(__builtin_amdgcn_readfirstlane(rec.x)) == epoch + 1u && rk1 != 0u && rq < static_cast<unsigned>(x.n_queues)) {
+        const unsigned k = rk1 - 1u, slot = k % S, rnd = k / S;
+        xcd_gu32* const done_a = ctl + XCD_W_QUEUES + rq * qw + 32u + mw + slot * 64u;
+        const unsigned da = xcd_load(done_a), db = xcd_load(done_a + 32);
+        state = db >= (rnd + 1u) * GB ? 2 : (da >= (rnd + 1u) * GA ? 1 : 0);
+        ring = (static_cast<long long>(rq) * S + slot) * slot_elems;
+      }
+    }
+    if (phase == XCD_RECOVER_STAGE_B) {
+      if (state == 1) stage_b(g, ring);
+      continue;
+    }
+    if (state == 2 || (state == 1 && phase == XCD_RECOVER_REST)) continue;
+    const long long mine = static_cast<long long>(blockIdx.x) * slot_elems;
+    for (unsigned r = 0; r < TA; ++r) {
+      bool live;
+      long long c0, nlive;
+      const auto io = strided_group<CfgA, 0>(x.a, g * GA + r * HA + half_a, f_a, &live, &c0, &nlive, 0, mine);
+      strided_passes<CfgA, BWD, STW, 0, decltype(io)>(io, x.a, f_a, tid_a, live, c0, lds_a, tw_a, nlive);
+    }
+    // the work-group's own stores have reached the L2 before its sc1 loads ask for them
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    stage_b(g, mine);
+    __syncthreads();
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (phase == XCD_RECOVER_STAGE_B) return;  // (the counters stay for the phase behind this one)
+  if (threadIdx.x == 0) s_ctl[9] = xcd_add(ctl + XCD_W_REXIT, 1u) == gridDim.x - 1u ? 1u : 0u;
+  __syncthreads();
+  if (s_ctl[9] == 0u) return;
+  if (threadIdx.x == 0 && x.report != nullptr) {
+    for (unsigned i = 0; i < 6u; ++i) __hip_atomic_store(x.report + 1 + i, xcd_load(tmo + i), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_fetch_add(x.report, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+  __syncthreads();
+  xcd_clear_ctl(x, ctl, WG, true);
 }
 
 /// LDS bytes of the launch (xcd_layout) and the table offsets the stage arguments carry

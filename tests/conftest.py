@@ -34,4 +34,5 @@ def oracle():
 def golden():
     import numpy as np
     d = os.path.join(ROOT, "tests", "golden")
-    return {"fft": np.load(os.path.join(d, "fft_vectors.npz")), "tw": np.load(os.path.join(d, "static_twiddles.npz"))}
+    return {"fft": np.load(os.path.join(d, "fft_vectors.npz")), "tw": np.load(os.path.join(d, "static_twiddles.npz")),
+            "global": np.load(os.path.join(d, "fft_vectors_global.npz"))}

@@ -19,6 +19,20 @@ def gen_fourier_data(batch, dims, dtype, seed=0):
     return x.astype(ctype), y.astype(ctype)
 
 
+def golden_global_cases(golden):
+    """(key, precision, n, input, expected output) of the GLOBAL-level fixture (tests/golden/fft_vectors_global.npz:
+    the reference's GlobalTest / WorkgroupOrGlobal sizes, batch 1).  Only the output is stored; the input is regenerated
+    from the reference generator's seed and must hash to the stored sha256."""
+    import hashlib
+    g = golden["global"]
+    for k in sorted(f[:-4] for f in g.files if f.endswith("_out")):
+        prec, _, n = k.split("_")
+        x, _ = gen_fourier_data(1, [int(n)], np.complex64 if prec == "f32" else np.complex128)
+        digest = hashlib.sha256(np.ascontiguousarray(x).tobytes()).digest()
+        assert digest == g[k + "_in_sha256"].tobytes(), "the regenerated input of %s is not the fixture's" % k
+        yield k, prec, int(n), x, g[k + "_out"]
+
+
 def default_strides(dims):
     s, t = [0] * len(dims), 1
     for i in reversed(range(len(dims))):

@@ -57,6 +57,15 @@ def test_golden_vectors_forward_and_backward(golden, oracle):
         _check(out, oref, n, x.dtype, key + " fwd vs oracle")
         back = G.run(d, pf.direction.BACKWARD, y.ravel()).reshape(x.shape)
         _check(back, x.astype(np.complex128) * n, n, x.dtype, key + " bwd vs golden")
+    # the reference's GLOBAL-level sizes (GlobalTest / BackwardGlobalTest 32768 / 65536 / 131072, WorkgroupOrGlobal 8192 /
+    # 16384 in double: instantiate_fft_tests.hpp:140-151, 169-173) against committed vectors, both placements
+    for key, prec, n, x, y in H.golden_global_cases(golden):
+        for place in (1, 0):
+            d = G.make_descriptor([n], prec, placement=place)
+            out = G.run(d, pf.direction.FORWARD, x.ravel()).reshape(y.shape)
+            _check(out, y, n, x.dtype, key + " fwd vs golden, placement %d" % place)
+            back = G.run(d, pf.direction.BACKWARD, y.ravel()).reshape(x.shape)
+            _check(back, x.astype(np.complex128) * n, n, x.dtype, key + " bwd vs golden, placement %d" % place)
 
 
 def test_config1_in_place(golden):
@@ -273,10 +282,11 @@ def test_maximum_sizes():
     a 7-smooth length near the top of the generic tier, and a long prime-factor-31 length"""
     import gpu_utils as G
     pf = _pf()
-    # (16807 = 7^5, 19683 = 3^9, 20480, fp64 10125 / 10240: the longest single-work-group transforms -- the whole LDS of a CU)
+    # (16807 = 7^5, 18000, 19683 = 3^9, 20480, fp64 9604 / 10125 / 10240: the longest single-work-group transforms -- the
+    #  whole LDS of a CU; 32768 / fp64 16384: the register-resident kernel's, test_register_resident_lengths)
     for prec, dtype, sizes in (("f32", np.complex64, [1 << 22, 1 << 24, 10080, 31 * 31 * 31 * 8, 9 * 5 * 7 * 11 * 13 * 16,
-                                                      16807, 19683, 20480]),
-                               ("f64", np.complex128, [1 << 22, 5040, 31 * 29 * 23 * 4, 10125, 10240])):
+                                                      16807, 18000, 19683, 20480, 32768]),
+                               ("f64", np.complex128, [1 << 22, 5040, 31 * 29 * 23 * 4, 9604, 10125, 10240, 16384])):
         for n in sizes:
             x, y = H.gen_fourier_data(1, [n], dtype, seed=5)
             d = G.make_descriptor([n], prec)
@@ -299,7 +309,7 @@ def test_wave64_prime_factors(prec, oracle):
     import gpu_utils as G
     pf = _pf()
     dtype = np.complex64 if prec == "f32" else np.complex128
-    for n in (37, 43, 53, 61, 37 * 64, 61 * 16, 43 * 47, 3 * 53 * 5, 61 * 61 * 8):
+    for n in (37, 41, 43, 47, 53, 59, 61, 74, 37 * 64, 41 * 64, 61 * 16, 43 * 47, 59 * 59, 3 * 53 * 5, 61 * 61 * 8):
         for batch in (1, 5):
             x, y = H.gen_fourier_data(batch, [n], dtype, seed=n)
             for place in (0, 1):
@@ -547,6 +557,53 @@ def test_fused_multidimensional():
         finally:
             del os.environ["PFFT_FUSED_ND"]
         assert H.rel_l2(fused, per_dim) < (2e-6 if prec == "f32" else 5e-15), (prec, dims)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("prec,n", [("f32", 32768), ("f64", 16384)])
+def test_register_resident_lengths(prec, n):
+    """The 256 KiB transforms that stay in the registers of one work-group for all their passes, one HBM pass
+    (stockham_wg_hx.hpp): fp32 32768, the reference's first GlobalTest size, and fp64 16384, its largest
+    WorkgroupOrGlobal size (instantiate_fft_tests.hpp:140-151).  Against NumPy on every layout the packed kernels
+    serve -- both placements, both storages, both directions, offsets and scales, ragged batches -- and against the
+    four-step plan of the same descriptor (PFFT_NO_REGRES=1), which is another algorithm: equal within the tolerance."""
+    import gpu_utils as G
+    pf = _pf()
+    dtype = np.complex64 if prec == "f32" else np.complex128
+    plan = G.make_descriptor([n], prec, batch=3).commit()
+    info = plan.info()
+    assert info.dims[0].tier == 1 and list(info.launches) == [1, 1], "one work-group kernel, one launch"
+    assert int(np.prod(info.dims[0].factors[:info.dims[0].n_factors])) == n
+    os.environ["PFFT_NO_REGRES"] = "1"
+    try:
+        twin = G.make_descriptor([n], prec, batch=3).commit()
+        assert twin.info().dims[0].tier == 3 and min(twin.info().launches) >= 2
+    finally:
+        del os.environ["PFFT_NO_REGRES"]
+    for batch in (1, 3, 517):  # (517: more transforms than a persistent grid has work-groups, a ragged tail)
+        x, y = H.gen_fourier_data(batch, [n], dtype, seed=batch)
+        for place in (1, 0):
+            for storage in (0, 1):
+                d = G.make_descriptor([n], prec, batch=batch, placement=place, storage=storage)
+                got, _ = G.transform_packed(d, pf.direction.FORWARD, x)
+                _check(got, y, n, dtype, ("regres fwd", prec, n, batch, place, storage))
+                back, _ = G.transform_packed(d, pf.direction.BACKWARD, y)
+                _check(back, x.astype(np.complex128) * n, n, dtype, ("regres bwd", prec, n, batch, place, storage))
+    x, y = H.gen_fourier_data(5, [n], dtype, seed=77)
+    d = G.make_descriptor([n], prec, batch=5, fwd_offset=24, bwd_offset=8, fwd_scale=0.5, bwd_scale=2.0 / n)
+    got, buf = G.transform_packed(d, pf.direction.FORWARD, x)
+    _check(got, y * 0.5, n, dtype, ("regres offsets + scale", prec, n))
+    assert np.all(buf[:8] == H.PADDING_VALUE), "elements in front of the offset stay untouched"
+    back, _ = G.transform_packed(d, pf.direction.BACKWARD, y)
+    _check(back, x.astype(np.complex128) * 2.0, n, dtype, ("regres backward offsets + scale", prec, n))
+    # the four-step twin of the same descriptor
+    os.environ["PFFT_NO_REGRES"] = "1"
+    try:
+        got2, _ = G.transform_packed(G.make_descriptor([n], prec, batch=5), pf.direction.FORWARD, x)
+    finally:
+        del os.environ["PFFT_NO_REGRES"]
+    got1, _ = G.transform_packed(G.make_descriptor([n], prec, batch=5), pf.direction.FORWARD, x)
+    _check(got1, got2.astype(np.complex128), n, dtype, ("regres vs four-step twin", prec, n))
 
 
 def test_random_descriptors():

@@ -136,3 +136,51 @@ def test_the_tuned_table_is_used_by_default_and_can_be_turned_off(tmp_path):
         finally:
             del os.environ["PFFT_NO_TUNED_TABLE"]
         assert static[:len(factors)] != factors, (prec, n, static)
+
+
+ALL_TUNED_CHILD = r"""
+import json, sys, time
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import numpy as np, torch
+import gpu_utils as G, helpers as H
+entries = json.loads(sys.argv[1])
+bad, t0 = [], time.time()
+for prec, n, is_split, factors in entries:
+    batch = max(2, min(64, (1 << 21) // n))
+    plan = G.make_descriptor([n], prec, batch=batch).commit()
+    d = plan.info().dims[0]
+    got = [int(d.factors[i]) for i in range(d.n_factors)]
+    want = factors[:-2] if (len(factors) >= 3 and factors[-2] == 0) else factors
+    g = torch.Generator(device="cuda").manual_seed(n)
+    x = torch.empty(batch * n, dtype=torch.complex64 if prec == "f32" else torch.complex128, device="cuda")
+    torch.view_as_real(x).uniform_(-1, 1, generator=g)
+    y = torch.empty_like(x)
+    plan.compute_forward(x, y).wait()
+    z = torch.empty_like(x)
+    plan.compute_backward(y, z).wait()
+    b = batch - 1
+    ref = np.fft.fft(x.view(batch, n)[b].cpu().numpy().astype(np.complex128))
+    err = float(H.rel_l2(y.view(batch, n)[b].cpu().numpy(), ref))
+    rt = float(((z / n - x).abs().double().pow(2).sum() / x.abs().double().pow(2).sum()).sqrt())
+    tol = 2e-6 if prec == "f32" else 5e-15
+    if got[:len(want)] != want or not (err <= tol and rt <= tol):
+        bad.append([prec, n, got, want, err, rt])
+print(json.dumps({"checked": len(entries), "bad": bad, "seconds": time.time() - t0}))
+""" % (ROOT, os.path.join(ROOT, "tests"))
+
+
+def test_every_tuned_entry_is_taken_and_computes_the_right_answer():
+    """Every (precision, length) of the shipped table (portfft_amd/csrc/tuned_gfx950.inc) -- radix sequences, lanes and
+    four-step splits that replace the static rule BY DEFAULT -- committed with a small batch: the planner takes the
+    entry's factors, the forward transform matches NumPy at the parity tolerance of tests/test_gpu_parity.py and the
+    backward transform returns the input (the table was covered by 5 sampled entries and an out-of-suite
+    A/B script)."""
+    entries = _tuned_entries()
+    if not entries:
+        pytest.skip("the table is empty")
+    p = subprocess.run([sys.executable, "-c", ALL_TUNED_CHILD, json.dumps(entries)], capture_output=True, text=True,
+                       timeout=1500)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
+    out = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    print("tuned table: %d entries in %.0f s" % (out["checked"], out["seconds"]))
+    assert out["checked"] == len(entries) and not out["bad"], out["bad"][:10]

@@ -52,6 +52,22 @@ def test_oracle_matches_golden_vectors(oracle, golden, sg):
     print("worst rel-L2", worst)
 
 
+def test_oracle_global_level_matches_golden_vectors(oracle, golden):
+    """the oracle's GLOBAL level (multi-factor algorithm, dispatcher/global_dispatcher.hpp:343-408) pinned to committed
+    vectors at the reference's own GLOBAL sizes: GlobalTest 32768 / 65536 / 131072 in float, WorkgroupOrGlobal 8192 /
+    16384 in double (instantiate_fft_tests.hpp:140-151) -- forward and unnormalised backward"""
+    seen = []
+    for key, prec, n, x, y in H.golden_global_cases(golden):
+        desc = oracle.make_desc([n], prec)
+        out = oracle.compute(desc, oracle.FORWARD, x.ravel(), threads=4).reshape(y.shape)
+        back = oracle.compute(desc, oracle.BACKWARD, y.ravel(), threads=4).reshape(x.shape)
+        e1, e2 = H.rel_l2(out[0], y[0]), H.rel_l2(back[0], x[0].astype(np.complex128) * n)
+        assert e1 <= H.REL_L2_TOL[x.dtype] and e2 <= H.REL_L2_TOL[x.dtype], (key, e1, e2)
+        assert H.check_reference_rule(out, y, n), key
+        seen.append(key)
+    assert seen == ["f32_b1_131072", "f32_b1_32768", "f32_b1_65536", "f64_b1_16384", "f64_b1_8192"], seen
+
+
 def test_config1_values(oracle, golden):
     """BASELINE config 1 / SURVEY 8(c): fp32 N=64 batch=1, first input and output values"""
     x = golden["fft"]["f32_b1_64_in"][0]

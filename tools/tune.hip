@@ -8,6 +8,7 @@
 #include <string>
 #include <vector>
 #include "../portfft_amd/csrc/stockham_xlane.hpp"
+#include "../portfft_amd/csrc/stockham_wg_hx.hpp"
 using namespace pfa;
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s line %d\n", hipGetErrorString(e_), __LINE__); exit(1);} } while (0)
 
@@ -39,6 +40,23 @@ void add_xlane(const char* name) {
   CK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS_BYTES));
   g_variants.push_back({name, Cfg::FPW, Cfg::WG, Cfg::LDS_BYTES, fn, [d_tw](unsigned grid, long long nfft) {
     hipLaunchKernelGGL((stockham_wg_xlane_kernel<Cfg, false>), dim3(grid), dim3(Cfg::WG), Cfg::LDS_BYTES, 0, (const cx<T>*)g_in, (cx<T>*)g_out, d_tw, nfft, (T)1);
+  }});
+}
+
+/// register-resident form (stockham_wg_hx.hpp)
+template <typename Cfg>
+void add_hx(const char* name) {
+  using T = typename Cfg::T;
+  auto tw = make_twiddles<typename Cfg::Seq, T>();
+  cx<T>* d_tw;
+  CK(hipMalloc(&d_tw, tw.size() * sizeof(cx<T>)));
+  CK(hipMemcpy(d_tw, tw.data(), tw.size() * sizeof(cx<T>), hipMemcpyHostToDevice));
+  const void* fn = (const void*)&stockham_wg_hx_kernel<Cfg, false>;
+  constexpr size_t lds = wg_hx_lds_bytes<Cfg>();
+  if (lds > 160 * 1024) { printf("%s: %zu bytes of LDS -- skipped\n", name, lds); return; }
+  CK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  g_variants.push_back({name, 1, Cfg::WG, lds, fn, [d_tw](unsigned grid, long long nfft) {
+    hipLaunchKernelGGL((stockham_wg_hx_kernel<Cfg, false>), dim3(grid), dim3(Cfg::WG), wg_hx_lds_bytes<Cfg>(), 0, (const cx<T>*)g_in, (cx<T>*)g_out, d_tw, nfft, (T)1);
   }});
 }
 
@@ -99,6 +117,21 @@ int main() {
   add<wg_cfg<f, radix_list<16, 16, 16, 2>, 512, 1, 16, 1, TW_GLOBAL, 4, NT>, false>("r16.16.16.2 twG wg512 o4");
   add<wg_cfg<f, radix_list<8, 8, 8, 16>, 512, 1, 16, 1, TW_GLOBAL, 4, NT>, false>("r8.8.8.16 twG wg512 o4");
   add<wg_cfg<f, radix_list<16, 8, 8, 8>, 512, 1, 16, 1, TW_GLOBAL, 4, NT>, false>("r16.8.8.8 twG wg512 o4");
+#elif TUNE_CASE == 32768  // beyond LDS: register-resident forms
+  using T = f; const int N = 32768;
+  add_hx<wg_cfg<f, radix_list<32, 32, 32>, 512, 1, 32, 1, TW_GLOBAL, 2, NT, 0, 1>>("hx 32.32.32 wg512 TWL1");
+  add_hx<wg_cfg<f, radix_list<32, 32, 32>, 512, 1, 32, 1, TW_GLOBAL, 2, NT, 0, 0>>("hx 32.32.32 wg512 TWL0");
+  add_hx<wg_cfg<f, radix_list<32, 32, 32>, 1024, 1, 32, 1, TW_GLOBAL, 4, NT, 0, 1>>("hx 32.32.32 wg1024 TWL1");
+  add_hx<wg_cfg<f, radix_list<16, 16, 16, 8>, 1024, 1, 16, 1, TW_GLOBAL, 4, NT, 0, 1>>("hx 16.16.16.8 wg1024 TWL1");
+  add_hx<wg_cfg<f, radix_list<16, 16, 16, 8>, 512, 1, 16, 1, TW_GLOBAL, 2, NT, 0, 1>>("hx 16.16.16.8 wg512 TWL1");
+  add_hx<wg_cfg<f, radix_list<8, 16, 16, 16>, 1024, 1, 8, 1, TW_GLOBAL, 4, NT, 0, 2>>("hx 8.16.16.16 wg1024 TWL2");
+  add_hx<wg_cfg<f, radix_list<32, 32, 32>, 1024, 1, 32, 1, TW_GLOBAL, 4, NT, 0, 0>>("hx 32.32.32 wg1024 TWL0");
+#elif TUNE_CASE == 16384064  // fp64 16384: the same 256 KiB
+  using T = d; const int N = 16384;
+  add_hx<wg_cfg<d, radix_list<16, 32, 32>, 512, 1, 16, 1, TW_GLOBAL, 2, NT, 0, 1>>("f64 hx 16.32.32 wg512 TWL1");
+  add_hx<wg_cfg<d, radix_list<16, 16, 8, 8>, 512, 1, 16, 1, TW_GLOBAL, 2, NT, 0, 1>>("f64 hx 16.16.8.8 wg512 TWL1");
+  add_hx<wg_cfg<d, radix_list<16, 16, 8, 8>, 1024, 1, 16, 1, TW_GLOBAL, 4, NT, 0, 1>>("f64 hx 16.16.8.8 wg1024 TWL1");
+  add_hx<wg_cfg<d, radix_list<8, 8, 16, 16>, 512, 1, 8, 1, TW_GLOBAL, 2, NT, 0, 2>>("f64 hx 8.8.16.16 wg512 TWL2");
 #elif TUNE_CASE == 16384
   using S = radix_list<32, 32, 16>; using T = f; const int N = 16384;
   add<wg_cfg<f, S, 512, 1, 16, 1, TW_GLOBAL, 2, NT>, false>("r32.32.16 twG wg512 o2");
