@@ -430,6 +430,10 @@ def main():
                          "kernel": live_label, "hbm_passes_per_execute": launches,
                          "launches_per_execute": int(plan.info().launches[0]),
                          "kernel_ms": round(avg_kernel_ms, 5),
+                         # the spread of the per-execute event times behind that mean (rocprofv3 sees 704-752 us on the
+                         # headline kernel, profiles/r4_c2_kernel_stats.csv): [min, median, max]
+                         "kernel_ms_min_median_max": [round(v, 5) for v in (min(kernel_ms), sorted(kernel_ms)[len(kernel_ms) // 2],
+                                                                          max(kernel_ms))],
                          "copy_probe": None if copy_ms is None else {
                              "what": "torch device-to-device copy_ of the same input into the same output buffer",
                              "gbs": round(alg_bytes / (copy_ms * 1e-3) / 1e9, 1),

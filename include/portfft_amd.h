@@ -104,6 +104,9 @@ typedef struct pfft_plan_info_t {
                            by its recovery launch, which does nothing unless a hand-off wait of the former gave up */
   uint64_t xcd_recoveries; /* executes of this plan (copy) whose persistent launch gave up and were recomputed, in stream
                               order, by the recovery launch: the result was valid whenever the execute's event completed */
+  uint64_t knob_mask; /* which PFFT_* environment knobs differed from their defaults when the plan was committed (bit order:
+                         plan_knobs::from_env, portfft_amd/csrc/plan_core.cpp); 0 = the product's defaults.  The environment
+                         is read at commit only, never at execute */
 } pfft_plan_info_t;
 
 typedef struct pfft_plan_t pfft_plan_t; /* opaque: portfft::committed_descriptor */

@@ -58,6 +58,7 @@ class pfft_plan_info_t(C.Structure):
         ("launches", C.c_int32 * 2),
         ("xcd_local", C.c_int32 * 2),
         ("xcd_recoveries", C.c_uint64),
+        ("knob_mask", C.c_uint64),
     ]
 
 

@@ -194,7 +194,7 @@ void validate(const pfft_desc_t& d) {
   // only supported for sizes that fit in the registers of a subgroup", committed_descriptor_impl.hpp:757-764).  That
   // is a limit of its kernels, not of the interface: here every length a single work-group can hold takes any
   // stride / distance (stockham_wg_unpacked_kernel, generic tier), so the check is not mirrored; only lengths that
-  // need the multi-kernel tier still require the default layout (plan.cpp).
+  // need the multi-kernel tier still require the default layout (plan_*.cpp).
 }
 
 }  // namespace pfa

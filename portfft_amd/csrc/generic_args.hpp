@@ -40,7 +40,7 @@ struct generic_args {
 
 inline unsigned long long generic_magic(unsigned d) { return ((1ull << 40) / d) + 1; }
 
-/// radices the generic kernel can run; the planner factorises lengths into these (plan.cpp: choose_radices)
+/// radices the generic kernel can run; the planner factorises lengths into these (plan_core.cpp: choose_radices)
 #define PFA_GENERIC_RADICES(X) \
   X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16) X(17) X(19) X(23) X(29) X(31)
 /// ... and the primes only the "big radix" instantiation of the kernel carries (generic_fft_kernel<T, true>): a

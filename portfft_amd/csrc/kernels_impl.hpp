@@ -244,7 +244,7 @@ spec_kernel make_spec_entry_hx(int groups_per_wg = 0) {
 
 /// Launch with one by-value argument struct.  args.any_order: the packet carries no barrier bit
 /// (hipExtAnyOrderLaunch), so the work-groups may start while the previous launch of the stream is still draining;
-/// the plan sets it only for launches that are independent of everything that can still be in flight (plan.cpp,
+/// the plan sets it only for launches that are independent of everything that can still be in flight (plan_exec.cpp,
 /// chunk overlap).
 template <typename K, typename A>
 inline hipError_t pfa_launch(K kernel, dim3 g, dim3 b, size_t lds, hipStream_t stream, const A& args) {

@@ -9,11 +9,13 @@
 // Design (ours, MI355X-specific): a CU has 512 KiB of vector registers beside its 160 KiB of LDS.  The transform
 // (256 KiB: fp32 2^15, fp64 2^14) stays in the REGISTERS of one 512-lane work-group (64 fp32 complex values per lane)
 // for all of its Stockham passes; only the exchange between two passes goes through LDS, and it goes in two rounds
-// through an image of HALF the transform: round h moves the elements [h * N/2, (h + 1) * N/2) -- on the writing
-// side the butterflies j with (j < NB / 2) == (h == 0) (every output of butterfly j lies in one half, because all
-// later radices are even), on the reading side the butterfly legs t with (t < R / 2) == (h == 0).  The registers a
-// lane frees by writing are the ones it reads into, so the peak is the transform itself plus a butterfly's temporaries.
-// 64-bit (fp64: 128-bit) LDS accesses at their full rate, four barriers per exchange instead of two.
+// through an image of (about) HALF the transform.  Between pass p (radix R, stride Ns) and pass p + 1 (radix R1, NB1 =
+// N / R1 butterflies) the elements split at H = ceil(R1 / 2) * NB1: round 0 moves [0, H), round 1 moves [H, N).  On the
+// reading side that is a split by butterfly leg (legs t < ceil(R1 / 2) read in round 0), on the writing side a split by
+// butterfly (H is a multiple of the Ns * R elements a butterfly's outputs span, so butterfly j writes in round 0 iff
+// j < H / R) -- any radices, ragged passes included; for even R1 the two halves are equal.  The registers a lane frees
+// by writing are the ones it reads into, so the peak is the transform itself plus a butterfly's temporaries.  64-bit
+// (fp64: 128-bit) LDS accesses at their full rate, four barriers per exchange instead of two.
 // Pass 0 reads HBM directly, the last pass writes it directly, both lane-contiguous -- 1.0 x the algorithmic traffic.
 //
 // Twiddles: with 128 data registers per lane there is no room to keep them (the N = 16384 kernel holds 77 complex
@@ -26,25 +28,25 @@
 
 namespace pfa {
 
-/// Is the configuration one this kernel can run?  One transform per work-group, no ragged pass (a pass with one
-/// butterfly per lane splits its writers by lane halves, which must be whole waves), all radices but the first even.
+/// Is the configuration one this kernel can run?  One transform per work-group, direct HBM access, two passes at least.
 template <typename Cfg>
 constexpr bool wg_hx_supported() {
-  if (Cfg::NP < 2 || Cfg::FPW != 1 || Cfg::STAGED != 0 || Cfg::N % 2 != 0) return false;
-  for (int p = 0; p < Cfg::NP; ++p) {
-    const int nb = Cfg::N / Cfg::Seq::r[p];
-    if (nb % Cfg::TPF != 0) return false;
-    const int bpt = nb / Cfg::TPF;
-    if (bpt % 2 != 0 && !(bpt == 1 && Cfg::TPF % 128 == 0)) return false;
-    if (p >= 1 && Cfg::Seq::r[p] % 2 != 0) return false;
-  }
-  return true;
+  return Cfg::NP >= 2 && Cfg::FPW == 1 && Cfg::STAGED == 0;
 }
 
-/// elements of the half image (padded like wg_cfg's full image), and the kernel's LDS bytes
+/// the split point of the exchange behind pass P: elements [0, H) move in round 0, [H, N) in round 1
+template <typename Cfg>
+constexpr int wg_hx_split(int P) {
+  const int r1 = Cfg::Seq::r[P + 1];
+  return ((r1 + 1) / 2) * (Cfg::N / r1);
+}
+
+/// elements of the image (the largest first half of any exchange, padded like wg_cfg's full image), and the LDS bytes
 template <typename Cfg>
 constexpr int wg_hx_image_elems() {
-  return Cfg::pad(Cfg::N / 2 - 1) + 1 + (Cfg::PADS == 0 ? 0 : Cfg::PADW);
+  int h = 0;
+  for (int p = 0; p + 1 < Cfg::NP; ++p) h = wg_hx_split<Cfg>(p) > h ? wg_hx_split<Cfg>(p) : h;
+  return Cfg::pad(h - 1) + 1 + (Cfg::PADS == 0 ? 0 : Cfg::PADW);
 }
 template <typename Cfg>
 constexpr size_t wg_hx_lds_bytes() {
@@ -89,7 +91,7 @@ PFA_DEV void hxw_twiddle(cx<typename Cfg::T> (&v)[Cfg::Seq::r[P]], unsigned q, c
   }
 }
 
-/// exchange between pass P and pass P + 1 through the half image, in two rounds
+/// exchange between pass P and pass P + 1 through the image, in two rounds
 template <typename Cfg, int P>
 PFA_DEV void hxw_exchange(cx<typename Cfg::T> (&v)[Cfg::bpt(P)][Cfg::Seq::r[P]],
                           cx<typename Cfg::T> (&n)[Cfg::bpt(P + 1)][Cfg::Seq::r[P + 1]], unsigned tid,
@@ -97,27 +99,34 @@ PFA_DEV void hxw_exchange(cx<typename Cfg::T> (&v)[Cfg::bpt(P)][Cfg::Seq::r[P]],
   using Seq = typename Cfg::Seq;
   constexpr int R = Seq::r[P], Ns = Seq::ns(P), NB = Cfg::N / R, BPT = Cfg::bpt(P);
   constexpr int R1 = Seq::r[P + 1], NB1 = Cfg::N / R1, BPT1 = Cfg::bpt(P + 1);
-  constexpr int HALF = Cfg::N / 2;
+  constexpr int HL = (R1 + 1) / 2;         // legs of a pass-(P + 1) butterfly read in round 0
+  constexpr int H = wg_hx_split<Cfg>(P);   // = HL * NB1, a multiple of Ns * R
+  constexpr int J0 = H / R;                // butterflies of pass P that write in round 0
+  static_assert(H % (Ns * R) == 0 && J0 * R == H, "the split point lies between two butterflies' outputs");
   sfor<0, 2>([&](auto h_) PFA_LAMBDA {
     constexpr int h = decltype(h_)::value;
     sfor<0, BPT>([&](auto i_) PFA_LAMBDA {
       constexpr int i = decltype(i_)::value;
       const unsigned j = tid + i * Cfg::TPF;
-      // (BPT even: butterfly i of every lane lies in half i / (BPT / 2); BPT == 1: the lanes split, whole waves each)
-      const bool mine = BPT > 1 ? (i / ((BPT + 1) / 2) == h) : ((j < NB / 2) == (h == 0));
-      if (mine) {
-        const unsigned base = (j / Ns) * (Ns * R) + j % Ns - h * HALF;
-        if constexpr (pad_is_linear<Cfg>(Ns, R, Ns * R)) {
-          cx<typename Cfg::T>* p = img + lds_pad<Cfg>(base);
-          sfor<0, R>([&](auto u_) PFA_LAMBDA {
-            constexpr int u = decltype(u_)::value;
-            p[u * pad_step<Cfg>(Ns)] = v[i][u];
-          });
-        } else {
-          sfor<0, R>([&](auto u_) PFA_LAMBDA {
-            constexpr int u = decltype(u_)::value;
-            img[lds_pad<Cfg>(base + u * Ns)] = v[i][u];
-          });
+      // butterflies [lo, hi) write in this round; most (lane, i) slots are wholly inside or wholly outside at compile time
+      constexpr int lo = h == 0 ? 0 : J0, hi = h == 0 ? J0 : NB;
+      constexpr bool none = (i + 1) * Cfg::TPF <= lo || i * Cfg::TPF >= hi;
+      constexpr bool all = i * Cfg::TPF >= lo && (i + 1) * Cfg::TPF <= hi;
+      if constexpr (!none) {
+        if (all || (j >= static_cast<unsigned>(lo) && j < static_cast<unsigned>(hi))) {
+          const unsigned base = (j / Ns) * (Ns * R) + j % Ns - h * H;
+          if constexpr (pad_is_linear<Cfg>(Ns, R, Ns * R) && (H % (Cfg::PADS == 0 ? 1 : Cfg::PADS) == 0)) {
+            cx<typename Cfg::T>* p = img + lds_pad<Cfg>(base);
+            sfor<0, R>([&](auto u_) PFA_LAMBDA {
+              constexpr int u = decltype(u_)::value;
+              p[u * pad_step<Cfg>(Ns)] = v[i][u];
+            });
+          } else {
+            sfor<0, R>([&](auto u_) PFA_LAMBDA {
+              constexpr int u = decltype(u_)::value;
+              img[lds_pad<Cfg>(base + u * Ns)] = v[i][u];
+            });
+          }
         }
       }
     });
@@ -125,17 +134,21 @@ PFA_DEV void hxw_exchange(cx<typename Cfg::T> (&v)[Cfg::bpt(P)][Cfg::Seq::r[P]],
     sfor<0, BPT1>([&](auto i_) PFA_LAMBDA {
       constexpr int i = decltype(i_)::value;
       const unsigned j = tid + i * Cfg::TPF;
-      if constexpr (pad_is_linear<Cfg>(NB1, R1, 1)) {
-        const cx<typename Cfg::T>* p = img + lds_pad<Cfg>(j);
-        sfor<h * (R1 / 2), (h + 1) * (R1 / 2)>([&](auto t_) PFA_LAMBDA {
-          constexpr int t = decltype(t_)::value;
-          n[i][t] = p[(t - h * (R1 / 2)) * pad_step<Cfg>(NB1)];
-        });
-      } else {
-        sfor<h * (R1 / 2), (h + 1) * (R1 / 2)>([&](auto t_) PFA_LAMBDA {
-          constexpr int t = decltype(t_)::value;
-          n[i][t] = img[lds_pad<Cfg>(j + t * NB1 - h * HALF)];
-        });
+      constexpr bool ragged1 = (NB1 % Cfg::TPF) != 0;
+      if (!ragged1 || j < NB1) {
+        constexpr int t0 = h == 0 ? 0 : HL, t1 = h == 0 ? HL : R1;
+        if constexpr (pad_is_linear<Cfg>(NB1, R1, 1)) {
+          const cx<typename Cfg::T>* p = img + lds_pad<Cfg>(j);
+          sfor<t0, t1>([&](auto t_) PFA_LAMBDA {
+            constexpr int t = decltype(t_)::value;
+            n[i][t] = p[(t - t0) * pad_step<Cfg>(NB1)];
+          });
+        } else {
+          sfor<t0, t1>([&](auto t_) PFA_LAMBDA {
+            constexpr int t = decltype(t_)::value;
+            n[i][t] = img[lds_pad<Cfg>(j + (t - t0) * NB1)];
+          });
+        }
       }
     });
     __syncthreads();
@@ -149,25 +162,30 @@ PFA_DEV void hxw_passes(cx<typename Cfg::T> (&v)[Cfg::bpt(P)][Cfg::Seq::r[P]], c
   using T = typename Cfg::T;
   using Seq = typename Cfg::Seq;
   constexpr int R = Seq::r[P], Ns = Seq::ns(P);
+  constexpr bool ragged = ((Cfg::N / R) % Cfg::TPF) != 0;
   sfor<0, Cfg::bpt(P)>([&](auto i_) PFA_LAMBDA {
     constexpr int i = decltype(i_)::value;
     const unsigned j = tid + i * Cfg::TPF;
-    if constexpr (P != 0) hxw_twiddle<Cfg, P>(v[i], j % Ns, twl, tw);
-    dft<R>(v[i]);
+    if (!ragged || j < Cfg::N / R) {
+      if constexpr (P != 0) hxw_twiddle<Cfg, P>(v[i], j % Ns, twl, tw);
+      dft<R>(v[i]);
+    }
   });
   if constexpr (P == Cfg::NP - 1) {
     sfor<0, Cfg::bpt(P)>([&](auto i_) PFA_LAMBDA {
       constexpr int i = decltype(i_)::value;
       const unsigned j = tid + i * Cfg::TPF;
       const unsigned base = (j / Ns) * (Ns * R) + j % Ns;
-      sfor<0, R>([&](auto u_) PFA_LAMBDA {
-        constexpr int u = decltype(u_)::value;
-        cx<T> y = v[i][u];
-        if constexpr (BWD) y.im = -y.im;
-        y.re *= scale;
-        y.im *= scale;
-        io.store(y, io.out_off(0, base), io.out_step(u * Ns));
-      });
+      if (!ragged || j < Cfg::N / R) {
+        sfor<0, R>([&](auto u_) PFA_LAMBDA {
+          constexpr int u = decltype(u_)::value;
+          cx<T> y = v[i][u];
+          if constexpr (BWD) y.im = -y.im;
+          y.re *= scale;
+          y.im *= scale;
+          io.store(y, io.out_off(0, base), io.out_step(u * Ns));
+        });
+      }
     });
   } else {
     cx<T> n[Cfg::bpt(P + 1)][Seq::r[P + 1]];

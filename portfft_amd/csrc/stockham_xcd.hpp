@@ -3,7 +3,7 @@
 //
 // Role in the reference: the GLOBAL tier (/root/reference/src/portfft/dispatcher/global_dispatcher.hpp:343-408) runs one
 // kernel per factor and keeps `num_batches_in_l2` transforms in flight so that the intermediate stays in the last-level
-// cache (committed_descriptor_impl.hpp:603-611).  The two-launch plan of this library (plan.cpp, plan_global) does the
+// cache (committed_descriptor_impl.hpp:603-611).  The two-launch plan of this library (plan_global.cpp, plan_global) does the
 // same through the 256 MiB Infinity Cache: every byte crosses the XCD <-> memory fabric four times and a plain copy
 // pair of the stages' access shapes tops out at 0.41-0.435 of the HBM peak (profiles/r3_ic_yardstick.txt).  Here a byte
 // crosses it twice.  Design (ours, MI355X-specific):

@@ -1,5 +1,6 @@
 // Runtime-specialisation planner (portfft_amd/csrc/jit.cpp) on the host: invariants of the chosen kernel
 // parameters for every length, and hiprtc compilation of a few of them for gfx950 (no device needed).
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <string>
@@ -65,7 +66,7 @@ int main(int argc, char** argv) {
         EXPECT(q.wg >= 64 && q.wg <= 1024 && q.wg % q.fpw == 0, "strided n=%lld wg=%d fpw=%d", n, q.wg, q.fpw);
         EXPECT(static_cast<size_t>(n) * q.fpw * es <= 128 * 1024, "strided n=%lld lds", n);
       }
-      // a requested group width (four-step half pairs, plan.cpp) is honoured exactly or refused
+      // a requested group width (four-step half pairs, plan_global.cpp) is honoured exactly or refused
       for (int want : {8, 16}) {
         pfa::wg_params w;
         if (n > 32 && pfa::choose_strided_params(prec, n, 1024, max_lds, &w, false, want)) {
@@ -107,7 +108,50 @@ int main(int argc, char** argv) {
     EXPECT(pfa::choose_rows2d_params(prec, 1000, 3000, max_lds, &q, 4) && q.fpw == 4, "rows2d 3000 x 1000, mask 4");
     EXPECT(!pfa::choose_rows2d_params(prec, 1000, 3000, max_lds, &q, 8), "rows2d 3000 x 1000: no radix-8 plan");
   }
+  // register-resident packed kernel (stockham_wg_hx.hpp): lengths beyond the LDS whose transform fits the registers of one
+  // work-group -- invariants of every plan the planner hands out
+  {
+    long long planned_hx[2] = {0, 0};
+    for (int prec = 0; prec < 2; ++prec) {
+      const int es = prec ? 16 : 8;
+      for (long long n = (prec ? 10241 : 20481); n <= (prec ? 21000 : 42000); ++n) {
+        pfa::wg_params p;
+        if (!pfa::choose_hx_params(prec, n, max_lds, &p)) continue;
+        ++planned_hx[prec];
+        long long prod = 1;
+        int regs = 0;
+        for (int r : p.radices) {
+          prod *= r;
+          EXPECT(r >= 2 && r <= 32, "hx n=%lld radix %d", n, r);
+          regs = std::max<int>(regs, static_cast<int>((n / r + p.wg - 1) / p.wg) * r);
+        }
+        EXPECT(prod == n && p.radices.size() >= 2 && p.radices.size() <= 4, "hx n=%lld radices", n);
+        EXPECT(p.fpw == 1 && p.staged == 0 && p.wg % 64 == 0 && p.wg >= 512 && p.wg <= 1024, "hx n=%lld lanes %d", n, p.wg);
+        EXPECT(pfa::hx_lds_bytes(p) <= max_lds && static_cast<size_t>(n) * es > max_lds, "hx n=%lld LDS", n);
+        const int budget = 512 / ((p.wg / 64 + 3) / 4);
+        EXPECT(regs * (prec ? 4 : 2) < budget && p.regs == regs, "hx n=%lld: %d elements per lane of %d lanes", n, regs, p.wg);
+      }
+    }
+    std::printf("hx planner: %lld fp32 and %lld fp64 lengths\n", planned_hx[0], planned_hx[1]);
+    EXPECT(planned_hx[0] > 300 && planned_hx[1] > 150, "hx planner coverage");
+    pfa::wg_params p;
+    EXPECT(!pfa::choose_hx_params(0, 20480, max_lds, &p), "20480 fits the LDS: the packed planner's");
+    EXPECT(!pfa::choose_hx_params(0, 65536, max_lds, &p), "65536 does not fit the registers");
+    EXPECT(pfa::choose_hx_params(0, 32768, max_lds, &p) && p.radices.size() == 3, "fp32 32768 in three passes");
+    EXPECT(pfa::choose_hx_params(1, 16384, max_lds, &p) && p.radices.size() <= 4, "fp64 16384");
+  }
   if (argc > 1 && std::string(argv[1]) == "compile") {
+    for (auto c : std::vector<std::pair<int, long long>>{{0, 24576}, {0, 30000}, {1, 12000}, {1, 20000}}) {
+      pfa::wg_params q;
+      EXPECT(pfa::choose_hx_params(c.first, c.second, max_lds, &q), "hx plan %lld", c.second);
+      for (int kind : {8, 9}) {
+        size_t bytes = 0;
+        std::string why;
+        const bool built = pfa::jit_compile_only(q, kind, "gfx950", &bytes, &why);
+        EXPECT(built && bytes > 1000, "hiprtc hx n=%lld kind=%d: %s", c.second, kind, why.c_str());
+        std::printf("hiprtc n=%lld kind=%d %s: %zu bytes\n", c.second, kind, pfa::wg_cfg_type_name(q).c_str(), bytes);
+      }
+    }
     struct { int prec; long long n; int kind; } cases[] = {{0, 1200, 0}, {1, 625, 1}, {0, 30, 0}, {0, 120, 2}, {1, 250, 3},
                                                             {0, 1000, 4}, {1, 768, 4},
                                                             // forms of the three-stage / tiled plans that exist only at run time

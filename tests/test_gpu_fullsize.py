@@ -403,7 +403,7 @@ def test_four_step_stage_pairs_and_split_storage():
 
 @pytest.mark.gpu
 def test_three_stage_plan_for_very_long_transforms():
-    """N > 2^22 (plan.cpp plan_three_stage): N = n1 * n2 * n3, the four-step applied twice -- S1 in place on the user's
+    """N > 2^22 (plan_global.cpp plan_three_stage): N = n1 * n2 * n3, the four-step applied twice -- S1 in place on the user's
     output buffer, S2 into tiles of the scratch, S3 (tiled-input stage B of n3 = 1024) to X[k1 + n1 k2 + n1 n2 k3];
     S2 / S3 chunk by chunk.  Factors through the plan info; against NumPy, round trip, in-place execution, a ragged last
     chunk, and the two-stage plan of the same descriptor (PFFT_NO_THREE_STAGE=1).  Also forced on a shorter length
@@ -539,7 +539,7 @@ def test_three_stage_plan_split_storage():
 
 @pytest.mark.gpu
 def test_four_step_half_pairs_and_split_choice():
-    """Four-step lengths k * 2^m (plan.cpp, half pairs): the split takes a registered stage-B length (1024 / 512 / 256)
+    """Four-step lengths k * 2^m (plan_global.cpp, half pairs): the split takes a registered stage-B length (1024 / 512 / 256)
     as n2 and a SHORT runtime-specialised stage A of the same group width as n1 -- factors checked through the plan
     info --, the intermediate is group-major and stage B reads it in its tiled-input form (fp64: carrying the
     inter-stage twiddles on its loads).  Against NumPy on sampled transforms, round trip, and against the round's

@@ -365,11 +365,20 @@ def test_offsets(prec):
                 out_off = bo if direction == F else fo
                 if place == 1:
                     assert np.all(raw[:out_off] == H.PADDING_VALUE), "padding before the offset was written"
-    # OffsetsWIErrorRegressionTest / OffsetsMDErrorRegressionTest
+    # OffsetsWIErrorRegressionTest (:204-209): all_valid_oop_placement_layouts x both_directions x mismatched_offsets at
+    # batch 33000 -- the whole 4 x 2 x 3 grid
     x, y = H.gen_fourier_data(33000, [8], dtype)
-    d = G.make_descriptor([8], prec, batch=33000, fwd_offset=2047, bwd_offset=2049)
-    got, _ = G.transform_packed(d, pf.direction.FORWARD, x)
-    _check(got, y, 8, dtype, "offsets wi")
+    for (fo, bo) in [(0, 2049), (2049, 0), (2047, 2049)]:
+        for direction in (F, B):
+            for lin, lout in (("P", "P"), ("P", "BI"), ("BI", "BI"), ("BI", "P")):
+                d = _layout_desc(G, 8, prec, 33000, 1, lin, lout, direction, 0)
+                d.forward_offset, d.backward_offset = fo, bo
+                src, ref = (x, y) if direction == F else (y, x.astype(np.complex128) * 8)
+                got, raw = G.transform_packed(d, pf.direction(direction), src)
+                _check(got, ref, 8, dtype, ("offsets wi", fo, bo, direction, lin, lout))
+                out_off = bo if direction == F else fo
+                assert np.all(raw[:out_off] == H.PADDING_VALUE), "padding before the offset was written"
+    # OffsetsMDErrorRegressionTest
     x, y = H.gen_fourier_data(2, [4, 4], dtype)
     d = G.make_descriptor([4, 4], prec, batch=2, fwd_offset=2, bwd_offset=0)
     got, _ = G.transform_packed(d, pf.direction.FORWARD, x)
@@ -415,7 +424,9 @@ def test_strided_layouts(prec):
              [(c, (1, 3, 33000), 0) for c in H.STRIDED_IP_CASES] +
              [(([3], [66], [66], 2, 2), (1, 3, 33), 0), (([6], [40], [40], 1, 1), (1, 3, 33), 0),
               (([75], [66], [66], 2, 2), (1, 3, 33), 0), (([96], [40], [40], 1, 1), (1, 3, 33), 0),
-              (([8], [2], [2], 2, 2), (1,), 1), (([8], [1], [1], 1, 1), (1,), 0),
+              # StridedStrideEqualsDistance is all_unpacked_unpacked_layout: both layouts in BOTH placements (:296-301)
+              (([8], [2], [2], 2, 2), (1,), 1), (([8], [2], [2], 2, 2), (1,), 0),
+              (([8], [1], [1], 1, 1), (1,), 1), (([8], [1], [1], 1, 1), (1,), 0),
               (([4], [4], [4], 3, 3), (4,), 1), (([85], [13], [13], 12, 12), (13,), 0)])
     for (lengths, fs, bs, fd, bd), batches, place in cases:
         n = lengths[0]

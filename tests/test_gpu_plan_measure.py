@@ -1,4 +1,4 @@
-"""Opt-in measured planning (PFFT_PLAN_MEASURE=1; plan.cpp measured_radices, jit.cpp spec_radix_candidates): the radix
+"""Opt-in measured planning (PFFT_PLAN_MEASURE=1; plan_global.cpp measured_radices, jit.cpp spec_radix_candidates): the radix
 sequence of a runtime-specialised packed length is timed at commit and recorded in the JIT cache directory.  The
 reference's rule is static (src/portfft/committed_descriptor_impl.hpp:210-313); with the knob off nothing changes.
 Every case runs in a process of its own: the kernel and choice tables are per process."""
@@ -74,14 +74,15 @@ def test_measured_choice_is_recorded_and_honoured(tmp_path):
 
 
 def test_measured_four_step_split_is_recorded_and_honoured(tmp_path):
-    """plan.cpp measured_split: the n1 x n2 of a GLOBAL-tier length without a registered stage pair"""
+    """plan_global.cpp measured_split: the n1 x n2 of a GLOBAL-tier length without a registered stage pair"""
     n = 30000
     static, _ = _commit(n, tmp_path / "a", measure=False, prec="f64")
     assert static[0] * static[1] == n
     measured, log = _commit(n, tmp_path / "b", measure=True, verbose=True, prec="f64")
     assert log.count("[portfft_amd plan] n=%d split" % n) >= 4, "the candidates were timed: " + log[-400:]
-    record = tmp_path / "b" / ("choice_gfx950_f64_%d.txt" % n)
+    record = tmp_path / "b" / ("choice_split_gfx950_f64_%d.txt" % n)
     assert record.exists() and [int(v) for v in record.read_text().split()] == measured[:2]
+    assert not (tmp_path / "b" / ("choice_gfx950_f64_%d.txt" % n)).exists(), "split records are kept apart from radix records"
     again, log2 = _commit(n, tmp_path / "b", measure=True, verbose=True, prec="f64")
     assert again == measured and "split" not in log2, log2[-400:]
     off, _ = _commit(n, tmp_path / "b", measure=False, prec="f64")
@@ -89,7 +90,7 @@ def test_measured_four_step_split_is_recorded_and_honoured(tmp_path):
     # a hand-written record is honoured; one whose product is another length is not
     d = tmp_path / "c"
     d.mkdir(mode=0o700)
-    rec = d / ("choice_gfx950_f64_%d.txt" % n)
+    rec = d / ("choice_split_gfx950_f64_%d.txt" % n)
     rec.write_text("120 250\n")
     rec.chmod(0o600)
     forced, _ = _commit(n, d, measure=True, prec="f64")

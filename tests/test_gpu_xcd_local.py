@@ -1,5 +1,5 @@
-"""The XCD-local single-launch four-step plan (portfft_amd/csrc/stockham_xcd.hpp, plan.cpp plan_xcd_local) through the
-C ABI on an MI355X: fp32 N = 2^16 ... 2^20 and fp64 N = 2^16, 2^17, 2^18, 2^20 (kernels_xcd.hip), the reference's
+"""The XCD-local single-launch four-step plan (portfft_amd/csrc/stockham_xcd.hpp, plan_global.cpp plan_xcd_local) through the
+C ABI on an MI355X: fp32 N = 2^16 ... 2^20 and fp64 N = 2^16 ... 2^19 (kernels_xcd.hip), the reference's
 GLOBAL-tier size range
 (ref: test/unit_test/instantiate_fft_tests.hpp:147-151, src/portfft/dispatcher/global_dispatcher.hpp:343-408).
 

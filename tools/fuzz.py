@@ -55,7 +55,7 @@ def main():
             rank = 1
             dims = [rng.choice([1 << 15, 1 << 16, 1 << 17, 1 << 18, 1 << 19, 1 << 20, 1 << 21, 3 << 15, 5 << 14, 3 << 17,
                                 6 << 15, 10 << 13, 100000, 1000000, 60000, 37 << 12, 61 << 10, 9 * 5 * 7 * 11 * 13 * 16, 49152,
-                                # k * 2^m: a registered stage B behind a runtime-specialised stage A (plan.cpp, half pairs)
+                                # k * 2^m: a registered stage B behind a runtime-specialised stage A (plan_global.cpp, half pairs)
                                 3 << 13, 5 << 13, 7 << 14, 3 << 16, 5 << 15, 9 << 16, 15 << 15, 11 << 13, 3 << 18,
                                 5 << 17, 3 << 20, 12288, 20480, 13 << 12, 25 << 12, 3 << 19, 5 << 18,
                                 1 << 23, 3 << 22])]  # (three-stage plan)

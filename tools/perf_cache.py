@@ -1,4 +1,4 @@
-"""Cache-sized chunks + writer/reader cache policies (plan.cpp cache_chunk_bytes) against everything-streamed, random
+"""Cache-sized chunks + writer/reader cache policies (plan_core.cpp cache_chunk_bytes) against everything-streamed, random
 data, through the library: small and large batches of the two-launch plans.  Each case runs in a child process with
 PFFT_CACHE_CHUNK_MIB unset (256) / 0 / other values."""
 import os, subprocess, sys

@@ -3,7 +3,8 @@
 # (counters alone with --kernel-trace: the guide's recipe), per-kernel means + the derived figures the question needs:
 #   VALU issue utilisation = SQ_ACTIVE_INST_VALU / SQ_BUSY_CU_CYCLES-equivalent, waves per SIMD, wait shares, LDS conflicts,
 #   registers / scratch / LDS from the kernel trace.
-#   tools/pmc_arith.sh <outdir>
+#   tools/pmc_arith.sh <outdir>                                  the round-4 set
+#   tools/pmc_arith.sh <outdir> tag n batch prec [tag n batch prec ...]   other descriptors
 set -u
 out=$1; mkdir -p "$out"
 export TMPDIR=/tmp PFFT_JIT_CACHE_DIR=/tmp/pmc_arith_cache
@@ -20,6 +21,11 @@ run_case() {  # tag n batch prec
   cat "$out/$tag.txt"
   rm -rf "$out/$tag"
 }
+if [ $# -ge 5 ]; then  # cases on the command line: <outdir> tag n batch prec [tag n batch prec ...]
+  shift
+  while [ $# -ge 4 ]; do run_case "$1" "$2" "$3" "$4"; shift 4; done
+  exit 0
+fi
 run_case f32_1e6 1000000 128 f32
 run_case f32_62500 62500 2048 f32
 run_case f32_30000 30000 4096 f32

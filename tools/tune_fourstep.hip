@@ -130,7 +130,7 @@ template <typename Cfg, int KIND> void addA(const char* name, bool tiled, int gp
 template <typename Cfg, int KIND> void addB(const char* name, bool tiled, int gpw, size_t x = 0) { add<Cfg, KIND, false>(name, tiled, gpw, x); }
 
 static int g_cus = 256;
-static unsigned grid_of(const variant& v, long long groups) {  // plan.cpp persistent_grid
+static unsigned grid_of(const variant& v, long long groups) {  // plan_core.cpp persistent_grid
   int per_cu = 0; CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, v.fn, v.wg, v.lds));
   per_cu = std::max(per_cu, 1);
   const long long resident = (long long)per_cu * g_cus;
@@ -139,7 +139,7 @@ static unsigned grid_of(const variant& v, long long groups) {  // plan.cpp persi
   return (unsigned)std::max<long long>(1, grid);
 }
 
-// strided_args of the two stages for `nb` transforms starting at user transform b0 (plan.cpp plan_global)
+// strided_args of the two stages for `nb` transforms starting at user transform b0 (plan_global.cpp plan_global)
 static strided_args args_a(const variant& v, const T* in, T* scratch, long long nb, int t_layout) {
   strided_args a{};
   a.in = in; a.out = scratch; a.tw = v.tw; a.total = nb * N2; a.inner = N2;
@@ -210,7 +210,7 @@ int main() {
   CK(hipMalloc(&in, total * sizeof(T))); CK(hipMalloc(&out, total * sizeof(T))); CK(hipMalloc(&scratch, (size_t)256 << 20));
   fill_uniform<<<4096, 256>>>(in, total, 7);
   CK(hipDeviceSynchronize());
-  {  // store-modifier tables (plan.cpp store_table_shape: fewest levels within 16 KiB)
+  {  // store-modifier tables (plan_core.cpp store_table_shape: fewest levels within 16 KiB)
     int bits = 0; while ((1ll << bits) < N) ++bits;
     for (int l = 1; l <= 4; ++l) {
       const int sh = (bits + l - 1) / l;
