@@ -133,9 +133,13 @@ PFA_DEV void hxw_exchange(cx<typename Cfg::T> (&v)[Cfg::bpt(P)][Cfg::Seq::r[P]],
     __syncthreads();
     sfor<0, BPT1>([&](auto i_) PFA_LAMBDA {
       constexpr int i = decltype(i_)::value;
-      const unsigned j = tid + i * Cfg::TPF;
-      constexpr bool ragged1 = (NB1 % Cfg::TPF) != 0;
-      if (!ragged1 || j < NB1) {
+      // (a slot that runs past the last butterfly reads butterfly NB1 - 1 again instead of being predicated: straight-line
+      //  code -- a predicated read of 16 values into live registers made the allocator keep both versions; slots wholly
+      //  past the end read nothing)
+      constexpr bool none1 = i * Cfg::TPF >= NB1, all1 = (i + 1) * Cfg::TPF <= NB1;
+      if constexpr (!none1) {
+        unsigned j = tid + i * Cfg::TPF;
+        if constexpr (!all1) j = j < static_cast<unsigned>(NB1) ? j : static_cast<unsigned>(NB1 - 1);
         constexpr int t0 = h == 0 ? 0 : HL, t1 = h == 0 ? HL : R1;
         if constexpr (pad_is_linear<Cfg>(NB1, R1, 1)) {
           const cx<typename Cfg::T>* p = img + lds_pad<Cfg>(j);
@@ -162,28 +166,32 @@ PFA_DEV void hxw_passes(cx<typename Cfg::T> (&v)[Cfg::bpt(P)][Cfg::Seq::r[P]], c
   using T = typename Cfg::T;
   using Seq = typename Cfg::Seq;
   constexpr int R = Seq::r[P], Ns = Seq::ns(P);
-  constexpr bool ragged = ((Cfg::N / R) % Cfg::TPF) != 0;
   sfor<0, Cfg::bpt(P)>([&](auto i_) PFA_LAMBDA {
     constexpr int i = decltype(i_)::value;
     const unsigned j = tid + i * Cfg::TPF;
-    if (!ragged || j < Cfg::N / R) {
-      if constexpr (P != 0) hxw_twiddle<Cfg, P>(v[i], j % Ns, twl, tw);
-      dft<R>(v[i]);
-    }
+    // (no `j < NB` around the arithmetic of a ragged pass: the idle lanes compute on whatever their registers hold --
+    //  their table addresses are valid, nothing of theirs is written -- and the butterflies stay straight-line code; a
+    //  predicated in-place update kept both versions of the lane's 30-60 values alive: 30.10.10.10 on 1024 lanes spilled
+    //  176 registers, on 1000 lanes none)
+    if constexpr (P != 0) hxw_twiddle<Cfg, P>(v[i], j % Ns, twl, tw);
+    dft<R>(v[i]);
   });
   if constexpr (P == Cfg::NP - 1) {
     sfor<0, Cfg::bpt(P)>([&](auto i_) PFA_LAMBDA {
       constexpr int i = decltype(i_)::value;
       const unsigned j = tid + i * Cfg::TPF;
       const unsigned base = (j / Ns) * (Ns * R) + j % Ns;
-      if (!ragged || j < Cfg::N / R) {
+      constexpr bool none_s = i * Cfg::TPF >= Cfg::N / R, all_s = (i + 1) * Cfg::TPF <= Cfg::N / R;
+      if constexpr (!none_s) {
+        // (the lanes of a slot that runs past the last butterfly store out of the buffer's range: dropped by the hardware)
+        const unsigned voff = (all_s || j < static_cast<unsigned>(Cfg::N / R)) ? io.out_off(0, base) : 0xFFFFFFF0u;
         sfor<0, R>([&](auto u_) PFA_LAMBDA {
           constexpr int u = decltype(u_)::value;
           cx<T> y = v[i][u];
           if constexpr (BWD) y.im = -y.im;
           y.re *= scale;
           y.im *= scale;
-          io.store(y, io.out_off(0, base), io.out_step(u * Ns));
+          io.store(y, voff, io.out_step(u * Ns));
         });
       }
     });
@@ -192,6 +200,27 @@ PFA_DEV void hxw_passes(cx<typename Cfg::T> (&v)[Cfg::bpt(P)][Cfg::Seq::r[P]], c
     hxw_exchange<Cfg, P>(v, n, tid, img);
     hxw_passes<Cfg, BWD, P + 1>(n, io, tid, img, twl, tw, scale);
   }
+}
+
+/// pass 0's loads; the lanes of a slot past the last butterfly read out of the buffer's range (zeros), unpredicated
+template <typename Cfg, bool BWD, typename IO>
+PFA_DEV void hxw_load(const IO& io, unsigned tid, cx<typename Cfg::T> (&v)[Cfg::bpt(0)][Cfg::Seq::r[0]]) {
+  using T = typename Cfg::T;
+  constexpr int R = Cfg::Seq::r[0], NB = Cfg::N / R;
+  sfor<0, Cfg::bpt(0)>([&](auto i_) PFA_LAMBDA {
+    constexpr int i = decltype(i_)::value;
+    const unsigned j = tid + i * Cfg::TPF;
+    constexpr bool none = i * Cfg::TPF >= NB, all = (i + 1) * Cfg::TPF <= NB;
+    if constexpr (!none) {
+      const unsigned voff = (all || j < static_cast<unsigned>(NB)) ? io.in_off(0, j) : 0xFFFFFFF0u;
+      sfor<0, R>([&](auto t_) PFA_LAMBDA {
+        constexpr int t = decltype(t_)::value;
+        cx<T> x = io.load(voff, io.in_step(t * NB));
+        if constexpr (BWD) x.im = -x.im;
+        v[i][t] = x;
+      });
+    }
+  });
 }
 
 /// Body shared by the interleaved and the split-storage kernels (`make_io(g)`: the transform's I/O object)
@@ -211,7 +240,7 @@ PFA_DEV void stockham_wg_hx_body(MakeIO&& make_io, const cx<typename Cfg::T>* __
   for (long long g = blockIdx.x; g < nfft; g += gridDim.x) {
     const auto io = make_io(g);
     cx<T> v[Cfg::bpt(0)][Cfg::Seq::r[0]];
-    wg_pass0_load<Cfg, BWD>(io, 0, static_cast<int>(tid), v);
+    hxw_load<Cfg, BWD>(io, tid, v);
     const cx<T>* twp = tw;
     asm volatile("" : "+s"(twp));  // keep the table reads inside the loop (see stockham_wg_body)
     hxw_passes<Cfg, BWD, 0>(v, io, tid, img, twl, twp, scale);

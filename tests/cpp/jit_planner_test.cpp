@@ -112,9 +112,10 @@ int main(int argc, char** argv) {
   // work-group -- invariants of every plan the planner hands out
   {
     long long planned_hx[2] = {0, 0};
+    pfa::wg_params p0;
     for (int prec = 0; prec < 2; ++prec) {
       const int es = prec ? 16 : 8;
-      for (long long n = (prec ? 10241 : 20481); n <= (prec ? 21000 : 42000); ++n) {
+      for (long long n = (prec ? 10241 : 19000); n <= (prec ? 21000 : 42000); ++n) {
         pfa::wg_params p;
         if (!pfa::choose_hx_params(prec, n, max_lds, &p)) continue;
         ++planned_hx[prec];
@@ -127,21 +128,24 @@ int main(int argc, char** argv) {
         }
         EXPECT(prod == n && p.radices.size() >= 2 && p.radices.size() <= 4, "hx n=%lld radices", n);
         EXPECT(p.fpw == 1 && p.staged == 0 && p.wg % 64 == 0 && p.wg >= 512 && p.wg <= 1024, "hx n=%lld lanes %d", n, p.wg);
-        EXPECT(pfa::hx_lds_bytes(p) <= max_lds && static_cast<size_t>(n) * es > max_lds, "hx n=%lld LDS", n);
+        EXPECT(pfa::hx_lds_bytes(p) <= max_lds && static_cast<size_t>(n) * es > 152 * 1024, "hx n=%lld LDS", n);
         const int budget = 512 / ((p.wg / 64 + 3) / 4);
         EXPECT(regs * (prec ? 4 : 2) < budget && p.regs == regs, "hx n=%lld: %d elements per lane of %d lanes", n, regs, p.wg);
       }
     }
     std::printf("hx planner: %lld fp32 and %lld fp64 lengths\n", planned_hx[0], planned_hx[1]);
     EXPECT(planned_hx[0] > 300 && planned_hx[1] > 150, "hx planner coverage");
+    EXPECT(!pfa::choose_hx_params(0, 40960, max_lds, &p0) , "40960: 80 values per lane do not pay");
     pfa::wg_params p;
-    EXPECT(!pfa::choose_hx_params(0, 20480, max_lds, &p), "20480 fits the LDS: the packed planner's");
+    EXPECT(!pfa::choose_hx_params(0, 16384, max_lds, &p), "16384 fits the LDS: the packed planner's");
+    EXPECT(pfa::choose_hx_params(0, 20480, max_lds, &p), "fp32 20480: the top of the LDS range goes register-resident");
+    EXPECT(!pfa::choose_hx_params(1, 10240, max_lds, &p), "fp64 10240 stays LDS-resident");
     EXPECT(!pfa::choose_hx_params(0, 65536, max_lds, &p), "65536 does not fit the registers");
     EXPECT(pfa::choose_hx_params(0, 32768, max_lds, &p) && p.radices.size() == 3, "fp32 32768 in three passes");
     EXPECT(pfa::choose_hx_params(1, 16384, max_lds, &p) && p.radices.size() <= 4, "fp64 16384");
   }
   if (argc > 1 && std::string(argv[1]) == "compile") {
-    for (auto c : std::vector<std::pair<int, long long>>{{0, 24576}, {0, 30000}, {1, 12000}, {1, 20000}}) {
+    for (auto c : std::vector<std::pair<int, long long>>{{0, 24576}, {0, 30000}, {1, 12000}, {1, 15000}}) {
       pfa::wg_params q;
       EXPECT(pfa::choose_hx_params(c.first, c.second, max_lds, &q), "hx plan %lld", c.second);
       for (int kind : {8, 9}) {

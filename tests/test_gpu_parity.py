@@ -571,11 +571,12 @@ def test_fused_multidimensional():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("prec,n", [("f32", 32768), ("f64", 16384)])
+@pytest.mark.parametrize("prec,n", [("f32", 32768), ("f64", 16384), ("f32", 24576), ("f32", 30000), ("f64", 12000), ("f64", 15000)])
 def test_register_resident_lengths(prec, n):
     """The 256 KiB transforms that stay in the registers of one work-group for all their passes, one HBM pass
     (stockham_wg_hx.hpp): fp32 32768, the reference's first GlobalTest size, and fp64 16384, its largest
-    WorkgroupOrGlobal size (instantiate_fft_tests.hpp:140-151).  Against NumPy on every layout the packed kernels
+    WorkgroupOrGlobal size (instantiate_fft_tests.hpp:140-151) -- registered kernels -- and lengths whose kernel is planned
+    (jit.cpp choose_hx_params: any radices, ragged passes) and compiled at commit.  Against NumPy on every layout the packed kernels
     serve -- both placements, both storages, both directions, offsets and scales, ragged batches -- and against the
     four-step plan of the same descriptor (PFFT_NO_REGRES=1), which is another algorithm: equal within the tolerance."""
     import gpu_utils as G

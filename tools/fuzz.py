@@ -1,9 +1,11 @@
 """Random descriptors against NumPy: rank, lengths (61-smooth), batch, layout (packed / batch-interleaved / unpacked rows /
-strided), storage, placement, offsets, scales, precision, direction.  usage: fuzz.py [seed] [iterations] [big2d|global]
+strided), storage, placement, offsets, scales, precision, direction.  usage: fuzz.py [seed] [iterations] [big2d|global|regres]
 With `big2d` the shapes are 2-D / 3-D with a long last dimension (256...2048): the two-pass 2-D plan
 (stockham_rows2d.hpp) and its fall-backs.  With `global` the lengths are four-step (GLOBAL tier) sizes: powers of two
 2^15 ... 2^21 (the registered stage pairs), 3 / 5 / 6 / 10 times powers of two, powers of ten, lengths with a prime factor
-37 ... 61 -- packed, both storages, both placements."""
+37 ... 61 -- packed, both storages, both placements.  With `regres` the lengths are 31-smooth and lie just beyond one
+work-group's LDS (fp32 20481 ... 40000, fp64 10241 ... 20000): the register-resident kernel (stockham_wg_hx.hpp) with
+whatever radices and lanes its planner picks, or the four-step plan where it declines."""
 import os, sys, random
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
@@ -40,6 +42,7 @@ def main():
     iters = int(sys.argv[2]) if len(sys.argv) > 2 else 200
     big2d = len(sys.argv) > 3 and sys.argv[3] == "big2d"
     glob = len(sys.argv) > 3 and sys.argv[3] == "global"
+    regres = len(sys.argv) > 3 and sys.argv[3] == "regres"
     rng = random.Random(seed)
     fails = 0
     for it in range(iters):
@@ -51,6 +54,16 @@ def main():
             last = rng.choice([256, 512, 1024, 2048, 1000, 768])
             mid = rng.choice([8, 16, 24, 40, 64, 96, 128, 250, 256, 512, 1024, 1500, 3000, 2560])
             dims = ([rng.choice([2, 3, 5, 8])] if rank == 3 else []) + [mid, last]
+        elif regres:
+            rank = 1
+            lo, hi = (20481, 40000) if prec == "f32" else (10241, 20000)
+            while True:
+                n = 1
+                while n < lo:
+                    n *= rng.choice([2, 2, 2, 2, 3, 3, 5, 5, 7, 11, 13, 17, 19, 23, 29, 31])
+                if n <= hi:
+                    break
+            dims = [n]
         elif glob:
             rank = 1
             dims = [rng.choice([1 << 15, 1 << 16, 1 << 17, 1 << 18, 1 << 19, 1 << 20, 1 << 21, 3 << 15, 5 << 14, 3 << 17,
@@ -66,12 +79,12 @@ def main():
         n = int(np.prod(dims))
         batch = rng.choice([1, 2, 3, 7, 16, 33, 100])
         if n * batch > 4_000_000:
-            batch = max(1, (8_000_000 if (big2d or glob) else 4_000_000) // n)
+            batch = max(1, (8_000_000 if (big2d or glob or regres) else 4_000_000) // n)
         storage = rng.choice([0, 0, 1])
         kw = {}
         place = rng.choice([0, 1])
         layout = "P"
-        if rank == 1 and not glob:
+        if rank == 1 and not glob and not regres:
             layout = rng.choice(["P", "P", "BI", "ROWS", "STR", "PBI", "BIP"])
             if layout == "BI":
                 kw = dict(fwd_strides=[batch], fwd_distance=1, bwd_strides=[batch], bwd_distance=1)
