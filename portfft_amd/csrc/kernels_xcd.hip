@@ -5,11 +5,11 @@
 //   fp32  2^16 256 x 256   0.41 / 0.38      fp64  2^16 256 x 256   0.46 / 0.34
 //         2^17 256 x 512   0.42 / 0.37            2^17 256 x 512   0.43 / 0.33
 //         2^18 512 x 512   0.42-0.44 / 0.35       2^18 512 x 512   0.41 / 0.32
-//         2^19 1024 x 512  0.38 / 0.33            2^19 512 x 1024  0.385 / 0.35
-//         2^20 1024 x 1024 0.38 / 0.32
+//         2^19 1024 x 512  0.38 / 0.33 (*)        2^19 512 x 1024  0.385 / 0.35 (*)
+//         2^20 1024 x 1024 0.38 / 0.32            (*) not registered since round 5: +1...4 % through the library
 // and through the library against the plan the two-launch planner takes (its own split, chunked to the Infinity Cache;
 // tools/probes/xcd_lib_ab*.sh): +6...12 % on fp32 2^16 / 2^17 / 2^18 / 2^20 and fp64 2^16 / 2^17 / 2^18 from 1 GiB of
-// data up, +1...4 % on the two 2^19 entries; below 0.5 GiB (0.75 GiB for fp32 2^16) the two launches win -- the
+// data up, +1...4 % on the two 2^19 pairs (hence not registered); below 0.5 GiB (0.75 GiB for fp32 2^16) the two launches win -- the
 // persistent launch has a fixed start-up of 20-30 us and the two-launch plan's data starts to fit the Infinity Cache.
 // Measured and NOT registered: fp32 2^15 (128 x 256: 0.34 against 0.38 -- 16...32 KiB tasks, the hand-off bookkeeping of
 // a task is a quarter of its time), fp64 2^20 (1024 x 1024, BASELINE configs[2]: 0.34-0.355 against 0.365).
@@ -88,15 +88,15 @@ std::vector<xcd_kernel> build() {
   v.push_back(make_xcd_entry<c256, c256, 4>(24, 12, 4, 768));  // four work-groups per CU
   v.push_back(make_xcd_entry<c256, c512, 4, 512>(24, 12, 4));  // two 256-lane stage-A groups side by side per task
   v.push_back(make_xcd_entry<c512, c512, 4>(12, 8, 4));
-  v.push_back(make_xcd_entry<c1024, c512, 4, 1024>(6, 4, 4));  // two 512-lane stage-B groups side by side per task
+  // (fp32 2^19 as 1024 x 512 -- two 512-lane stage-B groups side by side, schedule (6, 4) -- and fp64 2^19 as 512 x 1024 were
+  //  registered in round 4 for +1...4 % over the two-launch plan: inside the +-3 % box-to-box spread, and the recovery
+  //  launch's bookkeeping costs the single launch 1-2 %.  De-registered in round 5; tools/tune_xcd.hip cases 191 / 119 keep them.)
   v.push_back(make_xcd_entry<c1024, c1024, 4>(4, 2, 4));
   using d256 = strided_cfg<double, radix_list<16, 16>, 128, 8, 2, PFA_AUX_NT>;
   using d512 = strided_cfg<double, radix_list<8, 8, 8>, 512, 8, 2, PFA_AUX_NT>;
-  using d1024 = strided_cfg<double, radix_list<16, 8, 8>, 512, 8, 2, PFA_AUX_NT>;
   v.push_back(make_xcd_entry<d256, d256, 2, 512>(16, 8, 4));  // four 128-lane groups per task, one work-group per CU
   v.push_back(make_xcd_entry<d256, d512, 2, 512>(16, 8, 4));
   v.push_back(make_xcd_entry<d512, d512, 2, 1024>(4, 2, 4));  // two 512-lane groups per task
-  v.push_back(make_xcd_entry<d512, d1024, 2>(4, 2, 4));
   return v;
 }
 

@@ -171,6 +171,7 @@ struct plan_knobs {
   bool split_cached = true, pair_xcd = true, stop_event_on_launch = true, xcd_check = false;
   // overrides (unset: -1 / 0 / empty)
   int chunk_overlap = 2, jit_groups_per_wg = -1, groups_per_wg = 0, xcd_slots = 0, xcd_lag = 0;
+  int row_in_max_n = 512;  // PFFT_ROW_IN_MAX_N: longest stage whose row-shaped INPUT is staged through LDS
   bool groups_per_wg_set = false, global_chunk_mib_set = false, cache_chunk_mib_set = false;
   long global_chunk_mib = 0, cache_chunk_mib = 0;
   long long global_n1 = 0, three_stage_min = 0, three_stage_n3 = 0, xcd_min_batch = -1, xcd_max_iters = -1;

@@ -151,6 +151,8 @@ plan_knobs plan_knobs::from_env() {
     k.cache_chunk_mib = std::atol(e);
   }
   mark(k.cache_chunk_mib_set);
+  if (const char* e = set("PFFT_ROW_IN_MAX_N")) k.row_in_max_n = std::atoi(e);
+  mark(k.row_in_max_n != 512);
   if (const char* e = set("PFFT_THREE_STAGE_MIN")) k.three_stage_min = std::atoll(e);
   mark(k.three_stage_min > 0);
   if (const char* e = set("PFFT_THREE_STAGE_N3")) k.three_stage_n3 = std::atoll(e);
@@ -571,7 +573,7 @@ stage plan_t::make_strided_stage(const strided_kernel* k, long long count, long 
   // loses beyond (N=2^20: 1.76 vs 2.07 with the group-major intermediate; P->BI n=1024 2.7 vs 3.7); a staged
   // row-shaped OUTPUT always pays (BI->P n=1024 4.0 vs 2.0).
   int want_row = 0;
-  if (ia.stride == 1 && ia.dist_inner != 1 && oa.dist_inner == 1 && (k->n <= 512 || k->rowish != 0)) want_row = 1;
+  if (ia.stride == 1 && ia.dist_inner != 1 && oa.dist_inner == 1 && (k->n <= kn.row_in_max_n || k->rowish != 0)) want_row = 1;
   if (oa.stride == 1 && oa.dist_inner != 1 && ia.dist_inner == 1) want_row = 2;
   if (!allow_row) want_row = 0;  // four-step pair: stage B reads the group-major intermediate (tiled-input form)
   const bool mixed = desc.complex_storage == PFFT_SPLIT_COMPLEX && (in_buf == BUF_SCRATCH) != (out_buf == BUF_SCRATCH);

@@ -1,5 +1,5 @@
 """The XCD-local single-launch four-step plan (portfft_amd/csrc/stockham_xcd.hpp, plan_global.cpp plan_xcd_local) through the
-C ABI on an MI355X: fp32 N = 2^16 ... 2^20 and fp64 N = 2^16 ... 2^19 (kernels_xcd.hip), the reference's
+C ABI on an MI355X: fp32 N = 2^16, 2^17, 2^18, 2^20 and fp64 N = 2^16, 2^17, 2^18 (kernels_xcd.hip), the reference's
 GLOBAL-tier size range
 (ref: test/unit_test/instantiate_fft_tests.hpp:147-151, src/portfft/dispatcher/global_dispatcher.hpp:343-408).
 
@@ -65,8 +65,8 @@ def _check_samples(x, y, batch, samples, scale=1.0, n=N, tol=TOL):
 
 
 # every registered pair (kernels_xcd.hip): (precision, log2 N, a batch above the plan's threshold with a ragged tail)
-REGISTERED = [("f32", 16, 515), ("f32", 17, 301), ("f32", 19, 131), ("f32", 20, 67),
-              ("f64", 16, 387), ("f64", 17, 259), ("f64", 18, 133), ("f64", 19, 67)]
+REGISTERED = [("f32", 16, 515), ("f32", 17, 301), ("f32", 18, 150), ("f32", 20, 67),
+              ("f64", 16, 387), ("f64", 17, 259), ("f64", 18, 133)]
 
 
 @pytest.mark.parametrize("prec,log2n,batch", REGISTERED)
@@ -144,6 +144,7 @@ def test_small_batches_keep_the_two_launch_plan():
     assert taken([1 << 20], "f64", 256) == [0, 0]
     assert taken([1 << 15], "f32", 4096) == [0, 0]
     assert taken([3 << 16], "f32", 512) == [0, 0]
+    assert taken([1 << 19], "f32", 512) == [0, 0] and taken([1 << 19], "f64", 256) == [0, 0]  # (de-registered in round 5)
 
 
 def test_repeated_launches_offsets_scales_and_graph_replay():

@@ -295,7 +295,11 @@ int main() {
   const long long nfft = (long long)(bytes / (sizeof(cx<T>) * N));
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   struct gridopt { const char* name; int mode; int k; };
+#ifdef TUNE_GRID_SWEEP  // persistent grids of k / 4 x resident work-groups (one-work-group-per-CU kernels)
+  const gridopt gopts[] = {{"1.0xres", 2, 4}, {"1.25x", 2, 5}, {"1.5x", 2, 6}, {"1.75x", 2, 7}, {"2xres", 2, 8}, {"2.5x", 2, 10}, {"3xres", 2, 12}, {"6xres", 2, 24}};
+#else
   const gridopt gopts[] = {{"2xres", 0, 2}, {"4xres", 0, 4}, {"grp/8", 1, 8}, {"grp/4", 1, 4}, {"grp/2", 1, 2}, {"grp/1", 1, 1}};
+#endif
   const int NGO = sizeof(gopts) / sizeof(gopts[0]);
   std::vector<std::vector<std::vector<float>>> times(g_variants.size(), std::vector<std::vector<float>>(NGO));
   for (int round = 0; round < 6; ++round) {
@@ -303,7 +307,8 @@ int main() {
       int occ = 0; CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, g_variants[v].fn, g_variants[v].wg, g_variants[v].lds));
       const long long groups = (nfft + g_variants[v].fpw - 1) / g_variants[v].fpw;
       for (int go = 0; go < NGO; ++go) {
-        long long grid = gopts[go].mode == 0 ? (long long)gopts[go].k * occ * cus : (groups + gopts[go].k - 1) / gopts[go].k;
+        long long grid = gopts[go].mode == 0 ? (long long)gopts[go].k * occ * cus
+                         : gopts[go].mode == 2 ? (long long)gopts[go].k * occ * cus / 4 : (groups + gopts[go].k - 1) / gopts[go].k;
         grid = std::max<long long>(1, std::min(grid, groups));
         CK(hipEventRecord(e0));
         g_variants[v].launch((unsigned)grid, nfft);
