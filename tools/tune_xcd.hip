@@ -18,6 +18,9 @@
 #endif
 #include "../portfft_amd/csrc/stockham_xcd.hpp"
 #include "../portfft_amd/csrc/kernels.hpp"
+#ifdef TUNE_GANG
+#include "probes/xcd_gang.hpp"
+#endif
 using namespace pfa;
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s line %d\n", hipGetErrorString(e_), __LINE__); exit(1);} } while (0)
 
@@ -316,6 +319,51 @@ int main() {
     (void)verbose;
     CK(hipFree(ctl));
   };
+#ifdef TUNE_GANG
+  // ---- prototype: gang-synchronous launch (tools/probes/xcd_gang.hpp); slots per gang = TUNE_GANG (1 or 2)
+  auto run_gang = [&](int wg_per_cu, int prefetch) {
+    constexpr int GS = TUNE_GANG;
+    const void* fg = (const void*)&gang_fourstep_kernel<CfgA, CfgB, false, 1, 1, TUNE_OCCX, XWG, GS>;
+    const size_t own = xcd_lds_bytes<CfgA, CfgB, XWG>(stw_bytes);
+    size_t lds = own;
+    const size_t cu = 160 * 1024;
+    const size_t want = (cu / wg_per_cu) & ~(size_t)15;
+    if (want >= own) lds = std::max(own, std::min(want, (cu / (wg_per_cu + 1) + 16 + 15) & ~(size_t)15));
+    CK(hipFuncSetAttribute(fg, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    int per_cu = 0; CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fg, XWG, lds));
+    const unsigned grid = (unsigned)(per_cu * g_cus);
+    const size_t ctl_words = 4096 + (size_t)n_queues * GANG_MAXG * 64;
+    unsigned* gctl; CK(hipMalloc(&gctl, ctl_words * 4));
+    xcd_args x{};
+    x.a = args_a(in, scratch, g_batch, true);
+    x.b = args_b(scratch, out, g_batch, true);
+    x.batch = g_batch; x.n_queues = (int)n_queues; x.lds_ctl_off = (unsigned)(own - XCD_LDS_CTL_BYTES);
+    std::vector<double> tt;
+    unsigned long long bad = 0; unsigned tmo = 0;
+    for (int rep = 0; rep <= reps; ++rep) {
+      if (rep == 0) CK(hipMemset(out, 0xff, total * sizeof(T)));
+      CK(hipMemset(gctl, 0, ctl_words * 4));
+      CK(hipEventRecord(e0));
+      hipLaunchKernelGGL((gang_fourstep_kernel<CfgA, CfgB, false, 1, 1, TUNE_OCCX, XWG, GS>), dim3(grid), dim3(XWG), lds, 0, x, gctl, prefetch);
+      CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+      float ms; CK(hipEventElapsedTime(&ms, e0, e1)); if (rep) tt.push_back(ms);
+      if (rep == 0 || rep == reps) {
+        CK(hipMemset(d_diff, 0, 8));
+        count_diff<<<4096, 256>>>((const unsigned*)out, (const unsigned*)ref, total * sizeof(T) / 4, d_diff);
+        unsigned long long b; CK(hipMemcpy(&b, d_diff, 8, hipMemcpyDeviceToHost)); bad += b;
+        unsigned h[3]; CK(hipMemcpy(h, gctl, 12, hipMemcpyDeviceToHost)); tmo += h[2];
+      }
+    }
+    CK(hipGetLastError());
+    const double ms = median(tt);
+    printf("gang  slots %d  prefetch %d  %d WG/CU (grid %4u, lds %6zu, ring %zu KiB per XCD)  %.3f ms = %.3f of 8 TB/s  min %.3f  %s\n", GS, prefetch, per_cu, grid, lds,
+           (size_t)(grid / n_queues / (N2 / CfgA::FPW)) * GS * (size_t)(N * sizeof(cx<T>)) >> 10, ms, bytes / (ms * 1e-3) / 8e12,
+           *std::min_element(tt.begin(), tt.end()), (bad || tmo) ? "!! MISMATCH / TIMEOUT" : "bit-identical");
+    if (bad || tmo) printf("   !! %llu mismatching words, spins that gave up %u\n", bad, tmo);
+    CK(hipFree(gctl));
+  };
+  for (int w : {1, 2, 3, 4}) for (int pf : {0, 1}) run_gang(w, pf);
+#endif
   const int slots_log2 = getenv("TUNE_SLOTS") ? atoi(getenv("TUNE_SLOTS")) : 8;
   const int lag = getenv("TUNE_LAG") ? atoi(getenv("TUNE_LAG")) : 3;
   const int look = getenv("TUNE_LOOKAHEAD") ? atoi(getenv("TUNE_LOOKAHEAD")) : 4;
