@@ -57,7 +57,7 @@ constexpr int strided_pitch() {
 
 /// LDS copy of the store-modifier tables (strided_args::stw_tab): behind the images and the TWL tables.
 /// (IMGDIV: the kernel's image holds 1 / IMGDIV of the group -- 2 for the half-exchange kernel of
-/// stockham_strided_hx.hpp, the first radix for the experiment of tools/probes/stockham_strided_sfr.hpp)
+/// tools/probes/stockham_strided_hx.hpp, the first radix for the experiment of tools/probes/stockham_strided_sfr.hpp)
 template <typename Cfg, int IMGDIV = 1>
 PFA_DEV cx<typename Cfg::T>* stw_lds_tables(const strided_args& a) {
   extern __shared__ __attribute__((aligned(16))) char pfa_smem_strided[];

@@ -12,7 +12,7 @@
 // BATCH_INTERLEAVED dispatcher branches); same twiddle tables, addressing (strided_args) and store modifier.
 // Requirements: every pass divides evenly over the lanes (no ragged pass), interleaved storage.
 #pragma once
-#include "stockham_strided.hpp"
+#include "../../portfft_amd/csrc/stockham_strided.hpp"
 
 namespace pfa {
 

@@ -16,7 +16,7 @@
 #include <functional>
 #include <string>
 #include <vector>
-#include "../portfft_amd/csrc/stockham_strided_hx.hpp"
+#include "probes/stockham_strided_hx.hpp"
 #include "probes/stockham_strided_sfr.hpp"
 #include "probes/stockham_strided_dg.hpp"
 #include "../portfft_amd/csrc/kernels.hpp"

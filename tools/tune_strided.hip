@@ -7,7 +7,7 @@
 #include <functional>
 #include <string>
 #include <vector>
-#include "../portfft_amd/csrc/stockham_strided_hx.hpp"
+#include "probes/stockham_strided_hx.hpp"
 using namespace pfa;
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s line %d\n", hipGetErrorString(e_), __LINE__); exit(1);} } while (0)
 template <typename Seq, typename T>
