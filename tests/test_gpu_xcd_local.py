@@ -280,6 +280,22 @@ def test_a_launch_that_gives_up_is_recomputed_in_stream_order(prec, log2n, batch
     y = torch.empty_like(x)
     good.compute_forward(x, y).wait()
     assert torch.equal(y, want) and good.info().xcd_recoveries == 0
+    # a plan that gives up and recovers beside a healthy plan on another stream, launches interleaved without waiting:
+    # both results right, the healthy plan's report untouched (no process-wide state)
+    if log2n == 18 and iters == 20:
+        s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+        with _env(PFFT_XCD_CHECK="0", PFFT_XCD_MIN_BATCH="64"):
+            good2 = G.make_descriptor([n], prec, batch=batch).commit(s2)
+            with _env(PFFT_XCD_MAX_ITERS=str(iters)):
+                bad2 = G.make_descriptor([n], prec, batch=batch).commit(s1)
+        y1, y2 = torch.empty_like(x), torch.empty_like(x)
+        torch.cuda.synchronize()
+        for _ in range(3):
+            bad2.compute_forward(x, y1, want_event=False)
+            good2.compute_forward(x, y2, want_event=False)
+        torch.cuda.synchronize()
+        assert torch.equal(y1, want) and torch.equal(y2, want)
+        assert bad2.info().xcd_recoveries == 3 and good2.info().xcd_recoveries == 0
     # PFFT_XCD_CHECK=1 turns a recovery into an error (what the other tests of this file rely on)
     with _env(PFFT_XCD_CHECK="1", PFFT_XCD_MIN_BATCH="64", PFFT_XCD_MAX_ITERS=str(iters)):
         checked = G.make_descriptor([n], prec, batch=batch).commit()
