@@ -194,7 +194,7 @@ spec_kernel make_spec_entry_xlane(int groups_per_wg = 1) {
   return k;
 }
 
-template <typename Cfg>
+template <typename Cfg, bool PF = false>
 hipError_t launch_spec_hx(hipStream_t stream, unsigned grid, const void* in, void* out, const void* tw, long long nfft,
                           double scale, int backward) {
   using T = typename Cfg::T;
@@ -203,14 +203,14 @@ hipError_t launch_spec_hx(hipStream_t stream, unsigned grid, const void* in, voi
   const auto* t = static_cast<const cx<T>*>(tw);
   constexpr size_t lds = wg_hx_lds_bytes<Cfg>();
   if (backward) {
-    hipLaunchKernelGGL((stockham_wg_hx_kernel<Cfg, true>), dim3(grid), dim3(Cfg::WG), lds, stream, i, o, t, nfft, static_cast<T>(scale));
+    hipLaunchKernelGGL((stockham_wg_hx_kernel<Cfg, true, PF>), dim3(grid), dim3(Cfg::WG), lds, stream, i, o, t, nfft, static_cast<T>(scale));
   } else {
-    hipLaunchKernelGGL((stockham_wg_hx_kernel<Cfg, false>), dim3(grid), dim3(Cfg::WG), lds, stream, i, o, t, nfft, static_cast<T>(scale));
+    hipLaunchKernelGGL((stockham_wg_hx_kernel<Cfg, false, PF>), dim3(grid), dim3(Cfg::WG), lds, stream, i, o, t, nfft, static_cast<T>(scale));
   }
   return hipGetLastError();
 }
 
-template <typename Cfg>
+template <typename Cfg, bool PF = false>
 hipError_t launch_spec_hx_split(hipStream_t stream, unsigned grid, const void* in_re, const void* in_im, void* out_re,
                                 void* out_im, const void* tw, long long nfft, double scale, int backward) {
   using T = typename Cfg::T;
@@ -218,26 +218,26 @@ hipError_t launch_spec_hx_split(hipStream_t stream, unsigned grid, const void* i
   const dim3 g(grid), b(Cfg::WG);
   constexpr size_t lds = wg_hx_lds_bytes<Cfg>();
   if (backward) {
-    hipLaunchKernelGGL((stockham_wg_hx_split_kernel<Cfg, true>), g, b, lds, stream, static_cast<const T*>(in_re),
+    hipLaunchKernelGGL((stockham_wg_hx_split_kernel<Cfg, true, PF>), g, b, lds, stream, static_cast<const T*>(in_re),
                        static_cast<const T*>(in_im), static_cast<T*>(out_re), static_cast<T*>(out_im), t, nfft, static_cast<T>(scale));
   } else {
-    hipLaunchKernelGGL((stockham_wg_hx_split_kernel<Cfg, false>), g, b, lds, stream, static_cast<const T*>(in_re),
+    hipLaunchKernelGGL((stockham_wg_hx_split_kernel<Cfg, false, PF>), g, b, lds, stream, static_cast<const T*>(in_re),
                        static_cast<const T*>(in_im), static_cast<T*>(out_re), static_cast<T*>(out_im), t, nfft, static_cast<T>(scale));
   }
   return hipGetLastError();
 }
 
-/// register-resident form (stockham_wg_hx.hpp) of a packed length beyond the CU's LDS
-template <typename Cfg>
+/// register-resident form (stockham_wg_hx.hpp) of a packed length; PF: its software-pipelined form
+template <typename Cfg, bool PF = false>
 spec_kernel make_spec_entry_hx(int groups_per_wg = 0) {
   spec_kernel k = make_spec_entry<Cfg>(groups_per_wg);
   k.lds_bytes = wg_hx_lds_bytes<Cfg>();
-  k.fn[0] = reinterpret_cast<const void*>(&stockham_wg_hx_kernel<Cfg, false>);
-  k.fn[1] = reinterpret_cast<const void*>(&stockham_wg_hx_kernel<Cfg, true>);
-  k.launch = &launch_spec_hx<Cfg>;
-  k.fn_split[0] = reinterpret_cast<const void*>(&stockham_wg_hx_split_kernel<Cfg, false>);
-  k.fn_split[1] = reinterpret_cast<const void*>(&stockham_wg_hx_split_kernel<Cfg, true>);
-  k.launch_split = &launch_spec_hx_split<Cfg>;
+  k.fn[0] = reinterpret_cast<const void*>(&stockham_wg_hx_kernel<Cfg, false, PF>);
+  k.fn[1] = reinterpret_cast<const void*>(&stockham_wg_hx_kernel<Cfg, true, PF>);
+  k.launch = &launch_spec_hx<Cfg, PF>;
+  k.fn_split[0] = reinterpret_cast<const void*>(&stockham_wg_hx_split_kernel<Cfg, false, PF>);
+  k.fn_split[1] = reinterpret_cast<const void*>(&stockham_wg_hx_split_kernel<Cfg, true, PF>);
+  k.launch_split = &launch_spec_hx_split<Cfg, PF>;
   k.hx = 1;
   return k;
 }

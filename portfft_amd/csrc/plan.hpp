@@ -242,7 +242,7 @@ struct plan_t {
   void finish_store_tables(stage& s, const strided_kernel* k, size_t total, bool on_loads);
   /// Width of the intermediate's tiles -- i.e. the group width its stage A must have -- when `fb` is the four-step ...
   static int pair_tile(const strided_kernel* fb, long long n2, bool wide);
-  const spec_kernel* find_spec(long long n) const;
+  const spec_kernel* find_spec(long long n, bool allow_hx = true) const;
   /// column_both: the stage is column-shaped on both sides -> the wide-group entry of the length, when there is one ...
   const strided_kernel* find_strided(long long n, bool column_both = false, bool row_side = false,
                                      long long inner_count = -1, int policy = 0, bool store_modifier = false,

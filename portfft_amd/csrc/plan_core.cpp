@@ -370,7 +370,7 @@ void plan_t::finish_store_tables(stage& s, const strided_kernel* k, size_t total
   s.lds_bytes = total;
 }
 
-const spec_kernel* plan_t::find_spec(long long n) const {
+const spec_kernel* plan_t::find_spec(long long n, bool allow_hx) const {
   if (kn.no_precompiled) return nullptr;  // experiments: planner-chosen kernels everywhere
   int count = 0;
   const spec_kernel* k =
@@ -378,7 +378,7 @@ const spec_kernel* plan_t::find_spec(long long n) const {
   // PFFT_XLANE: prefer the cross-lane variant of a length (measurement / parity of stockham_xlane.hpp)
   const bool want_xlane = kn.xlane && desc.complex_storage == PFFT_INTERLEAVED_COMPLEX;
   const spec_kernel* found = nullptr;
-  const bool no_regres = kn.no_regres;  // A/B twin of the register-resident entries
+  const bool no_regres = kn.no_regres || !allow_hx;  // A/B twin of the register-resident entries / forms they do not have
   for (int i = 0; i < count; ++i) {
     if (k[i].n != n || k[i].lds_bytes > max_lds || (k[i].hx != 0 && no_regres)) continue;
     if (k[i].xlane != 0) {

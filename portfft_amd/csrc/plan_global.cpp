@@ -635,8 +635,7 @@ int plan_t::plan_1d(std::vector<stage>& out, long long n, long long count, long 
     const bool user_bufs = in_buf != BUF_SCRATCH && out_buf != BUF_SCRATCH;
     if (!packed_io && inner_count == count && row_like(ia) && row_like(oa) && (interleaved || user_bufs) &&
         !(ia.stride == 1 && ia.dist_inner == n && oa.stride == 1 && oa.dist_inner == n)) {
-      const spec_kernel* k = find_spec(n);
-      if (k != nullptr && k->hx != 0) k = nullptr;  // (no UNPACKED form of the register-resident entries)
+      const spec_kernel* k = find_spec(n, false);  // (no UNPACKED form of the register-resident entries)
       if (k == nullptr) {
         std::string why;
         k = jit_spec_kernel(desc.precision, n, !interleaved, max_lds, &why, true, nullptr, false);

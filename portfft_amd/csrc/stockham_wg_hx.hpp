@@ -159,10 +159,12 @@ PFA_DEV void hxw_exchange(cx<typename Cfg::T> (&v)[Cfg::bpt(P)][Cfg::Seq::r[P]],
   });
 }
 
-template <typename Cfg, bool BWD, int P, typename IO>
+/// `after_first_exchange(v)`: called once the exchange behind pass 0 has moved pass 0's outputs out of `v` -- the
+/// software-pipelined kernel issues the NEXT transform's loads into those registers there
+template <typename Cfg, bool BWD, int P, typename IO, typename Hook>
 PFA_DEV void hxw_passes(cx<typename Cfg::T> (&v)[Cfg::bpt(P)][Cfg::Seq::r[P]], const IO& io, unsigned tid,
                         cx<typename Cfg::T>* img, const cx<typename Cfg::T>* twl,
-                        const cx<typename Cfg::T>* __restrict__ tw, typename Cfg::T scale) {
+                        const cx<typename Cfg::T>* __restrict__ tw, typename Cfg::T scale, Hook&& after_first_exchange) {
   using T = typename Cfg::T;
   using Seq = typename Cfg::Seq;
   constexpr int R = Seq::r[P], Ns = Seq::ns(P);
@@ -198,7 +200,8 @@ PFA_DEV void hxw_passes(cx<typename Cfg::T> (&v)[Cfg::bpt(P)][Cfg::Seq::r[P]], c
   } else {
     cx<T> n[Cfg::bpt(P + 1)][Seq::r[P + 1]];
     hxw_exchange<Cfg, P>(v, n, tid, img);
-    hxw_passes<Cfg, BWD, P + 1>(n, io, tid, img, twl, tw, scale);
+    if constexpr (P == 0) after_first_exchange(v);
+    hxw_passes<Cfg, BWD, P + 1>(n, io, tid, img, twl, tw, scale, after_first_exchange);
   }
 }
 
@@ -223,8 +226,11 @@ PFA_DEV void hxw_load(const IO& io, unsigned tid, cx<typename Cfg::T> (&v)[Cfg::
   });
 }
 
-/// Body shared by the interleaved and the split-storage kernels (`make_io(g)`: the transform's I/O object)
-template <typename Cfg, bool BWD, typename MakeIO>
+/// Body shared by the interleaved and the split-storage kernels (`make_io(g)`: the transform's I/O object).
+/// PF: software-pipelined -- the next transform's HBM loads are issued behind the first exchange, into the registers
+/// pass 0 has just vacated, and are in flight through the remaining passes (for transforms that leave a lane that many
+/// registers: 2 x the transform + a butterfly's temporaries; fp64 8192 on 512 lanes, fp32 16384 on 1024)
+template <typename Cfg, bool BWD, bool PF = false, typename MakeIO>
 PFA_DEV void stockham_wg_hx_body(MakeIO&& make_io, const cx<typename Cfg::T>* __restrict__ tw, long long nfft,
                                  typename Cfg::T scale) {
   using T = typename Cfg::T;
@@ -237,32 +243,40 @@ PFA_DEV void stockham_wg_hx_body(MakeIO&& make_io, const cx<typename Cfg::T>* __
     for (int i = threadIdx.x; i < Cfg::TWL_ELEMS; i += Cfg::WG) twl[i] = tw[i];
     __syncthreads();
   }
+  cx<T> v[Cfg::bpt(0)][Cfg::Seq::r[0]];
+  if constexpr (PF) {
+    if (static_cast<long long>(blockIdx.x) < nfft) hxw_load<Cfg, BWD>(make_io(blockIdx.x), tid, v);
+  }
   for (long long g = blockIdx.x; g < nfft; g += gridDim.x) {
     const auto io = make_io(g);
-    cx<T> v[Cfg::bpt(0)][Cfg::Seq::r[0]];
-    hxw_load<Cfg, BWD>(io, tid, v);
+    if constexpr (!PF) hxw_load<Cfg, BWD>(io, tid, v);
     const cx<T>* twp = tw;
     asm volatile("" : "+s"(twp));  // keep the table reads inside the loop (see stockham_wg_body)
-    hxw_passes<Cfg, BWD, 0>(v, io, tid, img, twl, twp, scale);
+    const long long gn = g + gridDim.x;
+    hxw_passes<Cfg, BWD, 0>(v, io, tid, img, twl, twp, scale, [&](cx<T> (&regs)[Cfg::bpt(0)][Cfg::Seq::r[0]]) PFA_LAMBDA {
+      if constexpr (PF) {
+        if (gn < nfft) hxw_load<Cfg, BWD>(make_io(gn), tid, regs);
+      }
+    });
   }
 }
 
-template <typename Cfg, bool BWD>
+template <typename Cfg, bool BWD, bool PF = false>
 __global__ __launch_bounds__(Cfg::WG, Cfg::OCC) void stockham_wg_hx_kernel(const cx<typename Cfg::T>* in,
                                                                            cx<typename Cfg::T>* out,
                                                                            const cx<typename Cfg::T>* __restrict__ tw,
                                                                            long long nfft, typename Cfg::T scale) {
   using T = typename Cfg::T;
-  stockham_wg_hx_body<Cfg, BWD>(
+  stockham_wg_hx_body<Cfg, BWD, PF>(
       [&](long long g) PFA_LAMBDA { return packed_io<T, Cfg::N, 1, Cfg::AUX>(in, out, g, nfft); }, tw, nfft, scale);
 }
 
-template <typename Cfg, bool BWD>
+template <typename Cfg, bool BWD, bool PF = false>
 __global__ __launch_bounds__(Cfg::WG, Cfg::OCC) void stockham_wg_hx_split_kernel(
     const typename Cfg::T* in_re, const typename Cfg::T* in_im, typename Cfg::T* out_re, typename Cfg::T* out_im,
     const cx<typename Cfg::T>* __restrict__ tw, long long nfft, typename Cfg::T scale) {
   using T = typename Cfg::T;
-  stockham_wg_hx_body<Cfg, BWD>(
+  stockham_wg_hx_body<Cfg, BWD, PF>(
       [&](long long g) PFA_LAMBDA { return packed_split_io<T, Cfg::N, 1, Cfg::AUX>(in_re, in_im, out_re, out_im, g, nfft); },
       tw, nfft, scale);
 }

@@ -60,6 +60,23 @@ void add_hx(const char* name) {
   }});
 }
 
+/// ... software-pipelined (the next transform's loads in flight behind the first exchange)
+template <typename Cfg>
+void add_hx_pf(const char* name) {
+  using T = typename Cfg::T;
+  auto tw = make_twiddles<typename Cfg::Seq, T>();
+  cx<T>* d_tw;
+  CK(hipMalloc(&d_tw, tw.size() * sizeof(cx<T>)));
+  CK(hipMemcpy(d_tw, tw.data(), tw.size() * sizeof(cx<T>), hipMemcpyHostToDevice));
+  const void* fn = (const void*)&stockham_wg_hx_kernel<Cfg, false, true>;
+  constexpr size_t lds = wg_hx_lds_bytes<Cfg>();
+  if (lds > 160 * 1024) { printf("%s: %zu bytes of LDS -- skipped\n", name, lds); return; }
+  CK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  g_variants.push_back({name, 1, Cfg::WG, lds, fn, [d_tw](unsigned grid, long long nfft) {
+    hipLaunchKernelGGL((stockham_wg_hx_kernel<Cfg, false, true>), dim3(grid), dim3(Cfg::WG), wg_hx_lds_bytes<Cfg>(), 0, (const cx<T>*)g_in, (cx<T>*)g_out, d_tw, nfft, (T)1);
+  }});
+}
+
 template <typename Cfg, bool PF>
 void add(const char* name) {
   using T = typename Cfg::T;
@@ -132,6 +149,23 @@ int main() {
   add_hx<wg_cfg<d, radix_list<16, 16, 8, 8>, 512, 1, 16, 1, TW_GLOBAL, 2, NT, 0, 1>>("f64 hx 16.16.8.8 wg512 TWL1");
   add_hx<wg_cfg<d, radix_list<16, 16, 8, 8>, 1024, 1, 16, 1, TW_GLOBAL, 4, NT, 0, 1>>("f64 hx 16.16.8.8 wg1024 TWL1");
   add_hx<wg_cfg<d, radix_list<8, 8, 16, 16>, 512, 1, 8, 1, TW_GLOBAL, 2, NT, 0, 2>>("f64 hx 8.8.16.16 wg512 TWL2");
+#elif TUNE_CASE == 8192064  // fp64 8192 (reference WorkgroupOrGlobal size): LDS-resident production entry against register-resident forms
+  using T = d; const int N = 8192;
+  add<wg_cfg_twl<d, radix_list<16, 8, 8, 8>, 512, 1, 16, 1, 2, NT>, false>("f64 16.8.8.8 wg512 (production)");
+  add_hx<wg_cfg<d, radix_list<16, 16, 32>, 512, 1, 16, 1, TW_GLOBAL, 2, NT, 0, 1>>("f64 hx 16.16.32 wg512");
+  add_hx_pf<wg_cfg<d, radix_list<16, 16, 32>, 512, 1, 16, 1, TW_GLOBAL, 2, NT, 0, 1>>("f64 hx 16.16.32 wg512 PF");
+  add_hx_pf<wg_cfg<d, radix_list<32, 16, 16>, 512, 1, 32, 1, TW_GLOBAL, 2, NT, 0, 1>>("f64 hx 32.16.16 wg512 PF");
+  add_hx_pf<wg_cfg<d, radix_list<16, 32, 16>, 512, 1, 16, 1, TW_GLOBAL, 2, NT, 0, 1>>("f64 hx 16.32.16 wg512 PF");
+  add_hx_pf<wg_cfg<d, radix_list<16, 16, 32>, 256, 1, 16, 1, TW_GLOBAL, 1, NT, 0, 1>>("f64 hx 16.16.32 wg256 PF");
+  add_hx<wg_cfg<d, radix_list<16, 16, 32>, 1024, 1, 16, 1, TW_GLOBAL, 4, NT, 0, 1>>("f64 hx 16.16.32 wg1024");
+#elif TUNE_CASE == 16387  // fp32 16384: the TW_REGS production entry against register-resident forms
+  using T = f; const int N = 16384;
+  add<wg_cfg<f, radix_list<32, 16, 32>, 512, 1, 0, 0, TW_REGS, 2, NT>, false>("r32.16.32 twR wg512 (production)");
+  add_hx<wg_cfg<f, radix_list<32, 32, 16>, 1024, 1, 32, 1, TW_GLOBAL, 4, NT, 0, 1>>("hx 32.32.16 wg1024");
+  add_hx_pf<wg_cfg<f, radix_list<32, 32, 16>, 1024, 1, 32, 1, TW_GLOBAL, 4, NT, 0, 1>>("hx 32.32.16 wg1024 PF");
+  add_hx_pf<wg_cfg<f, radix_list<32, 32, 16>, 512, 1, 32, 1, TW_GLOBAL, 2, NT, 0, 1>>("hx 32.32.16 wg512 PF");
+  add_hx_pf<wg_cfg<f, radix_list<32, 16, 32>, 512, 1, 32, 1, TW_GLOBAL, 2, NT, 0, 1>>("hx 32.16.32 wg512 PF");
+  add_hx_pf<wg_cfg<f, radix_list<16, 32, 32>, 1024, 1, 16, 1, TW_GLOBAL, 4, NT, 0, 1>>("hx 16.32.32 wg1024 PF");
 #elif TUNE_CASE == 16384
   using S = radix_list<32, 32, 16>; using T = f; const int N = 16384;
   add<wg_cfg<f, S, 512, 1, 16, 1, TW_GLOBAL, 2, NT>, false>("r32.32.16 twG wg512 o2");
