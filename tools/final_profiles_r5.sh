@@ -6,8 +6,8 @@ set -u
 cd "$GRAFT_REPO_ROOT" || exit 1
 export TMPDIR=/tmp
 out=gpurun_out/final_r5; mkdir -p $out
-ALL="c3 c5 ref16 ref256 ref4096 ref65536 ref9800 ref15360 ref68640 g32_15 g32_17 g32_18 g32_19 g32_20 g32_21 g32_22 g32_24 g64_14 g64_16 g64_17 g64_18"
-PMC="c2 c3 c5 ref16 ref256 ref4096 ref65536 ref9800 ref15360 ref68640 g32_15 g32_17 g32_18 g32_19 g32_20 g32_21 g32_22 g32_24 g64_14 g64_16 g64_17 g64_18"
+ALL="c3 c5 ref16 ref256 ref4096 ref65536 ref9800 ref15360 ref68640 g32_15 g32_17 g32_18 g32_19 g32_20 g32_21 g32_22 g32_24 g64_13 g64_14 g64_16 g64_17 g64_18"
+PMC="c2 c3 c5 ref16 ref256 ref4096 ref65536 ref9800 ref15360 ref68640 g32_15 g32_17 g32_18 g32_19 g32_20 g32_21 g32_22 g32_24 g64_13 g64_14 g64_16 g64_17 g64_18"
 # ONLY_PMC="cfg ...": only the PMC passes and summaries of those configs (bench lines of them are refreshed too)
 if [ -n "${ONLY_PMC:-}" ]; then PMC="$ONLY_PMC"; fi
 if [ -z "${ONLY_PMC:-}" ]; then
@@ -38,6 +38,7 @@ sum c3 stockham_strided 4294967296 8 "C3 fp64 N=2^20 x 128: four-step, 8 chunks 
 sum c5 stockham_rows2d,stockham_strided 4294967296 8 "C5 fp32 1024x1024 x 256: two-pass 2-D plan, 8 chunks of 256 MiB"
 sum ref65536 stockham_xcd_fourstep 2147483648 1 "fp32 N=65536 x 2048: XCD-local single launch (256 x 256), slot rings of 24 transforms per XCD"
 sum g32_15 stockham_wg_hx 2147483648 1 "fp32 N=32768 x 4096: register-resident work-group kernel (32.32.32 on 1024 lanes), one launch"
+sum g64_13 stockham_wg_hx 2147483648 1 "fp64 N=8192 x 8192: register-resident, software-pipelined work-group kernel (16.32.16 on 512 lanes), one launch"
 sum g64_14 stockham_wg_hx 2147483648 1 "fp64 N=16384 x 4096: register-resident work-group kernel (16.32.32 on 512 lanes), one launch"
 sum ref16 stockham_wg 2147483648 1 "reference bench set: fp32 N=16 x 8Mi, one launch"
 sum ref256 stockham_wg 2147483648 1 "reference bench set: fp32 N=256 x 512Ki, one launch"
@@ -59,6 +60,7 @@ cp $out/r5_pmc_traffic*.json profiles/ 2>/dev/null
 for c in $PMC; do
   if [ $c = c2 ]; then python bench.py > $out/r5_bench_c2.json 2> $out/c2.err; else python bench.py --config $c --no-cpu-baseline > $out/r5_bench_$c.json 2> $out/$c.err; fi
 done
+for c in $PMC; do f=$(ls $out/pmc_$c/stats/*/*kernel_stats.csv 2>/dev/null | head -1); [ -n "$f" ] && [ ! -f $out/r5_${c}_kernel_stats.csv ] && cp "$f" $out/r5_${c}_kernel_stats.csv; done
 rm -rf $out/pmc_*/FETCH_SIZE $out/pmc_*/WRITE_SIZE $out/pmc_*/stats
 if [ -n "${ONLY_PMC:-}" ]; then exit 0; fi
 export HSA_ENABLE_IPC_MODE_LEGACY=0
