@@ -576,7 +576,9 @@ def test_four_step_half_pairs_and_split_choice():
         g = torch.Generator(device="cuda").manual_seed(n % 1000 + batch)
         x = torch.empty(batch * n, dtype=cdt, device="cuda")
         torch.view_as_real(x).uniform_(-1, 1, generator=g)
-        plan = commit(n, prec, batch)
+        # (24576 fp32 and 12288 fp64 fit the registers of one work-group since round 5 and would not take a four-step
+        #  plan at all -- test_gpu_parity.py::test_register_resident_lengths has them; here they stay four-step cases)
+        plan = commit(n, prec, batch, {"PFFT_NO_REGRES": "1"})
         d0 = plan.info().dims[0]
         assert d0.tier == 3, (n, prec)
         if factors is not None:
@@ -591,7 +593,8 @@ def test_four_step_half_pairs_and_split_choice():
         err = float(((z / n - x).abs().double().pow(2).sum() / x.abs().double().pow(2).sum()).sqrt())
         assert err <= tol, (n, prec, batch, "round trip", err)
         y0 = torch.empty_like(x)
-        commit(n, prec, batch, {"PFFT_NO_HALF_PAIRS": "1", "PFFT_NO_WIDE_TILES": "1"}).compute_forward(x, y0).wait()
+        commit(n, prec, batch, {"PFFT_NO_HALF_PAIRS": "1", "PFFT_NO_WIDE_TILES": "1",
+                                "PFFT_NO_REGRES": "1"}).compute_forward(x, y0).wait()
         diff = float(((y - y0).abs().double().pow(2).sum() / y0.abs().double().pow(2).sum()).sqrt())
         assert diff <= tol, (n, prec, batch, "vs the plan without half pairs / wide tiles", diff)
         del x, y, z, y0, plan

@@ -494,7 +494,8 @@ def test_runtime_specialised_lengths():
                            ("f32", np.complex64, 1000000)):
         x, y = H.gen_fourier_data(2, [n], dtype, seed=n)
         d = G.make_descriptor([n], prec, batch=2)
-        assert d.commit().info().dims[0].tier == 3
+        # (fp32 30000 fits the registers of one work-group: stockham_wg_hx.hpp, one launch, since round 5)
+        assert d.commit().info().dims[0].tier == (1 if (prec, n) == ("f32", 30000) else 3)
         got, _ = G.transform_packed(d, pf.direction.FORWARD, x)
         _check(got, y, n, dtype, ("jit four-step", prec, n))
         back, _ = G.transform_packed(d, pf.direction.BACKWARD, y)

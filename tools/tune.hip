@@ -60,20 +60,21 @@ void add_hx(const char* name) {
   }});
 }
 
-/// ... software-pipelined (the next transform's loads in flight behind the first exchange)
-template <typename Cfg>
+/// ... software-pipelined (PF = 1: the next transform's loads in flight behind the first exchange) or with the next
+/// transform's first half travelling by LDS-DMA into the idle image behind the last exchange (PF = 2)
+template <typename Cfg, int PF = 1>
 void add_hx_pf(const char* name) {
   using T = typename Cfg::T;
   auto tw = make_twiddles<typename Cfg::Seq, T>();
   cx<T>* d_tw;
   CK(hipMalloc(&d_tw, tw.size() * sizeof(cx<T>)));
   CK(hipMemcpy(d_tw, tw.data(), tw.size() * sizeof(cx<T>), hipMemcpyHostToDevice));
-  const void* fn = (const void*)&stockham_wg_hx_kernel<Cfg, false, true>;
+  const void* fn = (const void*)&stockham_wg_hx_kernel<Cfg, false, PF>;
   constexpr size_t lds = wg_hx_lds_bytes<Cfg>();
   if (lds > 160 * 1024) { printf("%s: %zu bytes of LDS -- skipped\n", name, lds); return; }
   CK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   g_variants.push_back({name, 1, Cfg::WG, lds, fn, [d_tw](unsigned grid, long long nfft) {
-    hipLaunchKernelGGL((stockham_wg_hx_kernel<Cfg, false, true>), dim3(grid), dim3(Cfg::WG), wg_hx_lds_bytes<Cfg>(), 0, (const cx<T>*)g_in, (cx<T>*)g_out, d_tw, nfft, (T)1);
+    hipLaunchKernelGGL((stockham_wg_hx_kernel<Cfg, false, PF>), dim3(grid), dim3(Cfg::WG), wg_hx_lds_bytes<Cfg>(), 0, (const cx<T>*)g_in, (cx<T>*)g_out, d_tw, nfft, (T)1);
   }});
 }
 
@@ -143,12 +144,20 @@ int main() {
   add_hx<wg_cfg<f, radix_list<16, 16, 16, 8>, 512, 1, 16, 1, TW_GLOBAL, 2, NT, 0, 1>>("hx 16.16.16.8 wg512 TWL1");
   add_hx<wg_cfg<f, radix_list<8, 16, 16, 16>, 1024, 1, 8, 1, TW_GLOBAL, 4, NT, 0, 2>>("hx 8.16.16.16 wg1024 TWL2");
   add_hx<wg_cfg<f, radix_list<32, 32, 32>, 1024, 1, 32, 1, TW_GLOBAL, 4, NT, 0, 0>>("hx 32.32.32 wg1024 TWL0");
+  add_hx_pf<wg_cfg<f, radix_list<32, 32, 32>, 1024, 1, 32, 1, TW_GLOBAL, 4, NT, 0, 1>, 2>("hx 32.32.32 wg1024 TWL1 DMA");
+  add_hx_pf<wg_cfg<f, radix_list<32, 32, 32>, 1024, 1, 0, 0, TW_GLOBAL, 4, NT, 0, 1>, 2>("hx 32.32.32 wg1024 TWL1 nopad DMA");
+  add_hx_pf<wg_cfg<f, radix_list<32, 32, 32>, 512, 1, 32, 1, TW_GLOBAL, 2, NT, 0, 1>, 2>("hx 32.32.32 wg512 TWL1 DMA");
+  add_hx_pf<wg_cfg<f, radix_list<16, 16, 16, 8>, 1024, 1, 16, 1, TW_GLOBAL, 4, NT, 0, 1>, 2>("hx 16.16.16.8 wg1024 TWL1 DMA");
 #elif TUNE_CASE == 16384064  // fp64 16384: the same 256 KiB
   using T = d; const int N = 16384;
   add_hx<wg_cfg<d, radix_list<16, 32, 32>, 512, 1, 16, 1, TW_GLOBAL, 2, NT, 0, 1>>("f64 hx 16.32.32 wg512 TWL1");
   add_hx<wg_cfg<d, radix_list<16, 16, 8, 8>, 512, 1, 16, 1, TW_GLOBAL, 2, NT, 0, 1>>("f64 hx 16.16.8.8 wg512 TWL1");
   add_hx<wg_cfg<d, radix_list<16, 16, 8, 8>, 1024, 1, 16, 1, TW_GLOBAL, 4, NT, 0, 1>>("f64 hx 16.16.8.8 wg1024 TWL1");
   add_hx<wg_cfg<d, radix_list<8, 8, 16, 16>, 512, 1, 8, 1, TW_GLOBAL, 2, NT, 0, 2>>("f64 hx 8.8.16.16 wg512 TWL2");
+  add_hx_pf<wg_cfg<d, radix_list<16, 32, 32>, 512, 1, 16, 1, TW_GLOBAL, 2, NT, 0, 1>, 2>("f64 hx 16.32.32 wg512 TWL1 DMA");
+  add_hx_pf<wg_cfg<d, radix_list<32, 32, 16>, 512, 1, 32, 1, TW_GLOBAL, 2, NT, 0, 1>, 2>("f64 hx 32.32.16 wg512 TWL1 DMA");
+  add_hx_pf<wg_cfg<d, radix_list<16, 16, 8, 8>, 512, 1, 16, 1, TW_GLOBAL, 2, NT, 0, 1>, 2>("f64 hx 16.16.8.8 wg512 TWL1 DMA");
+  add_hx<wg_cfg<d, radix_list<16, 32, 32>, 512, 1, 16, 1, TW_GLOBAL, 2, NT, 0, 1>>("f64 hx 16.32.32 wg512 TWL1 (again)");
 #elif TUNE_CASE == 8192064  // fp64 8192 (reference WorkgroupOrGlobal size): LDS-resident production entry against register-resident forms
   using T = d; const int N = 8192;
   add<wg_cfg_twl<d, radix_list<16, 8, 8, 8>, 512, 1, 16, 1, 2, NT>, false>("f64 16.8.8.8 wg512 (production)");
@@ -158,6 +167,8 @@ int main() {
   add_hx_pf<wg_cfg<d, radix_list<16, 32, 16>, 512, 1, 16, 1, TW_GLOBAL, 2, NT, 0, 1>>("f64 hx 16.32.16 wg512 PF");
   add_hx_pf<wg_cfg<d, radix_list<16, 16, 32>, 256, 1, 16, 1, TW_GLOBAL, 1, NT, 0, 1>>("f64 hx 16.16.32 wg256 PF");
   add_hx<wg_cfg<d, radix_list<16, 16, 32>, 1024, 1, 16, 1, TW_GLOBAL, 4, NT, 0, 1>>("f64 hx 16.16.32 wg1024");
+  add_hx_pf<wg_cfg<d, radix_list<16, 32, 16>, 512, 1, 16, 1, TW_GLOBAL, 2, NT, 0, 1>, 2>("f64 hx 16.32.16 wg512 DMA");
+  add_hx_pf<wg_cfg<d, radix_list<16, 32, 16>, 1024, 1, 16, 1, TW_GLOBAL, 4, NT, 0, 1>, 2>("f64 hx 16.32.16 wg1024 DMA");
 #elif TUNE_CASE == 16387  // fp32 16384: the TW_REGS production entry against register-resident forms
   using T = f; const int N = 16384;
   add<wg_cfg<f, radix_list<32, 16, 32>, 512, 1, 0, 0, TW_REGS, 2, NT>, false>("r32.16.32 twR wg512 (production)");
@@ -166,6 +177,9 @@ int main() {
   add_hx_pf<wg_cfg<f, radix_list<32, 32, 16>, 512, 1, 32, 1, TW_GLOBAL, 2, NT, 0, 1>>("hx 32.32.16 wg512 PF");
   add_hx_pf<wg_cfg<f, radix_list<32, 16, 32>, 512, 1, 32, 1, TW_GLOBAL, 2, NT, 0, 1>>("hx 32.16.32 wg512 PF");
   add_hx_pf<wg_cfg<f, radix_list<16, 32, 32>, 1024, 1, 16, 1, TW_GLOBAL, 4, NT, 0, 1>>("hx 16.32.32 wg1024 PF");
+  add_hx_pf<wg_cfg<f, radix_list<32, 32, 16>, 1024, 1, 32, 1, TW_GLOBAL, 4, NT, 0, 1>, 2>("hx 32.32.16 wg1024 DMA");
+  add_hx_pf<wg_cfg<f, radix_list<32, 32, 16>, 512, 1, 32, 1, TW_GLOBAL, 2, NT, 0, 1>, 2>("hx 32.32.16 wg512 DMA");
+  add_hx_pf<wg_cfg<f, radix_list<32, 16, 32>, 512, 1, 32, 1, TW_GLOBAL, 2, NT, 0, 1>, 2>("hx 32.16.32 wg512 DMA");
 #elif TUNE_CASE == 16384
   using S = radix_list<32, 32, 16>; using T = f; const int N = 16384;
   add<wg_cfg<f, S, 512, 1, 16, 1, TW_GLOBAL, 2, NT>, false>("r32.32.16 twG wg512 o2");
@@ -361,6 +375,30 @@ int main() {
       printf("  %s %.2f", gopts[go].name, 2.0 * bytes / t[t.size() / 2] * 1e-9);
     }
     printf("  TB/s\n");
+  }
+  {  // the variants agree with the first one (three sampled transforms, relative L2)
+    const long long sample[3] = {0, nfft / 2 + 1, nfft - 1};
+    std::vector<std::vector<cx<T>>> ref(3, std::vector<cx<T>>(N)), got(3, std::vector<cx<T>>(N));
+    for (size_t v = 0; v < g_variants.size(); ++v) {
+      int occ = 0; CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, g_variants[v].fn, g_variants[v].wg, g_variants[v].lds));
+      const long long groups = (nfft + g_variants[v].fpw - 1) / g_variants[v].fpw;
+      CK(hipMemset(g_out, 0xff, bytes));
+      g_variants[v].launch((unsigned)std::max<long long>(1, std::min<long long>(2ll * occ * cus, groups)), nfft);
+      CK(hipDeviceSynchronize());
+      double worst = 0;
+      for (int k = 0; k < 3; ++k) {
+        CK(hipMemcpy((v == 0 ? ref : got)[k].data(), (const cx<T>*)g_out + sample[k] * N, sizeof(cx<T>) * N, hipMemcpyDeviceToHost));
+        if (v == 0) continue;
+        double num = 0, den = 0;
+        for (int i = 0; i < N; ++i) {
+          const double dr = (double)got[k][i].re - (double)ref[k][i].re, di = (double)got[k][i].im - (double)ref[k][i].im;
+          num += dr * dr + di * di; den += (double)ref[k][i].re * ref[k][i].re + (double)ref[k][i].im * ref[k][i].im;
+        }
+        const double e = std::sqrt(num / den);
+        worst = (e == e && e > worst) || e != e ? (e != e ? 1e30 : e) : worst;
+      }
+      if (v != 0) printf("%-28s rel-L2 against the first variant %.2e%s\n", g_variants[v].name.c_str(), worst, worst > 1e-5 ? "   <-- DIFFERS" : "");
+    }
   }
   return 0;
 }
