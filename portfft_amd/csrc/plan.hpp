@@ -61,7 +61,8 @@ struct stage {
   int alias_scratch = 0;
   int store_modifier = 0;
   int row_mode = 0;  // 0: both sides addressed by the passes, 1: row-shaped input staged, 2: row-shaped output staged
-  int tiled_in = 0;  // 1: the kernel's tiled-input form (strided_kernel::launch_tin)
+  int tiled_in = 0;  // 1: the kernel's tiled-input form (strided_kernel::launch_tin), 2: ... with tiles twice as wide
+                     // (launch_tin_w), 3: row-lanes form of a runtime-compiled entry (jit_launch_strided_tin_rows)
   int gpw = 0;       // > 0: groups per work-group of this stage instead of the kernel's own rule (four-step pairs)
   int in_buf = BUF_IN, out_buf = BUF_OUT;
   long long count = 0;  // number of FFTs
@@ -166,6 +167,7 @@ struct plan_knobs {
   bool no_precompiled = false, xlane = false, no_regres = false, no_ltw = false, no_stw_rowish = false;
   bool jit_spec_radices = false, no_mixed_rows = false, no_three_stage = false, debug_global_set = false;
   bool no_tiled_scratch = false, no_tiled_lanes = false, no_xcd_local = false, global_n1_set = false;
+  bool no_tin_rows = false;  // PFFT_NO_TIN_ROWS: runtime stage B on a row-major intermediate keeps its f-fastest lanes
   bool nd_two_stage_columns = false, no_fs_pairs = false, no_half_pairs = false, no_split_rule = false;
   bool no_split_tiled = false, no_wide_tiles = false, two_pass_2d_off = false, jit_verbose = false;
   bool split_cached = true, pair_xcd = true, stop_event_on_launch = true, xcd_check = false;

@@ -1078,6 +1078,15 @@ int plan_t::plan_1d(std::vector<stage>& out, long long n, long long count, long 
       if (ltw) attach_store_tables(sb, n, true);
     }
   }
+  // No tiled intermediate (n2 or its first pass is not a multiple of stage A's group width: 10^6 = 1000 x 1000, 68640 = 104 x
+  // 660) and too long to stage its rows through LDS: a runtime-specialised stage B reads the row-major intermediate with its
+  // lanes element-fastest along the row (strided_pass TIN = -1) instead of four elements of each of FPW rows per wave
+  if (sb.strided != nullptr && sb.strided->launch == nullptr && sb.row_mode == 0 && sb.tiled_in == 0 &&
+      sb.sa.in_tile_shift == 0 && sb.sa.in_stride == 1 && sb.sa.in_gdist == 0 && interleaved_user && !sb.store_modifier &&
+      !kn.no_tin_rows) {
+    std::string why;
+    if (jit_strided_ensure_tin_rows(sb.strided, &why)) sb.tiled_in = 3;
+  }
   if (chunk < count || fs_pair) {  // (a pair's stages may carry their own grid rule / the tiled-input form)
     regrid_for_chunk(out.back(), std::min(chunk, count) * n2);
     regrid_for_chunk(sb, std::min(chunk, count) * n1);

@@ -185,14 +185,20 @@ PFA_DEV void strided_store_butterfly(const IO& io, const strided_args& a, unsign
 /// wave-instruction reads consecutive addresses, and the exchange behind pass 0 stores f ^ (i % FPW) in place of f so
 /// that the scatter (lane stride R0 elements = a multiple of all banks) stays conflict-free (TW <= FPW; two-way
 /// conflicts when TW = 2 * FPW); pass 1 reads through the same permutation, the later passes are unchanged.
-/// Template value: 0 off, 1 square tiles (TW = FPW), any other value = TW (a stage A with wider groups: fp32 n2 = 2048
-/// holds 8 columns, its stage A 16).  Needs TW * FPW | WG, (N / R0) % TW == 0 and (N / R0) % TPF == 0.
+/// Template value: 0 off, 1 square tiles (TW = FPW), any other positive value = TW (a stage A with wider groups: fp32
+/// n2 = 2048 holds 8 columns, its stage A 16).  Needs TW * FPW | WG, (N / R0) % TW == 0 and (N / R0) % TPF == 0.
+/// -1: ROWS -- the input is row-major (in_tile_shift 0, in_stride 1: FFT f is a contiguous row at f * in_fdist, the
+/// four-step stage B of a length without a tiled intermediate): pass 0 takes its lanes element-fastest over the WHOLE
+/// row -- lane = j + TPF * f -- so a wave reads 64 consecutive elements of one row (two rows at a seam) instead of
+/// four elements of each of FPW rows, with the same f ^ (j % FPW) slot permutation behind it.  Any length, ragged
+/// passes included; FPW a power of two.
 template <typename Cfg, int TIN = 1>
 constexpr int tin_width() {
   return TIN == 1 ? Cfg::FPW : TIN;
 }
 template <typename Cfg, int TIN = 1>
 constexpr bool tin_supported() {
+  if (TIN < 0) return Cfg::NP >= 2 && (Cfg::FPW & (Cfg::FPW - 1)) == 0 && Cfg::FPW >= 2;
   constexpr int TW = tin_width<Cfg, TIN>();
   return TIN != 0 && Cfg::NP >= 2 && (Cfg::FPW & (Cfg::FPW - 1)) == 0 && (TW & (TW - 1)) == 0 && TW >= 2 &&
          Cfg::WG % (TW * Cfg::FPW) == 0 && (Cfg::N / Cfg::Seq::r[0]) % TW == 0 &&
@@ -222,11 +228,16 @@ PFA_DEV void strided_pass(const IO& io, const strided_args& a, unsigned f,
   [[maybe_unused]] unsigned tin_jl = 0;
   if constexpr (tin0) {
     static_assert(first && tin_supported<Cfg, TIN>(), "TIN: see tin_supported()");
-    constexpr unsigned TW = tin_width<Cfg, TIN>();
     const unsigned lane = threadIdx.x;
-    tin_jl = lane % TW;
-    f = (lane / TW) % Cfg::FPW;
-    tid = (lane / (TW * Cfg::FPW)) * TW + tin_jl;
+    if constexpr (TIN < 0) {
+      f = lane / Cfg::TPF;
+      tid = lane % Cfg::TPF;
+    } else {
+      constexpr unsigned TW = tin_width<Cfg, TIN>();
+      tin_jl = lane % TW;
+      f = (lane / TW) % Cfg::FPW;
+      tid = (lane / (TW * Cfg::FPW)) * TW + tin_jl;
+    }
     live = static_cast<long long>(f) < nlive;
   }
   // LDS copy of the leading twiddle tables: behind the image, unless the launch says otherwise (strided_args::twl_lds_off)
@@ -335,10 +346,15 @@ PFA_DEV void strided_passes_range(const IO& io, const strided_args& a, unsigned 
 /// TIN lane mapping of pass 0 (see strided_pass): lanes element-fastest inside the FPW x TW input tiles
 template <typename Cfg, int TIN = 1>
 PFA_DEV void tin_lanes(unsigned* f, unsigned* tid, bool* live, long long nlive) {
-  constexpr unsigned TW = tin_width<Cfg, TIN>();
   const unsigned lane = threadIdx.x;
-  *f = (lane / TW) % Cfg::FPW;
-  *tid = (lane / (TW * Cfg::FPW)) * TW + lane % TW;
+  if constexpr (TIN < 0) {
+    *f = lane / Cfg::TPF;
+    *tid = lane % Cfg::TPF;
+  } else {
+    constexpr unsigned TW = tin_width<Cfg, TIN>();
+    *f = (lane / TW) % Cfg::FPW;
+    *tid = (lane / (TW * Cfg::FPW)) * TW + lane % TW;
+  }
   *live = static_cast<long long>(*f) < nlive;
 }
 

@@ -64,7 +64,9 @@ int main(int argc, char** argv) {
         for (int r : q.radices) pq *= r;
         EXPECT(pq == n && (q.radices.size() >= 2 || n <= 61), "strided n=%lld", n);  // one lane per FFT up to the largest radix
         EXPECT(q.wg >= 64 && q.wg <= 1024 && q.wg % q.fpw == 0, "strided n=%lld wg=%d fpw=%d", n, q.wg, q.fpw);
-        EXPECT(static_cast<size_t>(n) * q.fpw * es <= 128 * 1024, "strided n=%lld lds", n);
+        // (one FFT per work-group -- lengths beyond the generic tier's two images -- may use all of the LDS)
+        EXPECT(static_cast<size_t>(n) * q.fpw * es <= (q.fpw == 1 ? max_lds : 128 * 1024), "strided n=%lld lds", n);
+        EXPECT(q.fpw > 1 || static_cast<size_t>(n) * 2 * es > max_lds, "strided n=%lld: one FFT per work-group", n);
       }
       // a requested group width (four-step half pairs, plan_global.cpp) is honoured exactly or refused
       for (int want : {8, 16}) {
@@ -159,7 +161,9 @@ int main(int argc, char** argv) {
     struct { int prec; long long n; int kind; } cases[] = {{0, 1200, 0}, {1, 625, 1}, {0, 30, 0}, {0, 120, 2}, {1, 250, 3},
                                                             {0, 1000, 4}, {1, 768, 4},
                                                             // forms of the three-stage / tiled plans that exist only at run time
-                                                            {0, 128, 5}, {1, 1024, 6}, {0, 1024, 7}};
+                                                            {0, 128, 5}, {1, 1024, 6}, {0, 1024, 7},
+                                                            // row-lanes stage B (ragged: 52 lanes per row of 100 butterflies)
+                                                            {0, 1000, 10}, {1, 660, 10}};
     for (auto& c : cases) {
       pfa::wg_params q;
       const bool ok = c.kind < 2 ? pfa::choose_spec_params(c.prec, c.n, max_lds, &q)

@@ -258,6 +258,34 @@ def test_strided_workgroup_tier(prec, oracle):
 
 
 @pytest.mark.parametrize("prec", ["f32", "f64"])
+def test_long_transforms_in_strided_layouts(prec):
+    """Strided / batch-interleaved transforms longer than HALF the LDS (fp32 10 241 ... 20 480 points, fp64 5121 ... 10 240):
+    the generic tier needs two images and the four-step plan takes packed data only, so the strided work-group kernel
+    runs them one transform per work-group (jit.cpp choose_strided_params, fpw = 1).  Found by tools/fuzz.py seed 61
+    (profiles/r5_fuzz_61_150.txt): 11780 / 12464 (fp32) and 5610 (fp64) used to be `unsupported_configuration` inside
+    the documented limits."""
+    import gpu_utils as G
+    pf = _pf()
+    dtype = np.complex64 if prec == "f32" else np.complex128
+    sizes = (11780, 12464, 20480, 16384) if prec == "f32" else (5610, 10240, 7000)
+    for n in sizes:
+        for batch, lin, lout, place, storage in ((3, "BI", "BI", 1, 0), (33, "P", "BI", 1, 1), (5, "BI", "P", 1, 0),
+                                                 (2, "BI", "BI", 0, 0)):
+            x, y = H.gen_fourier_data(batch, [n], dtype, seed=n + batch)
+            for direction in (F, B):
+                d = _layout_desc(G, n, prec, batch, place, lin, lout, direction, storage)
+                src, ref = (x, y) if direction == F else (y, x.astype(np.complex128) * n)
+                got, _ = G.transform_packed(d, pf.direction(direction), src)
+                _check(got, ref, n, dtype, ("long strided", prec, n, batch, lin, lout, place, storage, direction))
+        # a strided row layout (stride 2, padded distance)
+        x, y = H.gen_fourier_data(3, [n], dtype, seed=n)
+        d = G.make_descriptor([n], prec, batch=3, placement=1, fwd_strides=[2], fwd_distance=2 * n + 5,
+                              bwd_strides=[2], bwd_distance=2 * n + 5)
+        got, _ = G.transform_packed(d, pf.direction.FORWARD, x)
+        _check(got, y, n, dtype, ("long strided rows", prec, n))
+
+
+@pytest.mark.parametrize("prec", ["f32", "f64"])
 def test_every_registered_length(prec):
     """every length that has a specialised kernel (kernels_f32.hip / kernels_f64.hip), plus neighbours that fall to
     the generic tier, packed, ragged batch counts, forward and backward"""

@@ -123,6 +123,16 @@ def test_the_tuned_table_is_used_by_default_and_can_be_turned_off(tmp_path):
     packed = [e for e in entries if not e[2]]
     splits = [e for e in entries if e[2]]
     sample = packed[:2] + packed[-1:] + splits[:1] + splits[-1:]
+    # (four-step splits of lengths that fit the registers of one work-group -- fp32 to ~39 000 points, fp64 to ~15 800 --
+    #  apply where the register-resident kernel is off or declines: PFFT_NO_REGRES=1 for every split entry)
+    os.environ["PFFT_NO_REGRES"] = "1"
+    try:
+        _sampled_entries_are_taken(sample, tmp_path)
+    finally:
+        del os.environ["PFFT_NO_REGRES"]
+
+
+def _sampled_entries_are_taken(sample, tmp_path):
     for prec, n, is_split, factors in sample:
         with_lanes = len(factors) >= 3 and factors[-2] == 0  # (a packed entry may end in "0, lanes")
         if with_lanes:
@@ -146,8 +156,13 @@ import numpy as np, torch
 import gpu_utils as G, helpers as H
 entries = json.loads(sys.argv[1])
 bad, t0 = [], time.time()
+import os
 for prec, n, is_split, factors in entries:
     batch = max(2, min(64, (1 << 21) // n))
+    # a four-step split of a length that the register-resident kernel takes by default is the plan of its A/B twin
+    os.environ.pop("PFFT_NO_REGRES", None)
+    if is_split:
+        os.environ["PFFT_NO_REGRES"] = "1"
     plan = G.make_descriptor([n], prec, batch=batch).commit()
     d = plan.info().dims[0]
     got = [int(d.factors[i]) for i in range(d.n_factors)]

@@ -180,6 +180,32 @@ int main() {
   add_hx_pf<wg_cfg<f, radix_list<32, 32, 16>, 1024, 1, 32, 1, TW_GLOBAL, 4, NT, 0, 1>, 2>("hx 32.32.16 wg1024 DMA");
   add_hx_pf<wg_cfg<f, radix_list<32, 32, 16>, 512, 1, 32, 1, TW_GLOBAL, 2, NT, 0, 1>, 2>("hx 32.32.16 wg512 DMA");
   add_hx_pf<wg_cfg<f, radix_list<32, 16, 32>, 512, 1, 32, 1, TW_GLOBAL, 2, NT, 0, 1>, 2>("hx 32.16.32 wg512 DMA");
+#elif TUNE_CASE == 16388  // fp32 16384: register-resident forms with TWO work-groups per CU (half images of 64 KiB)
+  using T = f; const int N = 16384;
+  add<wg_cfg<f, radix_list<32, 16, 32>, 512, 1, 0, 0, TW_REGS, 2, NT>, false>("r32.16.32 twR wg512 (production)");
+  add_hx<wg_cfg<f, radix_list<32, 32, 16>, 512, 1, 32, 1, TW_GLOBAL, 4, NT, 0, 1>>("hx 32.32.16 wg512 occ4");
+  add_hx<wg_cfg<f, radix_list<32, 16, 32>, 512, 1, 32, 1, TW_GLOBAL, 4, NT, 0, 1>>("hx 32.16.32 wg512 occ4");
+  add_hx<wg_cfg<f, radix_list<16, 32, 32>, 512, 1, 16, 1, TW_GLOBAL, 4, NT, 0, 1>>("hx 16.32.32 wg512 occ4");
+  add_hx<wg_cfg<f, radix_list<32, 32, 16>, 256, 1, 32, 1, TW_GLOBAL, 2, NT, 0, 1>>("hx 32.32.16 wg256 occ2");
+  add_hx<wg_cfg<f, radix_list<16, 16, 8, 8>, 512, 1, 16, 1, TW_GLOBAL, 4, NT, 0, 2>>("hx 16.16.8.8 wg512 occ4");
+  add_hx_pf<wg_cfg<f, radix_list<32, 32, 16>, 512, 1, 32, 1, TW_GLOBAL, 4, NT, 0, 1>, 2>("hx 32.32.16 wg512 occ4 DMA");
+  add_hx_pf<wg_cfg<f, radix_list<32, 16, 32>, 512, 1, 32, 1, TW_GLOBAL, 4, NT, 0, 1>, 2>("hx 32.16.32 wg512 occ4 DMA");
+  add_hx<wg_cfg<f, radix_list<32, 32, 16>, 1024, 1, 32, 1, TW_GLOBAL, 8, NT, 0, 1>>("hx 32.32.16 wg1024 occ8");
+#elif TUNE_CASE == 8192065  // fp64 8192: ... the same
+  using T = d; const int N = 8192;
+  add_hx_pf<wg_cfg<d, radix_list<16, 32, 16>, 512, 1, 16, 1, TW_GLOBAL, 2, NT, 0, 1>>("f64 hx 16.32.16 wg512 PF (production)");
+  add_hx<wg_cfg<d, radix_list<16, 32, 16>, 512, 1, 16, 1, TW_GLOBAL, 4, NT, 0, 1>>("f64 hx 16.32.16 wg512 occ4");
+  add_hx<wg_cfg<d, radix_list<16, 16, 32>, 512, 1, 16, 1, TW_GLOBAL, 4, NT, 0, 1>>("f64 hx 16.16.32 wg512 occ4");
+  add_hx<wg_cfg<d, radix_list<32, 16, 16>, 256, 1, 32, 1, TW_GLOBAL, 2, NT, 0, 1>>("f64 hx 32.16.16 wg256 occ2");
+  add_hx<wg_cfg<d, radix_list<16, 32, 16>, 256, 1, 16, 1, TW_GLOBAL, 2, NT, 0, 1>>("f64 hx 16.32.16 wg256 occ2");
+  add_hx_pf<wg_cfg<d, radix_list<16, 32, 16>, 512, 1, 16, 1, TW_GLOBAL, 4, NT, 0, 1>, 2>("f64 hx 16.32.16 wg512 occ4 DMA");
+#elif TUNE_CASE == 12000  // fp32 12000 (96 KB): LDS-resident planner choice against register-resident forms, two work-groups per CU
+  using T = f; const int N = 12000;
+  add<wg_cfg<f, radix_list<30, 20, 20>, 640, 1, 0, 0, TW_GLOBAL, 2, NT, 0, 1>, false>("r30.20.20 wg640 lds");
+  add_hx<wg_cfg<f, radix_list<30, 20, 20>, 640, 1, 0, 0, TW_GLOBAL, 3, NT, 0, 1>>("hx 30.20.20 wg640 occ3");
+  add_hx<wg_cfg<f, radix_list<30, 20, 20>, 448, 1, 0, 0, TW_GLOBAL, 4, NT, 0, 1>>("hx 30.20.20 wg448 occ4");
+  add_hx<wg_cfg<f, radix_list<24, 25, 20>, 512, 1, 0, 0, TW_GLOBAL, 4, NT, 0, 1>>("hx 24.25.20 wg512 occ4");
+  add_hx<wg_cfg<f, radix_list<20, 20, 30>, 640, 1, 0, 0, TW_GLOBAL, 3, NT, 0, 1>>("hx 20.20.30 wg640 occ3");
 #elif TUNE_CASE == 16384
   using S = radix_list<32, 32, 16>; using T = f; const int N = 16384;
   add<wg_cfg<f, S, 512, 1, 16, 1, TW_GLOBAL, 2, NT>, false>("r32.32.16 twG wg512 o2");
