@@ -167,7 +167,7 @@ struct plan_knobs {
   bool no_precompiled = false, xlane = false, no_regres = false, no_ltw = false, no_stw_rowish = false;
   bool jit_spec_radices = false, no_mixed_rows = false, no_three_stage = false, debug_global_set = false;
   bool no_tiled_scratch = false, no_tiled_lanes = false, no_xcd_local = false, global_n1_set = false;
-  bool no_tin_rows = false;  // PFFT_NO_TIN_ROWS: runtime stage B on a row-major intermediate keeps its f-fastest lanes
+  bool tin_rows = false;  // PFFT_TIN_ROWS=1: runtime stage B on a row-major intermediate with its lanes along the row
   bool nd_two_stage_columns = false, no_fs_pairs = false, no_half_pairs = false, no_split_rule = false;
   bool no_split_tiled = false, no_wide_tiles = false, two_pass_2d_off = false, jit_verbose = false;
   bool split_cached = true, pair_xcd = true, stop_event_on_launch = true, xcd_check = false;

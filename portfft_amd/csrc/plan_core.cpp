@@ -103,7 +103,7 @@ plan_knobs plan_knobs::from_env() {
   flag("PFFT_NO_THREE_STAGE", &k.no_three_stage);
   flag("PFFT_NO_TILED_SCRATCH", &k.no_tiled_scratch);
   flag("PFFT_NO_TILED_LANES", &k.no_tiled_lanes);
-  flag("PFFT_NO_TIN_ROWS", &k.no_tin_rows);
+  flag("PFFT_TIN_ROWS", &k.tin_rows);
   flag("PFFT_NO_XCD_LOCAL", &k.no_xcd_local);
   flag("PFFT_ND_TWO_STAGE_COLUMNS", &k.nd_two_stage_columns);
   flag("PFFT_NO_FS_PAIRS", &k.no_fs_pairs);

@@ -1,0 +1,26 @@
+"""Transforms of 64 ... 160 KiB (one LDS-resident work-group per CU today): the register-resident kernel planned as TWO
+work-groups per CU (choose_hx_params, lanes <= 512, half image <= 80 KiB each; PFFT_JIT_HX_PAIR_MIN_KIB lowers the planner's
+threshold) against the LDS-resident plan.  The threshold is read when the length is first planned: one process per variant."""
+import os, subprocess, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CHILD = r"""
+import sys; sys.path.insert(0, %r)
+from perf_survey_lib import run
+prec, n = sys.argv[1], int(sys.argv[2])
+es = 8 if prec == "f32" else 16
+run("%%s N=%%d %%s" %% (prec, n, sys.argv[3]), [n], max(1, (1 << 30) // (n * es)), prec)
+""" % os.path.join(ROOT, "tools")
+F32 = [8192, 9216, 10000, 10240, 12000, 12288, 13824, 14400, 15000, 15360, 15625, 16000, 16384, 17280, 18000, 18432, 19200, 19683]
+F64 = [4096, 4608, 5000, 5120, 6000, 6144, 6400, 7168, 7680, 8000, 8192]
+which = sys.argv[1] if len(sys.argv) > 1 else "all"
+for prec, sizes in (("f32", F32), ("f64", F64)):
+    if which not in ("all", prec):
+        continue
+    for n in sizes:
+        variants = (("lds", {}), ("pair", {"PFFT_JIT_HX_PAIR_MIN_KIB": "60", "PFFT_NO_PRECOMPILED": "1", "PFFT_NO_TUNED_TABLE": "1"}),
+                    ("pair persistent", {"PFFT_JIT_HX_PAIR_MIN_KIB": "60", "PFFT_NO_PRECOMPILED": "1", "PFFT_NO_TUNED_TABLE": "1", "PFFT_JIT_HX_PAIR_GPW": "0"}))
+        for tag, env in variants:
+            e = dict(os.environ, **env)
+            p = subprocess.run([sys.executable, "-c", CHILD, prec, str(n), tag], env=e, capture_output=True, text=True)
+            out = [l for l in p.stdout.splitlines() if "TB/s" in l]
+            print(out[-1] if out else ("%s N=%d %s: failed %s" % (prec, n, tag, p.stderr[-300:])), flush=True)

@@ -8,14 +8,14 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from perf_survey_lib import run
 F32 = [1000000, 68640, 250000, 62500, 100000, 120000, 500000, 2985984, 390625, 531441, 48000, 51200, 60000, 160000]
 F64 = [1000000, 68640, 250000, 62500, 100000, 30000, 50000]
-KN = ("PFFT_NO_TIN_ROWS", "PFFT_ROW_IN_MAX_N")
+KN = ("PFFT_TIN_ROWS", "PFFT_ROW_IN_MAX_N")
 for prec, sizes in (("f32", F32), ("f64", F64)):
     es = 8 if prec == "f32" else 16
     for n in sizes:
         batch = max(1, (1 << 30) // (n * es))
-        for tag, env in (("default", {}), ("f-fastest", {"PFFT_NO_TIN_ROWS": "1"}),
-                         ("rows, no staging", {"PFFT_ROW_IN_MAX_N": "0"}),
-                         ("f-fastest, no staging", {"PFFT_NO_TIN_ROWS": "1", "PFFT_ROW_IN_MAX_N": "0"})):
+        for tag, env in (("default", {}), ("rows", {"PFFT_TIN_ROWS": "1"}),
+                         ("rows, no staging", {"PFFT_TIN_ROWS": "1", "PFFT_ROW_IN_MAX_N": "0"}),
+                         ("f-fastest, no staging", {"PFFT_ROW_IN_MAX_N": "0"})):
             for k in KN:
                 os.environ.pop(k, None)
             os.environ.update(env)
