@@ -24,7 +24,12 @@ const spec_kernel g_spec_f32[] = {
     // the headline shape: register-resident twiddles + software-pipelined loads (3 work-groups per CU)
     make_spec_entry_prefetch<wg_cfg<f, radix_list<16, 16, 16>, 256, 1, 16, 1, TW_REGS, 3, NT>>(4),  // 4096
     make_spec_entry<wg_cfg<f, radix_list<32, 16, 16>, 256, 1, 16, 1, TW_REGS, 2, NT>>(4),       // 8192
-    make_spec_entry<wg_cfg<f, radix_list<32, 16, 32>, 512, 1, 0, 0, TW_REGS, 2, NT>>(0),       // 16384
+    // 16384 (128 KiB): register-resident on 512 lanes with 128 VGPRs and a 74 KiB half image -- TWO work-groups per CU cover each
+    // other's HBM phases.  tools/tune.hip case 16388, TB/s, persistent grid / one transform per work-group: LDS-resident 32.16.32
+    // with its twiddles in registers (one work-group per CU) 5.44 / 4.53, hx 32.32.16 5.78 / **6.11**, 32.16.32 5.63 / 6.11,
+    // 256 lanes x 64 values 5.62 / 6.23; through the library 0.62 -> 0.71 of the HBM peak
+    make_spec_entry_hx<wg_cfg<f, radix_list<32, 32, 16>, 512, 1, 32, 1, TW_GLOBAL, 4, NT, 0, 1>>(1),  // 16384
+    make_spec_entry<wg_cfg<f, radix_list<32, 16, 32>, 512, 1, 0, 0, TW_REGS, 2, NT>>(0),       // 16384 (PFFT_NO_REGRES=1, UNPACKED layouts)
     // beyond the CU's LDS: the transform stays in registers, the exchanges cross a half image (stockham_wg_hx.hpp).
     // tools/tune.hip case 32768, TB/s at a grid of 2 x resident / one transform per work-group: 1024 lanes x 32 points
     // 5.19 / 4.92, 512 lanes x 64 points 4.55 / 4.56, four passes (16.16.16.8, 8.16.16.16) 4.0-4.6; the two-launch

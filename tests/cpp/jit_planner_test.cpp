@@ -129,6 +129,7 @@ int main(int argc, char** argv) {
           regs = std::max<int>(regs, static_cast<int>((n / r + p.wg - 1) / p.wg) * r);
         }
         EXPECT(prod == n && p.radices.size() >= 2 && p.radices.size() <= 4, "hx n=%lld radices", n);
+        if (p.hx_pair != 0) continue;  // (checked below)
         EXPECT(p.fpw == 1 && p.staged == 0 && p.wg % 64 == 0 && p.wg >= 512 && p.wg <= 1024, "hx n=%lld lanes %d", n, p.wg);
         EXPECT(pfa::hx_lds_bytes(p) <= max_lds && static_cast<size_t>(n) * es > 152 * 1024, "hx n=%lld LDS", n);
         const int budget = 512 / ((p.wg / 64 + 3) / 4);
@@ -139,9 +140,31 @@ int main(int argc, char** argv) {
     EXPECT(planned_hx[0] > 300 && planned_hx[1] > 150, "hx planner coverage");
     EXPECT(!pfa::choose_hx_params(0, 40960, max_lds, &p0) , "40960: 80 values per lane do not pay");
     pfa::wg_params p;
-    EXPECT(!pfa::choose_hx_params(0, 16384, max_lds, &p), "16384 fits the LDS: the packed planner's");
+    // 80 ... 152 KiB: TWO register-resident work-groups per CU (half the LDS, half the registers each), three passes
+    // behind a padded power-of-two first radix -- or the packed planner's LDS-resident kernel
+    long long pairs[2] = {0, 0};
+    for (int prec = 0; prec < 2; ++prec) {
+      const int es = prec ? 16 : 8;
+      for (long long n = 80 * 1024 / es - 100; n <= (prec ? 10240 : 19000); ++n) {
+        pfa::wg_params q;
+        if (!pfa::choose_hx_params(prec, n, max_lds, &q)) continue;
+        ++pairs[prec];
+        EXPECT(static_cast<size_t>(n) * es > 80 * 1024 && q.hx_pair == 1, "hx pair n=%lld", n);
+        EXPECT(q.radices.size() <= 3 && q.radices[0] >= 16 && (q.radices[0] & (q.radices[0] - 1)) == 0 && q.pads == q.radices[0],
+               "hx pair n=%lld: padded power-of-two first radix, three passes", n);
+        EXPECT(q.wg >= 256 && q.wg <= 512 && q.wg % 64 == 0 && 2 * pfa::hx_lds_bytes(q) <= max_lds, "hx pair n=%lld: lanes %d", n, q.wg);
+        const int budget = 512 / ((2 * (q.wg / 64) + 3) / 4);
+        EXPECT(q.regs * (prec ? 4 : 2) < budget && q.occ == (2 * (q.wg / 64) + 3) / 4, "hx pair n=%lld: %d values per lane", n, q.regs);
+      }
+    }
+    std::printf("hx planner: %lld fp32 and %lld fp64 lengths as pairs\n", pairs[0], pairs[1]);
+    EXPECT(pairs[0] > 20 && pairs[1] > 10, "hx pair coverage");
+    EXPECT(pfa::choose_hx_params(0, 16384, max_lds, &p) && p.hx_pair == 1 && p.wg == 512, "fp32 16384: two work-groups per CU");
+    EXPECT(!pfa::choose_hx_params(0, 16000, max_lds, &p), "fp32 16000: no three-pass pair plan, LDS-resident");
+    EXPECT(!pfa::choose_hx_params(0, 8192, max_lds, &p), "fp32 8192: the LDS-resident kernel has two work-groups per CU itself");
     EXPECT(pfa::choose_hx_params(0, 20480, max_lds, &p), "fp32 20480: the top of the LDS range goes register-resident");
     EXPECT(!pfa::choose_hx_params(1, 10240, max_lds, &p), "fp64 10240 stays LDS-resident");
+    EXPECT(pfa::choose_hx_params(1, 6144, max_lds, &p) && p.hx_pair == 1 && p.wg == 256, "fp64 6144: two work-groups per CU");
     EXPECT(!pfa::choose_hx_params(0, 65536, max_lds, &p), "65536 does not fit the registers");
     EXPECT(pfa::choose_hx_params(0, 32768, max_lds, &p) && p.radices.size() == 3, "fp32 32768 in three passes");
     EXPECT(pfa::choose_hx_params(1, 16384, max_lds, &p) && p.radices.size() <= 4, "fp64 16384");

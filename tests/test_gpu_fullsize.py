@@ -601,6 +601,52 @@ def test_four_step_half_pairs_and_split_choice():
         torch.cuda.empty_cache()
 
 
+@pytest.mark.gpu
+def test_row_lanes_form_of_a_runtime_stage_b():
+    """PFFT_TIN_ROWS=1 (opt-in, profiles/r5_notes.md section 12): the runtime-specialised stage B of a four-step length
+    without a tiled intermediate reads its row-major input with the lanes along the row (strided_pass TIN = -1, ragged
+    passes included: 1000 points on 52 lanes x 2, 660 on 40 x 3).  Against NumPy, the round trip, and the default plan of
+    the same descriptor."""
+    G, pf, torch = _mods()
+
+    def commit(n, prec, batch, env):
+        old = {k: os.environ.get(k) for k in env}
+        os.environ.update(env)
+        try:
+            return G.make_descriptor([n], prec, batch=batch).commit()
+        finally:
+            for k, v in old.items():
+                if v is None:
+                    del os.environ[k]
+                else:
+                    os.environ[k] = v
+
+    for n, prec, batch in ((1000000, "f32", 3), (68640, "f32", 5), (68640, "f64", 3), (250000, "f32", 2), (1000000, "f64", 2)):
+        cdt = torch.complex64 if prec == "f32" else torch.complex128
+        tol = H.REL_L2_TOL[np.dtype(np.complex64 if prec == "f32" else np.complex128)]
+        g = torch.Generator(device="cuda").manual_seed(n % 1000 + batch)
+        x = torch.empty(batch * n, dtype=cdt, device="cuda")
+        torch.view_as_real(x).uniform_(-1, 1, generator=g)
+        plan = commit(n, prec, batch, {"PFFT_TIN_ROWS": "1", "PFFT_ROW_IN_MAX_N": "0"})
+        assert plan.info().dims[0].tier == 3 and plan.info().knob_mask != 0, (n, prec)
+        y = torch.empty_like(x)
+        plan.compute_forward(x, y).wait()
+        for b in sorted({0, batch - 1}):
+            ref = np.fft.fft(x.view(batch, n)[b].cpu().numpy().astype(np.complex128))
+            assert H.rel_l2(y.view(batch, n)[b].cpu().numpy(), ref) <= tol, (n, prec, batch, b)
+        z = torch.empty_like(x)
+        plan.compute_backward(y, z).wait()
+        err = float(((z / n - x).abs().double().pow(2).sum() / x.abs().double().pow(2).sum()).sqrt())
+        assert err <= tol, (n, prec, "round trip", err)
+        y0 = torch.empty_like(x)
+        commit(n, prec, batch, {}).compute_forward(x, y0).wait()
+        diff = float(((y - y0).abs().double().pow(2).sum() / y0.abs().double().pow(2).sum()).sqrt())
+        assert diff <= tol, (n, prec, "against the default plan", diff)
+        del x, y, z, y0, plan
+        torch.cuda.empty_cache()
+
+
+
 def test_committed_descriptor_is_a_snapshot():
     """The reference copies `params` at commit (committed_descriptor_impl.hpp:716-725): changing the user's descriptor
     afterwards -- the common `d.number_of_transforms = ...; d.commit()` pattern -- must not change what an existing plan

@@ -1,11 +1,13 @@
 """Random descriptors against NumPy: rank, lengths (61-smooth), batch, layout (packed / batch-interleaved / unpacked rows /
-strided), storage, placement, offsets, scales, precision, direction.  usage: fuzz.py [seed] [iterations] [big2d|global|regres]
+strided), storage, placement, offsets, scales, precision, direction.  usage: fuzz.py [seed] [iterations] [big2d|global|regres|pairs]
 With `big2d` the shapes are 2-D / 3-D with a long last dimension (256...2048): the two-pass 2-D plan
 (stockham_rows2d.hpp) and its fall-backs.  With `global` the lengths are four-step (GLOBAL tier) sizes: powers of two
 2^15 ... 2^21 (the registered stage pairs), 3 / 5 / 6 / 10 times powers of two, powers of ten, lengths with a prime factor
 37 ... 61 -- packed, both storages, both placements.  With `regres` the lengths are 31-smooth and lie just beyond one
 work-group's LDS (fp32 20481 ... 40000, fp64 10241 ... 20000): the register-resident kernel (stockham_wg_hx.hpp) with
-whatever radices and lanes its planner picks, or the four-step plan where it declines."""
+whatever radices and lanes its planner picks, or the four-step plan where it declines.  With `pairs` they are multiples
+of 16 between 80 and 152 KiB (fp32 10241 ... 19000, fp64 5121 ... 9500): the same kernel planned as two work-groups per CU, or
+the LDS-resident kernel where there is no such plan -- both storages, both placements, offsets, scales."""
 import os, sys, random
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
@@ -42,7 +44,8 @@ def main():
     iters = int(sys.argv[2]) if len(sys.argv) > 2 else 200
     big2d = len(sys.argv) > 3 and sys.argv[3] == "big2d"
     glob = len(sys.argv) > 3 and sys.argv[3] == "global"
-    regres = len(sys.argv) > 3 and sys.argv[3] == "regres"
+    regres = len(sys.argv) > 3 and sys.argv[3] in ("regres", "pairs")
+    pairs = len(sys.argv) > 3 and sys.argv[3] == "pairs"
     rng = random.Random(seed)
     fails = 0
     for it in range(iters):
@@ -57,8 +60,10 @@ def main():
         elif regres:
             rank = 1
             lo, hi = (20481, 40000) if prec == "f32" else (10241, 20000)
+            if pairs:
+                lo, hi = (10241, 19000) if prec == "f32" else (5121, 9500)
             while True:
-                n = 1
+                n = 16 if pairs else 1
                 while n < lo:
                     n *= rng.choice([2, 2, 2, 2, 3, 3, 5, 5, 7, 11, 13, 17, 19, 23, 29, 31])
                 if n <= hi:

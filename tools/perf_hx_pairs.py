@@ -10,15 +10,17 @@ prec, n = sys.argv[1], int(sys.argv[2])
 es = 8 if prec == "f32" else 16
 run("%%s N=%%d %%s" %% (prec, n, sys.argv[3]), [n], max(1, (1 << 30) // (n * es)), prec)
 """ % os.path.join(ROOT, "tools")
-F32 = [8192, 9216, 10000, 10240, 12000, 12288, 13824, 14400, 15000, 15360, 15625, 16000, 16384, 17280, 18000, 18432, 19200, 19683]
-F64 = [4096, 4608, 5000, 5120, 6000, 6144, 6400, 7168, 7680, 8000, 8192]
+F32 = [10240, 11264, 12000, 12288, 13824, 14400, 15360, 16384]
+F64 = [5632, 6144, 6400, 7168, 7680, 8192]
 which = sys.argv[1] if len(sys.argv) > 1 else "all"
 for prec, sizes in (("f32", F32), ("f64", F64)):
     if which not in ("all", prec):
         continue
     for n in sizes:
-        variants = (("lds", {}), ("pair", {"PFFT_JIT_HX_PAIR_MIN_KIB": "60", "PFFT_NO_PRECOMPILED": "1", "PFFT_NO_TUNED_TABLE": "1"}),
-                    ("pair persistent", {"PFFT_JIT_HX_PAIR_MIN_KIB": "60", "PFFT_NO_PRECOMPILED": "1", "PFFT_NO_TUNED_TABLE": "1", "PFFT_JIT_HX_PAIR_GPW": "0"}))
+        # lds: the LDS-resident plan (registered entry / tuned table / static rule); default: what a commit takes today;
+        # pair: the planner's two-per-CU plan whatever the table or the registry hold for the length
+        variants = (("lds", {"PFFT_JIT_HX_PAIRS": "0", "PFFT_NO_REGRES": "1"}), ("default", {}),
+                    ("pair", {"PFFT_JIT_HX_PAIR_MIN_KIB": "60", "PFFT_NO_PRECOMPILED": "1", "PFFT_NO_TUNED_TABLE": "1"}))
         for tag, env in variants:
             e = dict(os.environ, **env)
             p = subprocess.run([sys.executable, "-c", CHILD, prec, str(n), tag], env=e, capture_output=True, text=True)
