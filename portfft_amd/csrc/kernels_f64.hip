@@ -23,7 +23,11 @@ const spec_kernel g_spec_f64[] = {
     // the next transform's 32 in flight (235 VGPRs, no scratch).  tools/tune.hip case 8192064, TB/s at a grid of 2 x resident:
     // LDS-resident 16.8.8.8 5.41, hx 16.16.32 5.40, with the prefetch 5.68, **16.32.16 with the prefetch 6.28**, 32.16.16 5.49-5.76.
     // (the same form for fp32 16384 -- tune case 16387 -- ties the TW_REGS entry: 5.36-5.53 against 5.50)
-    make_spec_entry_hx<wg_cfg<d, radix_list<16, 32, 16>, 512, 1, 16, 1, TW_GLOBAL, 2, NT, 0, 1>, true>(0),  // 8192
+    // ... and then TWO work-groups of 256 lanes per CU (32 values per lane, 205 VGPRs, 76 KiB of LDS each), no prefetch: tune case
+    // 8192065, one transform per work-group: 16.32.16 6.29, 32.16.16 6.10 against 6.13 for the pipelined form on the same box --
+    // and through the library on three other boxes 0.75 against 0.66 ... 0.73 (tools/perf_hx_pairs.py): the pair is the entry,
+    // the pipelined form (stockham_wg_hx_body PF = 1) stays in the tuner
+    make_spec_entry_hx<wg_cfg<d, radix_list<16, 32, 16>, 256, 1, 16, 1, TW_GLOBAL, 2, NT, 0, 1>>(1),  // 8192
     make_spec_entry<wg_cfg_twl<d, radix_list<16, 8, 8, 8>, 512, 1, 16, 1, 2, NT>>(1),   // 8192 (PFFT_NO_REGRES=1, UNPACKED layouts)
     // register-resident form (stockham_wg_hx.hpp; tools/tune.hip case 16384064, TB/s at a grid of 2 x resident): 16.32.32 on
     // 512 lanes 5.93, 16.16.8.8 on 512 / 1024 lanes 5.53 / 5.22, 8.8.16.16 5.53; the four-step plan runs at 3.2

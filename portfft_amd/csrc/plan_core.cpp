@@ -474,9 +474,23 @@ void plan_t::jit_note(const char* what, long long n, const std::string& why) con
 
 /// the pre-compiled packed kernel, otherwise a runtime-specialised one
 const spec_kernel* plan_t::get_spec(long long n) {
-  if (const spec_kernel* k = find_spec(n)) return k;
   std::string why;
   const bool split = desc.complex_storage == PFFT_SPLIT_COMPLEX;
+  // 80 ... 152 KiB: where the register-resident planner has a two-work-groups-per-CU plan it goes before a registered or
+  // tuned LDS-resident kernel of the length (one work-group per CU) -- tools/perf_hx_pairs.py: fp32 12288 0.49 -> 0.62,
+  // 13824 0.52 -> 0.64, 14400 0.48 -> 0.60, 15360 0.52 -> 0.66, fp64 6144 0.56 -> 0.72, 6400 0.52 -> 0.67.  (A plan whose kernel
+  // does not fit its register budget hands the length back: jit_spec_kernel.)
+  if (!kn.no_regres && jit_enabled() && !kn.jit_spec_radices) {
+    wg_params q;
+    if (choose_hx_params(desc.precision, n, max_lds, &q) && q.hx_pair != 0) {
+      const spec_kernel* reg = find_spec(n);
+      if (reg != nullptr && reg->hx != 0) return reg;  // a registered register-resident entry is such a plan already
+      if (const spec_kernel* k = jit_spec_kernel(desc.precision, n, split, max_lds, &why, false, nullptr, true); k != nullptr && k->hx != 0) {
+        return k;
+      }
+    }
+  }
+  if (const spec_kernel* k = find_spec(n)) return k;
   if (plan_measure_enabled() && jit_enabled() && !kn.jit_spec_radices) {
     const std::vector<int> choice = measured_radices(n);
     if (!choice.empty()) {

@@ -601,15 +601,16 @@ def test_fused_multidimensional():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("prec,n", [("f32", 32768), ("f64", 16384), ("f64", 8192), ("f32", 24576), ("f32", 30000), ("f64", 12000),
-                                    ("f64", 15000)])
+                                    ("f64", 15000), ("f32", 16384), ("f32", 15360), ("f32", 11264), ("f64", 6144), ("f64", 7680)])
 def test_register_resident_lengths(prec, n):
     """The 256 KiB transforms that stay in the registers of one work-group for all their passes, one HBM pass
     (stockham_wg_hx.hpp): fp32 32768, the reference's first GlobalTest size, and fp64 16384, its largest
     WorkgroupOrGlobal size (instantiate_fft_tests.hpp:140-151) -- registered kernels -- and lengths whose kernel is planned
     (jit.cpp choose_hx_params: any radices, ragged passes) and compiled at commit.  Against NumPy on every layout the packed kernels
     serve -- both placements, both storages, both directions, offsets and scales, ragged batches -- and against the
-    plan the same descriptor gets with PFFT_NO_REGRES=1 (four-step; for fp64 8192, whose register-resident entry is the
-    software-pipelined form, the LDS-resident kernel): another algorithm, equal within the tolerance."""
+    plan the same descriptor gets with PFFT_NO_REGRES=1 (four-step): another algorithm, equal within the tolerance.
+    Transforms of 80 ... 152 KiB (fp32 16384 and fp64 8192 registered, the others planned) run the same kernel as TWO
+    work-groups per CU; they fit the LDS, so their twin is the LDS-resident kernel of the length."""
     import gpu_utils as G
     pf = _pf()
     dtype = np.complex64 if prec == "f32" else np.complex128
@@ -620,9 +621,10 @@ def test_register_resident_lengths(prec, n):
     os.environ["PFFT_NO_REGRES"] = "1"
     try:
         twin = G.make_descriptor([n], prec, batch=3).commit()
-        if (prec, n) == ("f64", 8192):  # (fits the LDS: its twin is the LDS-resident kernel; the entry is the software-pipelined form)
-            assert twin.info().dims[0].tier == 1 and list(twin.info().dims[0].factors[:4]) == [16, 8, 8, 8]
-            assert list(info.dims[0].factors[:3]) == [16, 32, 16]
+        if n * (8 if prec == "f32" else 16) <= 152 * 1024:  # a pair: it fits the LDS, the twin is the LDS-resident kernel
+            assert twin.info().dims[0].tier == 1 and twin.info().dims[0].lds_bytes > 80 * 1024
+            assert info.dims[0].lds_bytes <= 80 * 1024 and info.dims[0].workgroup_size <= 512, "two work-groups per CU"
+            assert info.dims[0].factors[0] in (16, 32) and info.dims[0].n_factors == 3
         else:
             assert twin.info().dims[0].tier == 3 and min(twin.info().launches) >= 2
     finally:

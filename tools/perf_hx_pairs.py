@@ -10,8 +10,8 @@ prec, n = sys.argv[1], int(sys.argv[2])
 es = 8 if prec == "f32" else 16
 run("%%s N=%%d %%s" %% (prec, n, sys.argv[3]), [n], max(1, (1 << 30) // (n * es)), prec)
 """ % os.path.join(ROOT, "tools")
-F32 = [10240, 11264, 12000, 12288, 13824, 14400, 15360, 16384]
-F64 = [5632, 6144, 6400, 7168, 7680, 8192]
+F32 = [10240, 10752, 11264, 11520, 12000, 12288, 12800, 13312, 13824, 14336, 14400, 14848, 15360, 15872, 16384]
+F64 = [5376, 5632, 5760, 6144, 6400, 6656, 6912, 7168, 7424, 7680, 7936, 8192]
 which = sys.argv[1] if len(sys.argv) > 1 else "all"
 for prec, sizes in (("f32", F32), ("f64", F64)):
     if which not in ("all", prec):
@@ -19,8 +19,9 @@ for prec, sizes in (("f32", F32), ("f64", F64)):
     for n in sizes:
         # lds: the LDS-resident plan (registered entry / tuned table / static rule); default: what a commit takes today;
         # pair: the planner's two-per-CU plan whatever the table or the registry hold for the length
-        variants = (("lds", {"PFFT_JIT_HX_PAIRS": "0", "PFFT_NO_REGRES": "1"}), ("default", {}),
-                    ("pair", {"PFFT_JIT_HX_PAIR_MIN_KIB": "60", "PFFT_NO_PRECOMPILED": "1", "PFFT_NO_TUNED_TABLE": "1"}))
+        variants = (("lds", {"PFFT_JIT_HX_PAIRS": "0", "PFFT_NO_REGRES": "1"}), ("default", {}))
+        if len(sys.argv) > 2 and sys.argv[2] == "forced":
+            variants += (("pair", {"PFFT_JIT_HX_PAIR_MIN_KIB": "60", "PFFT_NO_PRECOMPILED": "1", "PFFT_NO_TUNED_TABLE": "1"}),)
         for tag, env in variants:
             e = dict(os.environ, **env)
             p = subprocess.run([sys.executable, "-c", CHILD, prec, str(n), tag], env=e, capture_output=True, text=True)
