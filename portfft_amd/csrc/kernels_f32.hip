@@ -34,7 +34,9 @@ const spec_kernel g_spec_f32[] = {
     // tools/tune.hip case 32768, TB/s at a grid of 2 x resident / one transform per work-group: 1024 lanes x 32 points
     // 5.19 / 4.92, 512 lanes x 64 points 4.55 / 4.56, four passes (16.16.16.8, 8.16.16.16) 4.0-4.6; the two-launch
     // four-step plan of this length runs at 3.2
-    make_spec_entry_hx<wg_cfg<f, radix_list<32, 32, 32>, 1024, 1, 32, 1, TW_GLOBAL, 4, NT, 0, 1>>(0),  // 32768
+    // (grid: four transforms per work-group -- bench.py g32_15 0.589 with the persistent 2 x resident grid, 0.606 / 0.605 / 0.594 with
+    //  4 / 2 / 1 per work-group, profiles/r5_hx_grid_rule.txt; the planned lengths of the band prefer the persistent grid)
+    make_spec_entry_hx<wg_cfg<f, radix_list<32, 32, 32>, 1024, 1, 32, 1, TW_GLOBAL, 4, NT, 0, 1>>(4),  // 32768
     // 3 * 2^k and 5 * 2^k families, powers of ten
     make_spec_entry<wg_cfg_twl<f, radix_list<12, 8>, 256, 32, 0, 0, 4, NT, 1>>(),       // 96
     make_spec_entry<wg_cfg_twl<f, radix_list<16, 12>, 256, 16, 16, 1, 4, NT, 1>>(),      // 192 (LDS-staged I/O: 5.96 vs 5.64)

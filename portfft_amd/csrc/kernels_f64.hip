@@ -31,7 +31,8 @@ const spec_kernel g_spec_f64[] = {
     make_spec_entry<wg_cfg_twl<d, radix_list<16, 8, 8, 8>, 512, 1, 16, 1, 2, NT>>(1),   // 8192 (PFFT_NO_REGRES=1, UNPACKED layouts)
     // register-resident form (stockham_wg_hx.hpp; tools/tune.hip case 16384064, TB/s at a grid of 2 x resident): 16.32.32 on
     // 512 lanes 5.93, 16.16.8.8 on 512 / 1024 lanes 5.53 / 5.22, 8.8.16.16 5.53; the four-step plan runs at 3.2
-    make_spec_entry_hx<wg_cfg<d, radix_list<16, 32, 32>, 512, 1, 16, 1, TW_GLOBAL, 2, NT, 0, 1>>(0),  // 16384
+    // (grid: four transforms per work-group -- bench.py g64_14 0.615 persistent, 0.651-0.653 with 8 / 4 / 2 per work-group)
+    make_spec_entry_hx<wg_cfg<d, radix_list<16, 32, 32>, 512, 1, 16, 1, TW_GLOBAL, 2, NT, 0, 1>>(4),  // 16384
     make_spec_entry<wg_cfg<d, radix_list<12, 8>, 256, 32, 0, 0, TW_GLOBAL, 2, NT, 1>>(),  // 96 (TWL loses 8 % here)
     make_spec_entry<wg_cfg_twl<d, radix_list<16, 12>, 256, 16, 16, 1, 2, NT>>(),         // 192
     make_spec_entry<wg_cfg_twl<d, radix_list<8, 8, 6>, 256, 4, 16, 1, 2, NT>>(),         // 384

@@ -6,8 +6,8 @@ set -u
 cd "$GRAFT_REPO_ROOT" || exit 1
 export TMPDIR=/tmp
 out=gpurun_out/final_r5; mkdir -p $out
-ALL="c3 c5 ref16 ref256 ref4096 ref65536 ref9800 ref15360 ref68640 g32_15 g32_17 g32_18 g32_19 g32_20 g32_21 g32_22 g32_24 g64_13 g64_14 g64_16 g64_17 g64_18"
-PMC="c2 c3 c5 ref16 ref256 ref4096 ref65536 ref9800 ref15360 ref68640 g32_15 g32_17 g32_18 g32_19 g32_20 g32_21 g32_22 g32_24 g64_13 g64_14 g64_16 g64_17 g64_18"
+ALL="c3 c5 ref16 ref256 ref4096 ref65536 ref9800 ref15360 ref68640 g32_14 g32_15 g32_17 g32_18 g32_19 g32_20 g32_21 g32_22 g32_24 g64_13 g64_14 g64_16 g64_17 g64_18"
+PMC="c2 c3 c5 ref16 ref256 ref4096 ref65536 ref9800 ref15360 ref68640 g32_14 g32_15 g32_17 g32_18 g32_19 g32_20 g32_21 g32_22 g32_24 g64_13 g64_14 g64_16 g64_17 g64_18"
 # ONLY_PMC="cfg ...": only the PMC passes and summaries of those configs (bench lines of them are refreshed too)
 if [ -n "${ONLY_PMC:-}" ]; then PMC="$ONLY_PMC"; fi
 if [ -z "${ONLY_PMC:-}" ]; then
@@ -38,7 +38,8 @@ sum c3 stockham_strided 4294967296 8 "C3 fp64 N=2^20 x 128: four-step, 8 chunks 
 sum c5 stockham_rows2d,stockham_strided 4294967296 8 "C5 fp32 1024x1024 x 256: two-pass 2-D plan, 8 chunks of 256 MiB"
 sum ref65536 stockham_xcd_fourstep 2147483648 1 "fp32 N=65536 x 2048: XCD-local single launch (256 x 256), slot rings of 24 transforms per XCD"
 sum g32_15 stockham_wg_hx 2147483648 1 "fp32 N=32768 x 4096: register-resident work-group kernel (32.32.32 on 1024 lanes), one launch"
-sum g64_13 stockham_wg_hx 2147483648 1 "fp64 N=8192 x 8192: register-resident, software-pipelined work-group kernel (16.32.16 on 512 lanes), one launch"
+sum g32_14 stockham_wg_hx 2147483648 1 "fp32 N=16384 x 8192: register-resident work-group kernel, two work-groups per CU (32.32.16 on 512 lanes), one launch"
+sum g64_13 stockham_wg_hx 2147483648 1 "fp64 N=8192 x 8192: register-resident work-group kernel, two work-groups per CU (16.32.16 on 256 lanes), one launch"
 sum g64_14 stockham_wg_hx 2147483648 1 "fp64 N=16384 x 4096: register-resident work-group kernel (16.32.32 on 512 lanes), one launch"
 sum ref16 stockham_wg 2147483648 1 "reference bench set: fp32 N=16 x 8Mi, one launch"
 sum ref256 stockham_wg 2147483648 1 "reference bench set: fp32 N=256 x 512Ki, one launch"
@@ -51,7 +52,7 @@ sum g32_21 stockham_strided 2147483648 4 "fp32 N=2^21 x 64: four-step (1024 x 20
 sum g32_22 stockham_strided 2147483648 4 "fp32 N=2^22 x 32: four-step, 4 chunks of 256 MiB"
 sum g32_24 stockham_strided 2147483648 1 "fp32 N=2^24 x 8: three stages (256 x 256 x 256): 4 + 4 chunked launches of stages 1-2, one launch of stage 3"
 sum ref9800 stockham_wg 2147483648 1 "fp32 N=9800 x 13312: one launch (tuned table: 7.8.7.5.5)"
-sum ref15360 stockham_wg 2147483648 1 "fp32 N=15360 x 8704: one launch (tuned table: 24.32.20)"
+sum ref15360 stockham_wg_hx 2147483648 1 "fp32 N=15360 x 8704: register-resident work-group kernel planned at commit, two work-groups per CU (32.30.16 on 512 lanes), one launch"
 sum ref68640 stockham_strided 2147483648 4 "fp32 N=68640 x 1920: four-step (104 x 660, tuned table), 4 chunks of 256 MiB"
 sum g64_16 stockham_xcd_fourstep 2147483648 1 "fp64 N=65536 x 1024: XCD-local single launch (256 x 256), slot rings of 16 transforms per XCD"
 sum g64_17 stockham_xcd_fourstep 2147483648 1 "fp64 N=2^17 x 512: XCD-local single launch (256 x 512), slot rings of 16 transforms per XCD"
