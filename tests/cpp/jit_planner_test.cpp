@@ -141,7 +141,8 @@ int main(int argc, char** argv) {
     EXPECT(!pfa::choose_hx_params(0, 40960, max_lds, &p0) , "40960: 80 values per lane do not pay");
     pfa::wg_params p;
     // 80 ... 152 KiB: TWO register-resident work-groups per CU (half the LDS, half the registers each), three passes
-    // behind a padded power-of-two first radix -- or the packed planner's LDS-resident kernel
+    // behind a first radix >= 15 with a conflict-free scatter (odd, or even and padded with its own period) -- or the
+    // packed planner's LDS-resident kernel
     long long pairs[2] = {0, 0};
     for (int prec = 0; prec < 2; ++prec) {
       const int es = prec ? 16 : 8;
@@ -150,17 +151,17 @@ int main(int argc, char** argv) {
         if (!pfa::choose_hx_params(prec, n, max_lds, &q)) continue;
         ++pairs[prec];
         EXPECT(static_cast<size_t>(n) * es > 80 * 1024 && q.hx_pair == 1, "hx pair n=%lld", n);
-        EXPECT(q.radices.size() <= 3 && q.radices[0] >= 16 && (q.radices[0] & (q.radices[0] - 1)) == 0 && q.pads == q.radices[0],
-               "hx pair n=%lld: padded power-of-two first radix, three passes", n);
+        EXPECT(q.radices.size() <= 3 && q.radices[0] >= 15 && q.pads == (q.radices[0] % 2 == 0 ? q.radices[0] : 0),
+               "hx pair n=%lld: three passes, an even first radix padded", n);
         EXPECT(q.wg >= 256 && q.wg <= 512 && q.wg % 64 == 0 && 2 * pfa::hx_lds_bytes(q) <= max_lds, "hx pair n=%lld: lanes %d", n, q.wg);
         const int budget = 512 / ((2 * (q.wg / 64) + 3) / 4);
         EXPECT(q.regs * (prec ? 4 : 2) < budget && q.occ == (2 * (q.wg / 64) + 3) / 4, "hx pair n=%lld: %d values per lane", n, q.regs);
       }
     }
     std::printf("hx planner: %lld fp32 and %lld fp64 lengths as pairs\n", pairs[0], pairs[1]);
-    EXPECT(pairs[0] > 20 && pairs[1] > 10, "hx pair coverage");
+    EXPECT(pairs[0] > 100 && pairs[1] > 50, "hx pair coverage");
     EXPECT(pfa::choose_hx_params(0, 16384, max_lds, &p) && p.hx_pair == 1 && p.wg == 512, "fp32 16384: two work-groups per CU");
-    EXPECT(!pfa::choose_hx_params(0, 16000, max_lds, &p), "fp32 16000: no three-pass pair plan, LDS-resident");
+    EXPECT(!pfa::choose_hx_params(0, 18000, max_lds, &p), "fp32 18000: no three-pass pair plan, LDS-resident");
     EXPECT(!pfa::choose_hx_params(0, 8192, max_lds, &p), "fp32 8192: the LDS-resident kernel has two work-groups per CU itself");
     EXPECT(pfa::choose_hx_params(0, 20480, max_lds, &p), "fp32 20480: the top of the LDS range goes register-resident");
     EXPECT(!pfa::choose_hx_params(1, 10240, max_lds, &p), "fp64 10240 stays LDS-resident");

@@ -10,8 +10,8 @@ prec, n = sys.argv[1], int(sys.argv[2])
 es = 8 if prec == "f32" else 16
 run("%%s N=%%d %%s" %% (prec, n, sys.argv[3]), [n], max(1, (1 << 30) // (n * es)), prec)
 """ % os.path.join(ROOT, "tools")
-F32 = [10240, 10752, 11264, 11520, 12000, 12288, 12800, 13312, 13824, 14336, 14400, 14848, 15360, 15872, 16384]
-F64 = [5376, 5632, 5760, 6144, 6400, 6656, 6912, 7168, 7424, 7680, 7936, 8192]
+F32 = [10500, 10935, 11000, 11250, 11520, 11664, 12150, 12500, 13000, 13125, 13500, 14000, 14580, 15000, 15120, 15625, 16000, 16200]
+F64 = [5250, 5400, 5500, 5625, 5832, 6000, 6250, 6480, 6561, 6750, 7000, 7290, 7500, 7776, 8000]
 which = sys.argv[1] if len(sys.argv) > 1 else "all"
 for prec, sizes in (("f32", F32), ("f64", F64)):
     if which not in ("all", prec):
