@@ -56,7 +56,7 @@ WORKLOADS = {
     # beyond them, 1 GiB per buffer
     "g32_15": ([32768], 4096, "f32", "fp32 N=32768 batch=4Ki (reference GlobalTest size): register-resident work-group kernel", 1),
     "g32_14": ([16384], 8192, "f32", "fp32 N=16384 batch=8Ki: register-resident work-group kernel, two work-groups per CU", 1),
-    "g64_13": ([8192], 8192, "f64", "fp64 N=8192 batch=8Ki (reference WorkgroupOrGlobal size): register-resident, software-pipelined work-group kernel", 1),
+    "g64_13": ([8192], 8192, "f64", "fp64 N=8192 batch=8Ki (reference WorkgroupOrGlobal size): register-resident work-group kernel, two work-groups per CU", 1),
     "g64_14": ([16384], 4096, "f64", "fp64 N=16384 batch=4Ki (reference WorkgroupOrGlobal size): register-resident work-group kernel", 1),
     "g32_17": ([131072], 1024, "f32", "fp32 four-step N=131072 batch=1Ki (reference GlobalTest size)", 2),
     "g32_18": ([1 << 18], 512, "f32", "fp32 four-step N=2^18 batch=512", 2),

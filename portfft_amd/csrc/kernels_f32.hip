@@ -45,7 +45,10 @@ const spec_kernel g_spec_f32[] = {
     make_spec_entry<wg_cfg_twl<f, radix_list<16, 12, 8>, 256, 2, 16, 1, 4, NT>>(),       // 1536
     make_spec_entry<wg_cfg_twl<f, radix_list<16, 16, 12>, 256, 1, 16, 1, 4, NT>>(),      // 3072
     make_spec_entry<wg_cfg_twl<f, radix_list<24, 16, 16>, 256, 1, 16, 1, 2, NT>>(),      // 6144
-    make_spec_entry<wg_cfg_twl<f, radix_list<32, 24, 16>, 512, 1, 16, 1, 2, NT>>(),      // 12288
+    // 12288 (96 KiB): the planner's two-per-CU register-resident plan (choose_hx_params), pre-compiled so that the length keeps its
+    // instant commit -- 0.49 -> 0.62 of the HBM peak (tools/perf_hx_pairs.py)
+    make_spec_entry_hx<wg_cfg<f, radix_list<32, 24, 16>, 512, 1, 32, 1, TW_GLOBAL, 4, NT, 0, 1>>(1),  // 12288
+    make_spec_entry<wg_cfg_twl<f, radix_list<32, 24, 16>, 512, 1, 16, 1, 2, NT>>(),      // 12288 (PFFT_NO_REGRES=1, UNPACKED layouts)
     make_spec_entry<wg_cfg_twl<f, radix_list<10, 8>, 256, 32, 0, 0, 4, NT, 1>>(),       // 80
     make_spec_entry<wg_cfg_twl<f, radix_list<10, 10>, 250, 25, 0, 0, 4, NT, 1>>(),      // 100
     make_spec_entry<wg_cfg_twl<f, radix_list<16, 10>, 256, 16, 0, 0, 4, NT, 1>>(),       // 160

@@ -39,7 +39,9 @@ const spec_kernel g_spec_f64[] = {
     make_spec_entry<wg_cfg_twl<d, radix_list<16, 8, 6>, 256, 4, 16, 1, 2, NT>>(),        // 768
     make_spec_entry<wg_cfg_twl<d, radix_list<16, 12, 8>, 256, 2, 16, 1, 2, NT>>(),       // 1536
     make_spec_entry<wg_cfg_twl<d, radix_list<16, 16, 12>, 256, 1, 16, 1, 2, NT>>(),      // 3072
-    make_spec_entry<wg_cfg_twl<d, radix_list<12, 8, 8, 8>, 768, 1, 0, 0, 2, NT>>(),      // 6144
+    // 6144 (96 KiB): the planner's two-per-CU register-resident plan, pre-compiled -- 0.56 -> 0.72
+    make_spec_entry_hx<wg_cfg<d, radix_list<32, 24, 8>, 256, 1, 32, 1, TW_GLOBAL, 2, NT, 0, 1>>(1),  // 6144
+    make_spec_entry<wg_cfg_twl<d, radix_list<12, 8, 8, 8>, 768, 1, 0, 0, 2, NT>>(),      // 6144 (PFFT_NO_REGRES=1, UNPACKED layouts)
     make_spec_entry<wg_cfg_twl<d, radix_list<10, 8>, 256, 32, 0, 0, 2, NT, 1>>(),       // 80
     make_spec_entry<wg_cfg_twl<d, radix_list<10, 10>, 250, 25, 0, 0, 2, NT, 1>>(),      // 100
     make_spec_entry<wg_cfg_twl<d, radix_list<10, 10, 10>, 200, 2, 0, 0, 2, NT>>(),      // 1000
