@@ -199,6 +199,16 @@ int main() {
   add_hx<wg_cfg<d, radix_list<32, 16, 16>, 256, 1, 32, 1, TW_GLOBAL, 2, NT, 0, 1>>("f64 hx 32.16.16 wg256 occ2");
   add_hx<wg_cfg<d, radix_list<16, 32, 16>, 256, 1, 16, 1, TW_GLOBAL, 2, NT, 0, 1>>("f64 hx 16.32.16 wg256 occ2");
   add_hx_pf<wg_cfg<d, radix_list<16, 32, 16>, 512, 1, 16, 1, TW_GLOBAL, 4, NT, 0, 1>, 2>("f64 hx 16.32.16 wg512 occ4 DMA");
+#elif TUNE_CASE == 8192066  // fp64 8192 pair: padding of the 128-bit exchange image (21 % conflict cycles with period 16)
+  using T = d; const int N = 8192;
+  add_hx<wg_cfg<d, radix_list<16, 32, 16>, 256, 1, 16, 1, TW_GLOBAL, 2, NT, 0, 1>>("f64 hx 16.32.16 wg256 pad 16/1 (production)");
+  add_hx<wg_cfg<d, radix_list<16, 32, 16>, 256, 1, 16, 2, TW_GLOBAL, 2, NT, 0, 1>>("f64 hx 16.32.16 wg256 pad 16/2");
+  add_hx<wg_cfg<d, radix_list<16, 32, 16>, 256, 1, 32, 1, TW_GLOBAL, 2, NT, 0, 1>>("f64 hx 16.32.16 wg256 pad 32/1");
+  add_hx<wg_cfg<d, radix_list<16, 32, 16>, 256, 1, 8, 1, TW_GLOBAL, 2, NT, 0, 1>>("f64 hx 16.32.16 wg256 pad 8/1");
+  add_hx<wg_cfg<d, radix_list<16, 32, 16>, 256, 1, 0, 0, TW_GLOBAL, 2, NT, 0, 1>>("f64 hx 16.32.16 wg256 no pad");
+  add_hx<wg_cfg<d, radix_list<32, 16, 16>, 256, 1, 32, 1, TW_GLOBAL, 2, NT, 0, 1>>("f64 hx 32.16.16 wg256 pad 32/1");
+  add_hx<wg_cfg<d, radix_list<32, 16, 16>, 256, 1, 32, 2, TW_GLOBAL, 2, NT, 0, 1>>("f64 hx 32.16.16 wg256 pad 32/2");
+  add_hx<wg_cfg<d, radix_list<32, 16, 16>, 256, 1, 16, 1, TW_GLOBAL, 2, NT, 0, 1>>("f64 hx 32.16.16 wg256 pad 16/1");
 #elif TUNE_CASE == 12000  // fp32 12000 (96 KB): LDS-resident planner choice against register-resident forms, two work-groups per CU
   using T = f; const int N = 12000;
   add<wg_cfg<f, radix_list<30, 20, 20>, 640, 1, 0, 0, TW_GLOBAL, 2, NT, 0, 1>, false>("r30.20.20 wg640 lds");
