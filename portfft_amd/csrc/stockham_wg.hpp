@@ -91,7 +91,7 @@ struct wg_cfg {
 };
 
 /// The TWL a kernel should use: the most leading passes whose tables fit 16 KiB of LDS without pushing the CU below
-/// 16 resident waves (or below what it had).  Same rule as the runtime planner (jit.cpp); measured in
+/// 16 resident waves (or below what it had).  Same rule as the runtime planner (jit_planner.cpp); measured in
 /// profiles/r1_notes.md.
 template <typename T, typename Seq, int WG, int FPW, int PADS, int PADW, int STAGED = 0>
 constexpr int auto_twl() {

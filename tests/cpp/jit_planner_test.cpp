@@ -1,4 +1,4 @@
-// Runtime-specialisation planner (portfft_amd/csrc/jit.cpp) on the host: invariants of the chosen kernel
+// Runtime-specialisation planner (portfft_amd/csrc/jit_planner.cpp) on the host: invariants of the chosen kernel
 // parameters for every length, and hiprtc compilation of a few of them for gfx950 (no device needed).
 #include <algorithm>
 #include <cstdio>
@@ -19,7 +19,7 @@ static int fails = 0;
     }                                  \
   } while (0)
 
-/// prime factors up to the wavefront size (jit.cpp: jit_max_prime)
+/// prime factors up to the wavefront size (jit_planner.cpp: jit_max_prime)
 static bool smooth31(long long n) {
   for (int p = 2; p <= 61; ++p) {
     while (n % p == 0) n /= p;

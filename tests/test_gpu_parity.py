@@ -261,7 +261,7 @@ def test_strided_workgroup_tier(prec, oracle):
 def test_long_transforms_in_strided_layouts(prec):
     """Strided / batch-interleaved transforms longer than HALF the LDS (fp32 10 241 ... 20 480 points, fp64 5121 ... 10 240):
     the generic tier needs two images and the four-step plan takes packed data only, so the strided work-group kernel
-    runs them one transform per work-group (jit.cpp choose_strided_params, fpw = 1).  Found by tools/fuzz.py seed 61
+    runs them one transform per work-group (jit_planner.cpp choose_strided_params, fpw = 1).  Found by tools/fuzz.py seed 61
     (profiles/r5_fuzz_61_150.txt): 11780 / 12464 (fp32) and 5610 (fp64) used to be `unsupported_configuration` inside
     the documented limits."""
     import gpu_utils as G
@@ -606,7 +606,7 @@ def test_register_resident_lengths(prec, n):
     """The 256 KiB transforms that stay in the registers of one work-group for all their passes, one HBM pass
     (stockham_wg_hx.hpp): fp32 32768, the reference's first GlobalTest size, and fp64 16384, its largest
     WorkgroupOrGlobal size (instantiate_fft_tests.hpp:140-151) -- registered kernels -- and lengths whose kernel is planned
-    (jit.cpp choose_hx_params: any radices, ragged passes) and compiled at commit.  Against NumPy on every layout the packed kernels
+    (jit_planner.cpp choose_hx_params: any radices, ragged passes) and compiled at commit.  Against NumPy on every layout the packed kernels
     serve -- both placements, both storages, both directions, offsets and scales, ragged batches -- and against the
     plan the same descriptor gets with PFFT_NO_REGRES=1 (four-step): another algorithm, equal within the tolerance.
     Transforms of 80 ... 152 KiB (fp32 16384 and fp64 8192 registered, the others planned) run the same kernel as TWO

@@ -1,4 +1,4 @@
-"""Runtime specialisation (portfft_amd/csrc/jit.cpp): the planner's invariants for every length up to 20000 in both
+"""Runtime specialisation (portfft_amd/csrc/jit_planner.cpp, jit.cpp): the planner's invariants for every length up to 20000 in both
 precisions, and -- without a GPU -- hiprtc compilation of the embedded kernel headers for gfx950."""
 import os
 import shutil
