@@ -29,11 +29,7 @@ namespace {
 /// generic tier's "big radix" kernel (tools/perf_primes.py): fp32 N = 37 1.6 -> 5.0 TB/s, 61 1.3 -> 3.3, 37 * 64
 /// 1.0 -> 4.3, 59 * 59 0.9 -> 2.3, fp64 37 * 64 0.7 -> 2.9.
 static int jit_max_prime() {
-  static const int v = [] {
-    const char* e = getenv("PFFT_JIT_MAX_PRIME");
-    const int x = e != nullptr ? atoi(e) : 61;
-    return x < 2 ? 2 : (x > 61 ? 61 : x);
-  }();
+  static const int v = jit_knobs::from_env().max_prime;
   return v;
 }
 #define JIT_MAX_PRIME jit_max_prime()
@@ -208,10 +204,7 @@ std::vector<std::vector<int>> spec_radix_candidates(int precision, long long n, 
   return out;
 }
 
-bool plan_measure_enabled() {
-  const char* e = getenv("PFFT_PLAN_MEASURE");
-  return e != nullptr && std::atoi(e) != 0;
-}
+bool plan_measure_enabled() { return jit_knobs::from_env().plan_measure; }
 
 bool choose_spec_params(int precision, long long n, size_t max_lds, wg_params* out,
                         const std::vector<int>* forced_radices) {
@@ -249,7 +242,8 @@ bool choose_spec_params(int precision, long long n, size_t max_lds, wg_params* o
   if (!forced_ok || forced_tpf < 1 || forced_tpf > 1024) forced_tpf = 0;
   // planner experiments (tools/jit_sweep_radices.py): PFFT_JIT_SPEC_RADICES=n:r0xr1x... forces the radix sequence
   bool env_radices = false;
-  if (const char* e = getenv("PFFT_JIT_SPEC_RADICES")) {
+  const jit_knobs kn = jit_knobs::from_env();
+  if (const char* e = kn.spec_radices) {
     long long fn = 0;
     char rad[64] = {0};
     if (std::sscanf(e, "%lld:%63[0-9x]", &fn, rad) == 2 && fn == n) {
@@ -272,13 +266,11 @@ bool choose_spec_params(int precision, long long n, size_t max_lds, wg_params* o
   // 976 = 16 x 61 0.27 -> 0.48, 1696 = 32 x 53 0.34 -> 0.51, 2021 = 47 x 43 0.275 -> 0.41, 3481 = 59 x 59 0.33 -> 0.38,
   // 2368 = 37 x 8 x 8 0.59 -> 0.62; prime first / last and 8 ... 128 lanes swept.
   int prime_tpf = 0;
-  if (p.radices.size() >= 2 && !env_radices && !forced_ok &&
-      getenv("PFFT_NO_PRIME_LANES") == nullptr) {
+  if (p.radices.size() >= 2 && !env_radices && !forced_ok && !kn.no_prime_lanes) {
     int big = 0;
     for (int r : p.radices) big = std::max(big, r);
     const long long nb = n / std::max(big, 1);
-    int prime_min = 37;
-    if (const char* e = getenv("PFFT_PRIME_LANES_MIN")) prime_min = std::atoi(e);  // experiments
+    const int prime_min = kn.prime_lanes_min;  // (experiments: PFFT_PRIME_LANES_MIN)
     if (big >= prime_min && is_prime_i(big) && nb >= 16 && nb <= 64) {  // (beyond 64 the planner's own lanes keep one butterfly per lane)
       int t = 16;
       while (t < nb && t < 64) t *= 2;
@@ -334,7 +326,7 @@ bool choose_spec_params(int precision, long long n, size_t max_lds, wg_params* o
   //  are 7 % faster than on 64, 37 x 8 x 8 5 % slower)
   int force_tpf = (prime_tpf > 0 && !(lc.tpf == 2 * prime_tpf && prime_tpf == 64)) ? prime_tpf : 0;
   if (forced_tpf > 0) force_tpf = forced_tpf;
-  if (const char* e = getenv("PFFT_JIT_FORCE_TPF")) force_tpf = std::atoi(e);  // tools/jit_sweep.py: force the lanes per FFT
+  if (kn.force_tpf != 0) force_tpf = kn.force_tpf;  // tools/jit_sweep.py (PFFT_JIT_FORCE_TPF): force the lanes per FFT
   {
     const int t = force_tpf;
     if (t > 0 && t <= 1024) {
@@ -386,7 +378,7 @@ bool choose_spec_params(int precision, long long n, size_t max_lds, wg_params* o
   // profiles/r1_notes.md): N=1280 (16.10.8) +5 %, 1920 (16.12.10) +4-10 %, 384 (8.8.6) +3 %; with other first
   // radices the same padding costs 10-35 % (N=3000, 5120, 6000: non-linear addresses), and a period equal to the
   // first radix changes nothing.
-  if (const char* e = getenv("PFFT_JIT_FORCE_PAD")) {  // tools/jit_sweep.py: force the padding period
+  if (const char* e = kn.force_pad) {  // tools/jit_sweep.py (PFFT_JIT_FORCE_PAD): force the padding period
     p.pads = std::atoi(e);
     p.padw = p.pads > 0 ? 1 : 0;
     fit_fpw();
@@ -410,26 +402,18 @@ bool choose_spec_params(int precision, long long n, size_t max_lds, wg_params* o
 
 /// transforms of more than this many bytes take the register-resident form when it plans (default: what does not fit
 /// the LDS; PFFT_JIT_HX_MIN_KIB: experiments with the lengths below, tools/perf_hx.py)
-static size_t hx_min_bytes(size_t max_lds, int precision) {
-  if (const char* e = getenv("PFFT_JIT_HX_MIN_KIB")) return static_cast<size_t>(std::atol(e)) << 10;
+static size_t hx_min_bytes(const jit_knobs& kn, size_t max_lds, int precision) {
+  if (kn.hx_min_kib >= 0) return static_cast<size_t>(kn.hx_min_kib) << 10;
   // Below the LDS limit the two forms are within +-5 % of each other (tools/perf_hx_below.py: fp32 8000 ... 19683, fp64
   // 5000 ... 10240) -- except at the very top in fp32, where the LDS-resident kernel has the CU's whole LDS and nothing
   // else: 20480 0.425 -> 0.52 of the HBM peak, 19683 0.43 -> 0.45
   return precision == PFFT_PRECISION_F32 ? std::min<size_t>(max_lds, 152 * 1024) : max_lds;
 }
 
-/// PFFT_JIT_HX_PAIRS=0: no two-work-groups-per-CU plans of the register-resident kernel (experiments)
-static bool hx_pairs_enabled() {
-  const char* e = getenv("PFFT_JIT_HX_PAIRS");
-  return !(e != nullptr && e[0] == '0');
-}
-
 /// transforms of more than this many bytes (and no more than hx_min_bytes) are planned as two register-resident
-/// work-groups per CU; PFFT_JIT_HX_PAIR_MIN_KIB (experiments, tools/perf_hx_pairs.py)
-static size_t hx_pair_min_bytes() {
-  if (const char* e = getenv("PFFT_JIT_HX_PAIR_MIN_KIB")) return static_cast<size_t>(std::atol(e)) << 10;
-  return 80 * 1024;  // (up to 80 KiB the LDS-resident kernel has two work-groups per CU itself)
-}
+/// work-groups per CU (PFFT_JIT_HX_PAIRS=0: never; PFFT_JIT_HX_PAIR_MIN_KIB: experiments, tools/perf_hx_pairs.py).
+/// Default 80 KiB: up to there the LDS-resident kernel has two work-groups per CU itself.
+static size_t hx_pair_min_bytes(const jit_knobs& kn) { return static_cast<size_t>(kn.hx_pair_min_kib) << 10; }
 
 size_t hx_lds_bytes(const wg_params& p) {
   auto pad = [&](int i) { return p.pads == 0 ? i : i + ((i / p.pads) * p.padw); };
@@ -445,12 +429,13 @@ size_t hx_lds_bytes(const wg_params& p) {
 }
 
 bool choose_hx_params(int precision, long long n, size_t max_lds, wg_params* out, int skip_pairs) {
+  const jit_knobs kn = jit_knobs::from_env();
   const int es = elem_bytes_of(precision);
   const bool f64 = precision == PFFT_PRECISION_F64;
   if (n < 1024 || static_cast<size_t>(n) * es > 3 * max_lds) return false;
   // below the threshold of the one-work-group form only the two-work-groups-per-CU plans are looked at
-  const bool pairs_only = static_cast<size_t>(n) * es <= hx_min_bytes(max_lds, precision);
-  if (pairs_only && (!hx_pairs_enabled() || static_cast<size_t>(n) * es <= hx_pair_min_bytes())) return false;
+  const bool pairs_only = static_cast<size_t>(n) * es <= hx_min_bytes(kn, max_lds, precision);
+  if (pairs_only && (!kn.hx_pairs || static_cast<size_t>(n) * es <= hx_pair_min_bytes(kn))) return false;
   // every factorisation with radices up to 32 (primes included), ranked by the packed planner's score with the "one
   // work-group per CU anyway" weights: fewer passes first, radices above 16 cheap
   radix_search s{precision, 32, {}, {}, 1e30, {}, false, false};
@@ -479,7 +464,7 @@ bool choose_hx_params(int precision, long long n, size_t max_lds, wg_params* out
     for (int lanes_signed : {1024, 896, 768, 640, 512, -512, -448, -384, -320, -256}) {
       const bool pair = lanes_signed < 0;
       const int lanes = pair ? -lanes_signed : lanes_signed;
-      if ((pair && !hx_pairs_enabled()) || (!pair && pairs_only)) continue;
+      if ((pair && !kn.hx_pairs) || (!pair && pairs_only)) continue;
       // Pairs: three passes behind a first radix of 15 and up whose scatter is conflict-free -- an odd radix as it is, an even
       // one with the image padded by one element per R0 (lane stride R0 + 1).  tools/perf_hx_pairs.py, pair against the
       // LDS-resident plan: 32.24.16 (12288) +20 %, 32.27.16 +29 %, 32.30.16 (15360) +32 %, 32.32.16 +14 %, fp64 32.24.8 +28 %;
@@ -546,7 +531,7 @@ bool choose_hx_params(int precision, long long n, size_t max_lds, wg_params* out
       // (a power-of-two first radix first: its butterfly is the cheapest in registers -- fp64 7680 as 30.16.16 needed scratch at
       //  the pair's 256 VGPRs, as 32.16.15 it runs 31 % above the LDS-resident plan)
       if (pair && (rad[0] & (rad[0] - 1)) != 0) cost *= 1.15;
-      if (const char* e = getenv("PFFT_JIT_HX_FORCE")) {  // experiments (tools/perf_hx.py): "lanes:r0xr1x..." or "lanes"
+      if (const char* e = kn.hx_force) {  // experiments (tools/perf_hx.py, PFFT_JIT_HX_FORCE): "lanes:r0xr1x..." or "lanes"
         int fl = 0;
         char rs[64] = {0};
         const int got = std::sscanf(e, "%d:%63[0-9x]", &fl, rs);
@@ -606,7 +591,8 @@ bool choose_strided_params(int precision, long long n, long long inner_count, si
   const size_t lds_cap = std::min<size_t>(max_lds, 128 * 1024);
   const int e_cap = f64 ? 16 : 32;
   // planner experiments (tools/jit_sweep_strided.py): PFFT_JIT_STRIDED_FORCE=n:fpw:lanes_per_fft:r0xr1x...[:twl]
-  if (const char* e = getenv("PFFT_JIT_STRIDED_FORCE")) {
+  const jit_knobs kn = jit_knobs::from_env();
+  if (const char* e = kn.strided_force) {
     long long fn = 0;
     int ffpw = 0, ftpf = 0, ftwl = 0;
     char rad[64] = {0};
@@ -638,9 +624,9 @@ bool choose_strided_params(int precision, long long n, long long inner_count, si
   // FPW adjacent FFTs: 256-byte HBM segments when LDS allows (32 fp32 columns; 16 fp64 columns only for stages that
   // are column-shaped on both sides -- a row-shaped fp64 side gets worse with more rows per wave), else 128-byte
   int fpw_first = f64 ? (column_both ? 16 : 8) : 32;
-  if (const char* e = getenv("PFFT_JIT_STRIDED_FPW")) fpw_first = std::atoi(e);  // experiments
-  if (const char* e = getenv("PFFT_JIT_STRIDED_LDS_KIB")) {  // experiments: the widest group whose image stays below
-    while (fpw_first > 4 && static_cast<size_t>(n) * fpw_first * es > (static_cast<size_t>(std::atoi(e)) << 10)) fpw_first /= 2;
+  if (kn.strided_fpw != 0) fpw_first = kn.strided_fpw;  // experiments (PFFT_JIT_STRIDED_FPW)
+  if (kn.strided_lds_kib > 0) {  // experiments (PFFT_JIT_STRIDED_LDS_KIB): the widest group whose image stays below
+    while (fpw_first > 4 && static_cast<size_t>(n) * fpw_first * es > (static_cast<size_t>(kn.strided_lds_kib) << 10)) fpw_first /= 2;
   }
   // (down to ONE FFT per work-group: a strided or batch-interleaved transform longer than half the LDS -- fp32 10 241 ...
   //  20 480 points, fp64 5121 ... 10 240 -- has no other single-kernel plan, the generic tier needs two images)
@@ -650,7 +636,7 @@ bool choose_strided_params(int precision, long long n, long long inner_count, si
     if (static_cast<size_t>(n) * fpw * es > (fpw == 1 ? max_lds : lds_cap)) continue;
     if (fpw == 1 && static_cast<size_t>(n) * 2 * es <= max_lds) continue;  // (the generic tier's length: unchanged)
     int wg_max = (f64 && fpw > 1) ? 512 : 1024;  // (one long fp64 transform per work-group: 10240 points on 1024 lanes)
-    if (const char* e = getenv("PFFT_JIT_STRIDED_WG")) wg_max = std::atoi(e);  // experiments
+    if (kn.strided_wg != 0) wg_max = kn.strided_wg;  // experiments (PFFT_JIT_STRIDED_WG)
     const int t_max = wg_max / fpw;
     int max_r = 0;
     for (int r : p.radices) max_r = std::max(max_r, r);
@@ -693,7 +679,7 @@ bool choose_rows2d_params(int precision, long long n1, long long n0, size_t max_
   const int emax = precision == PFFT_PRECISION_F64 ? 16 : 32;  // complex elements a lane may hold
   if (n1 < 32 || n1 > 16384 || n0 < 4) return false;
   // planner experiments (tools/jit_sweep_strided.py): PFFT_JIT_ROWS2D_FORCE=n1:rc:lanes:r0x...xr_last[:twl]
-  if (const char* e = getenv("PFFT_JIT_ROWS2D_FORCE")) {
+  if (const char* e = jit_knobs::from_env().rows2d_force) {
     long long fn = 0;
     int frc = 0, fwg = 0, ftwl = 0;
     char rad[64] = {0};
