@@ -601,7 +601,10 @@ def test_fused_multidimensional():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("prec,n", [("f32", 32768), ("f64", 16384), ("f64", 8192), ("f32", 24576), ("f32", 30000), ("f64", 12000),
-                                    ("f64", 15000), ("f32", 16384), ("f32", 15360), ("f32", 11264), ("f64", 6144), ("f64", 7680)])
+                                    ("f64", 15000), ("f32", 16384), ("f32", 15360), ("f32", 11264), ("f64", 6144), ("f64", 7680),
+                                    # (two-per-CU lengths whose first plan needs scratch at the pair's register budget: the runtime
+                                    #  compiler moves on to the next one -- 27.24.18 / 32.28.8, profiles/r5_pair_plans_of_dropped_tuned_entries.txt)
+                                    ("f32", 11664), ("f64", 7168), ("f32", 13500)])
 def test_register_resident_lengths(prec, n):
     """The 256 KiB transforms that stay in the registers of one work-group for all their passes, one HBM pass
     (stockham_wg_hx.hpp): fp32 32768, the reference's first GlobalTest size, and fp64 16384, its largest
@@ -624,7 +627,7 @@ def test_register_resident_lengths(prec, n):
         if n * (8 if prec == "f32" else 16) <= 152 * 1024:  # a pair: it fits the LDS, the twin is the LDS-resident kernel
             assert twin.info().dims[0].tier == 1 and twin.info().dims[0].lds_bytes > 80 * 1024
             assert info.dims[0].lds_bytes <= 80 * 1024 and info.dims[0].workgroup_size <= 512, "two work-groups per CU"
-            assert info.dims[0].factors[0] in (16, 32) and info.dims[0].n_factors == 3
+            assert info.dims[0].factors[0] >= 15 and info.dims[0].n_factors == 3
         else:
             assert twin.info().dims[0].tier == 3 and min(twin.info().launches) >= 2
     finally:
