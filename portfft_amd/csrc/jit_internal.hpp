@@ -51,6 +51,10 @@ struct jit_knobs {
   long strided_lds_kib = 0;               ///< PFFT_JIT_STRIDED_LDS_KIB
   int strided_wg = 0;                     ///< PFFT_JIT_STRIDED_WG
   const char* rows2d_force = nullptr;     ///< PFFT_JIT_ROWS2D_FORCE
+  bool strided_hx = true;                 ///< PFFT_JIT_STRIDED_HX=0: no register-resident strided kernels
+  long strided_hx_min_kib = 80;           ///< PFFT_JIT_STRIDED_HX_MIN_KIB: groups above this take the half-image form
+  const char* strided_hx_force = nullptr; ///< PFFT_JIT_STRIDED_HX_FORCE=tpf:per_cu
+  bool strided_pf = false;                ///< PFFT_JIT_STRIDED_PF=1 (experiment): groups alone on their CU software-pipelined
 
   static jit_knobs from_env() {
     jit_knobs k;
@@ -83,6 +87,10 @@ struct jit_knobs {
     k.strided_lds_kib = num("PFFT_JIT_STRIDED_LDS_KIB", 0);
     k.strided_wg = static_cast<int>(num("PFFT_JIT_STRIDED_WG", 0));
     k.rows2d_force = str("PFFT_JIT_ROWS2D_FORCE");
+    if (const char* e = str("PFFT_JIT_STRIDED_HX")) k.strided_hx = e[0] != '0';
+    k.strided_hx_min_kib = num("PFFT_JIT_STRIDED_HX_MIN_KIB", 80);
+    k.strided_hx_force = str("PFFT_JIT_STRIDED_HX_FORCE");
+    k.strided_pf = num("PFFT_JIT_STRIDED_PF", 0) != 0;
     return k;
   }
 };

@@ -674,6 +674,124 @@ bool choose_strided_params(int precision, long long n, long long inner_count, si
   return false;
 }
 
+size_t strided_hx_lds_bytes(const wg_params& p) {
+  int h = 0;
+  for (size_t i = 1; i < p.radices.size(); ++i) h = std::max(h, ((p.radices[i] + 1) / 2) * (p.n / p.radices[i]));
+  size_t tw = 0, ns = 1;
+  for (size_t i = 0; i < p.radices.size(); ++i) {
+    if (i > 0 && static_cast<int>(i) <= p.twl) tw += ns * static_cast<size_t>(p.radices[i] - 1);
+    ns *= static_cast<size_t>(p.radices[i]);
+  }
+  return (static_cast<size_t>(h) * static_cast<size_t>(p.fpw) + tw) * elem_bytes_of(p.precision);
+}
+
+std::vector<wg_params> strided_hx_candidates(const wg_params& base, size_t max_lds) {
+  std::vector<wg_params> out;
+  const jit_knobs kn = jit_knobs::from_env();
+  const int es = elem_bytes_of(base.precision);
+  const bool f64 = base.precision == PFFT_PRECISION_F64;
+  const size_t full = static_cast<size_t>(base.n) * static_cast<size_t>(base.fpw) * es;
+  if (!kn.strided_hx || base.radices.size() < 2 || base.fpw < 2 || base.staged != 0 ||
+      full <= (static_cast<size_t>(kn.strided_hx_min_kib) << 10)) {
+    return out;
+  }
+  const size_t cu_lds = std::min<size_t>(max_lds, 160 * 1024);
+  const size_t tables = f64 ? 8 * 1024 : 4 * 1024;  // store-modifier tables + allocation granularity, per work-group
+  // the order of the radices: the planner's own (a small last radix keeps the store modifier cheap) while half an image of
+  // it lets two work-groups share the CU; else the order with the smallest image -- pass 0 is the one pass whose inputs do
+  // not come through the image, and the image is ceil(R / 2) / R of the group for the others
+  auto image_of = [&](const std::vector<int>& o) {
+    size_t h = 0;
+    for (size_t i = 1; i < o.size(); ++i) {
+      h = std::max<size_t>(h, static_cast<size_t>((o[i] + 1) / 2) * static_cast<size_t>(base.n / o[i]));
+    }
+    return h * static_cast<size_t>(base.fpw) * es;
+  };
+  std::vector<int> rad = base.radices;
+  if (image_of(rad) + tables > cu_lds / 2) {
+    std::vector<int> order = base.radices;
+    std::sort(order.begin(), order.end());
+    size_t best_h = image_of(rad);
+    do {
+      if (image_of(order) < best_h) {
+        best_h = image_of(order);
+        rad = order;
+      }
+    } while (std::next_permutation(order.begin(), order.end()));
+  }
+  int rmax = 0;
+  for (int r : rad) rmax = std::max(rmax, r);
+  std::vector<std::pair<double, wg_params>> ranked;
+  for (int tpf = std::max(1, 64 / base.fpw); tpf * base.fpw <= 1024; ++tpf) {
+    int regs = 0;
+    double slots = 0.0;
+    for (int r : rad) {
+      const long long nb = base.n / r;
+      const long long bpt = (nb + tpf - 1) / tpf;
+      regs = std::max<int>(regs, static_cast<int>(bpt) * r);
+      slots += static_cast<double>(tpf) * static_cast<double>(bpt) * r / static_cast<double>(base.n);
+    }
+    const int wg = tpf * base.fpw, waves = (wg + 63) / 64;
+    for (int per_cu = 2; per_cu <= 4; ++per_cu) {
+      wg_params p = base;
+      p.radices = rad;
+      p.wg = wg;
+      p.regs = regs;
+      p.twl = 0;
+      p.hx_strided = per_cu;
+      const size_t budget_lds = cu_lds / static_cast<size_t>(per_cu);
+      if (strided_hx_lds_bytes(p) + tables > budget_lds) continue;
+      for (int k = static_cast<int>(rad.size()) - 1; k >= 1; --k) {  // leading twiddle tables in LDS while they fit
+        wg_params q = p;
+        q.twl = k;
+        if (strided_hx_lds_bytes(q) - strided_hx_lds_bytes(p) <= 16 * 1024 && strided_hx_lds_bytes(q) + tables <= budget_lds) {
+          p.twl = k;
+          break;
+        }
+      }
+      const int wps = (per_cu * waves + 3) / 4;
+      if (wps > 8) continue;
+      // fp32: only plans that keep 14 or more waves on the CU.  Measured (tools/perf_stage_hx.py, profiles/r6_stage_hx.txt;
+      // fraction of the HBM peak, LDS-resident -> register-resident): 768 x 16 on 2 x 512 lanes 0.453 -> 0.541, 660 x 16 on
+      // 2 x 480 lanes 0.513 -> 0.551, 68640 = 104 x 660 0.289 -> 0.301 -- but 800 x 16 on 2 x 320 lanes 0.438 -> 0.438 and 1728 x 8
+      // on 2 x 384 lanes 0.233 -> 0.215: ten or twelve waves of 160-register kernels hide less than the thirteen of the
+      // LDS-resident one.  (fp64 has no such pattern: 660 x 8 on 2 x 176 lanes 0.469 -> 0.527, 768 x 8 on 2 x 256 lanes a tie.)
+      if (!f64 && per_cu * waves < 14 && kn.strided_hx_force == nullptr) continue;
+      const int budget = std::min(256, (512 / wps) / 8 * 8);
+      // the group's values, one butterfly's temporaries, the store modifier's powers, addresses (the compiler has the last
+      // word: a kernel that needs scratch at this occupancy is dropped for the next candidate, jit_strided_kernel)
+      // Measured with hipcc -Rpass-analysis (tools/jit_strided_hx_dump.cpp + tools/kres.py): beside the values a kernel of
+      // this shape needs 60-70 registers in fp32 and ~100 in fp64 -- fp32 11.10.6 x 16 on 480 lanes (30 values) 121 VGPRs,
+      // 10.10.10 x 16 on 560 lanes (30 values) 131 unconstrained and 26 spilled at 96, on 320 lanes (50 values) 205
+      const int need = regs * (f64 ? 4 : 2) + (f64 ? 100 : 62) + std::max(0, rmax - 12) * (f64 ? 4 : 2);
+      bool forced = false;
+      if (const char* e = kn.strided_hx_force) {  // experiments: "tpf:per_cu", whatever the register estimate says
+        int ft = 0, fk = 0;
+        forced = std::sscanf(e, "%d:%d", &ft, &fk) == 2 && ft == tpf && fk == per_cu;
+      }
+      if (need > budget && !forced) continue;
+      p.occ = wps;
+      const double idle = slots / static_cast<double>(rad.size()) - 1.0;
+      const double lane_waste = static_cast<double>(waves * 64) / static_cast<double>(wg) - 1.0;
+      double cost = (1.0 + idle) * (1.0 + lane_waste);
+      // 16 waves per CU in two or more work-groups is where the packed pairs and the registered stage pairs sit
+      cost *= 1.0 + 0.04 * std::abs(per_cu * waves - 16);
+      cost *= 1.0 + 0.3 * std::max(0.0, static_cast<double>(need) / budget - 0.85);  // at the edge of the budget
+      if (forced) cost *= 1e-3;
+      ranked.emplace_back(cost, p);
+    }
+  }
+  std::stable_sort(ranked.begin(), ranked.end(), [](const auto& a, const auto& b) { return a.first < b.first; });
+  for (const auto& c : ranked) {
+    bool dup = false;
+    // (one plan per register load: 544, 560 and 576 lanes holding 30 values each are the same kernel to the allocator)
+    for (const wg_params& o : out) dup = dup || (o.regs == c.second.regs && o.hx_strided == c.second.hx_strided);
+    if (!dup) out.push_back(c.second);
+    if (out.size() >= 3) break;
+  }
+  return out;
+}
+
 bool choose_rows2d_params(int precision, long long n1, long long n0, size_t max_lds, wg_params* out, int rc_mask) {
   const int es = elem_bytes_of(precision);
   const int emax = precision == PFFT_PRECISION_F64 ? 16 : 32;  // complex elements a lane may hold

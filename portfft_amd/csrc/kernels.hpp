@@ -119,6 +119,10 @@ struct strided_kernel {
   /// form multiplies the inputs of pass 0: strided_pass0_compute LTW) and stage A runs without the store modifier --
   /// fp64 n = 1024 (C3): stage A 120 -> 108 us per chunk, stage B 90 -> 91-94 (tools/tune_fourstep.hip case 120)
   int fs_ltw;
+  /// > 0 (runtime-compiled entries): the register-resident form (stockham_strided_hx.hpp) planned as that many work-groups
+  /// per CU; lds_bytes is its HALF image (+ TWL copy), the interleaved / split / mixed forms are that kernel's, the
+  /// row-staged forms stay those of stockham_strided.hpp and there are no tiled-input forms
+  int hx;
 };
 
 /// First pass of the two-pass 2-D plan (stockham_rows2d.hpp): whole row FFTs of length n + the first radix-rc

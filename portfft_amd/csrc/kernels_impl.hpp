@@ -136,8 +136,9 @@ spec_kernel make_spec_entry_prefetch(int groups_per_wg = 4) {
   return k;
 }
 
+/// the fields every form of a packed configuration shares (no kernel is instantiated by this)
 template <typename Cfg>
-spec_kernel make_spec_entry(int groups_per_wg) {
+spec_kernel spec_entry_fields(int groups_per_wg) {
   spec_kernel k{};
   k.groups_per_wg = groups_per_wg;
   k.precision = sizeof(typename Cfg::T) == 8 ? PFFT_PRECISION_F64 : PFFT_PRECISION_F32;
@@ -156,6 +157,12 @@ spec_kernel make_spec_entry(int groups_per_wg) {
   k.aux = Cfg::AUX;
   k.staged = Cfg::STAGED;
   k.twl = Cfg::TWL;
+  return k;
+}
+
+template <typename Cfg>
+spec_kernel make_spec_entry(int groups_per_wg) {
+  spec_kernel k = spec_entry_fields<Cfg>(groups_per_wg);
   k.fn[0] = reinterpret_cast<const void*>(&stockham_wg_kernel<Cfg, false>);
   k.fn[1] = reinterpret_cast<const void*>(&stockham_wg_kernel<Cfg, true>);
   k.launch = &launch_spec<Cfg>;
@@ -230,7 +237,9 @@ hipError_t launch_spec_hx_split(hipStream_t stream, unsigned grid, const void* i
 /// register-resident form (stockham_wg_hx.hpp) of a packed length; PF: its software-pipelined form
 template <typename Cfg, bool PF = false>
 spec_kernel make_spec_entry_hx(int groups_per_wg = 0) {
-  spec_kernel k = make_spec_entry<Cfg>(groups_per_wg);
+  // (fields only: the LDS-resident stockham_wg kernels of such a configuration -- fp32 32768 would need a 256 KiB image --
+  //  are never instantiated, and every pointer of the entry is the register-resident kernel's: ADVICE r5)
+  spec_kernel k = spec_entry_fields<Cfg>(groups_per_wg);
   k.lds_bytes = wg_hx_lds_bytes<Cfg>();
   k.fn[0] = reinterpret_cast<const void*>(&stockham_wg_hx_kernel<Cfg, false, PF>);
   k.fn[1] = reinterpret_cast<const void*>(&stockham_wg_hx_kernel<Cfg, true, PF>);

@@ -171,6 +171,7 @@ struct plan_knobs {
   bool nd_two_stage_columns = false, no_fs_pairs = false, no_half_pairs = false, no_split_rule = false;
   bool no_split_tiled = false, no_wide_tiles = false, two_pass_2d_off = false, jit_verbose = false;
   bool split_cached = true, pair_xcd = true, stop_event_on_launch = true, xcd_check = false;
+  bool xcd_contig = true;  // PFFT_XCD_CONTIG=0: no XCD-contiguous group walk for stages with unaligned row pitches
   // overrides (unset: -1 / 0 / empty)
   int chunk_overlap = 2, jit_groups_per_wg = -1, groups_per_wg = 0, xcd_slots = 0, xcd_lag = 0;
   int row_in_max_n = 512;  // PFFT_ROW_IN_MAX_N: longest stage whose row-shaped INPUT is staged through LDS
@@ -202,6 +203,7 @@ struct plan_t {
   size_t xcd_tmap_bytes = 0;
   unsigned* xcd_report = nullptr;  // ... and the copy's host report (pinned; XCD_REPORT_WORDS words, xcd_args.hpp)
   unsigned xcd_recoveries_seen = 0;  // PFFT_XCD_CHECK=1: report[0] at the last check
+  bool xcd_recovery_warned = false;  // the one-time stderr note about a recovered launch has been printed
   void* alias_scratch = nullptr;  // intermediate of the two-pass 2-D plan for aliasing (in-place) executes
   size_t alias_scratch_bytes = 0;
   size_t two_pass_chunk_bytes = 0;  // bytes of one chunk of the two-pass 2-D plan (what an aliasing execute needs)

@@ -166,6 +166,7 @@ plan_knobs plan_knobs::from_env() {
   mark(k.xcd_lag > 0);
   if (const char* e = set("PFFT_XCD_MAX_ITERS")) k.xcd_max_iters = std::atoll(e);
   mark(k.xcd_max_iters >= 0);
+  onoff("PFFT_XCD_CONTIG", &k.xcd_contig);
   return k;
 }
 

@@ -2,6 +2,8 @@
 // (include/portfft_amd.h).
 #include "plan.hpp"
 
+#include <cstdio>
+
 namespace pfa {
 
 /// intermediate of the two-pass 2-D plan when the caller's buffers alias: allocated at commit for IN_PLACE
@@ -64,6 +66,18 @@ void plan_t::run_stage(const stage& s, const void* in_re, const void* in_im, voi
     // hand-off wait of the former gave up, in which case it recomputes what is missing IN STREAM ORDER -- the
     // submission's event (the stop event of the last launch) and everything queued behind the execute see valid data.
     // Aliasing buffers: stage B from the slot rings first (the input of those transforms is already overwritten).
+    // A launch that gave up is recomputed silently in stream order -- but it first stalled the stream for seconds (2^24
+    // polls of the waiting wave, stockham_xcd.hpp XCD_SPIN_LIMIT).  The report word lives in pinned host memory: look at it
+    // WITHOUT synchronising, here, on the next execute, and say so once (latency spikes without a diagnostic).
+    if (!xcd_recovery_warned && xcd_report != nullptr && __atomic_load_n(xcd_report, __ATOMIC_RELAXED) != 0) {
+      xcd_recovery_warned = true;
+      std::fprintf(stderr,
+                   "[portfft_amd] an XCD-local four-step launch of this plan gave up a hand-off wait and was recomputed by its "
+                   "recovery launch (%u so far; the results are valid, the execute stalled for up to ~3 s). "
+                   "pfft_plan_info_t::xcd_recoveries counts them, PFFT_XCD_CHECK=1 turns them into errors, "
+                   "PFFT_NO_XCD_LOCAL=1 keeps the two-launch plan.\n",
+                   __atomic_load_n(xcd_report, __ATOMIC_RELAXED));
+    }
     const hipEvent_t stop = take_stop_event();
     hip_check(s.xcd->launch(stream, s.grid, s.lds_bytes, x, s.backward), "kernel launch");
     const bool aliasing = in_re == out_re;
@@ -116,6 +130,14 @@ void plan_t::run_stage(const stage& s, const void* in_re, const void* in_im, voi
           groups >= 32 && kn.pair_xcd) {
         a.pair_xcd = 1;
         grid &= ~15u;
+      }
+      // ... and a row pitch that is no multiple of a line (68640 = 104 x 660: 5280-byte rows; the columns of a 1000 x 1000
+      // matrix): every segment straddles one line more than it fills and shares it with the neighbour group -- the blocks
+      // of an XCD walk neighbouring groups (strided_group_walk, pair_xcd 2) so that the shared line is fetched once
+      const size_t pitch = static_cast<size_t>(a.in_stride) * (in_user_split ? sb : elem_bytes());
+      if (a.pair_xcd == 0 && column_in && a.in_tile_shift == 0 && pitch % 128 != 0 && s.row_mode == 0 && s.tiled_in == 0 &&
+          s.strided->fpw > 1 && grid >= 64 && kn.xcd_contig) {
+        a.pair_xcd = 2;
       }
     }
     if (split && (s.in_buf == BUF_SCRATCH) != (s.out_buf == BUF_SCRATCH)) {  // mixed storage (four-step stages)

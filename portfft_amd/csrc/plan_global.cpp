@@ -566,6 +566,11 @@ bool plan_t::plan_xcd_local(std::vector<stage>& out, long long n, long long coun
   int per_cu = 0;
   hip_check(hipFuncSetAttribute(k->fn[backward], hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)),
             "hipFuncSetAttribute");
+  // (the recovery launch that follows every execute asks for the same LDS: ADVICE r5)
+  if (k->fn_recover[backward] != nullptr) {
+    hip_check(hipFuncSetAttribute(k->fn_recover[backward], hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)),
+              "hipFuncSetAttribute");
+  }
   hip_check(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k->fn[backward], k->wg, lds), "occupancy query");
   per_cu = std::max(per_cu, 1);
   s.grid = static_cast<unsigned>(per_cu * n_cus);

@@ -630,6 +630,39 @@ PFA_DEV void strided_copy_twiddles(cx<typename Cfg::T>* lds, const cx<typename C
   }
 }
 
+/// The walk of a launch's work-groups over its groups: body(g) for every group g this work-group owns.
+/// (a two-tier grid like the headline kernel's was measured here: neutral on C3 / ref65536, 1.2 % slower on C5, and
+///  the extra loop state alone cost the fp64 n = 256 row-in / column-out shape 15 % -- plain grid-stride loop)
+/// strided_args::pair_xcd 1: groups whose input segments are narrower than a 128-byte line share every line with their
+/// neighbour group.  Blocks b and b + 8 run on the same XCD and are dispatched back to back (MI355X_MICROARCH.md,
+/// "workgroup dispatch"), so they take groups 2k and 2k + 1: the two halves of a line are then fetched by one XCD at
+/// about the same time -- 64-byte segments read at 4.1-4.2 instead of 3.5-3.7 TB/s as a plain copy
+/// (tools/probes/seg64_pairing.hip; stores do not gain).  The permutation is a bijection on every aligned run of 16
+/// blocks; the host rounds the grid to 16.
+/// pair_xcd 2: XCD-contiguous -- the blocks of XCD x (b % 8 == x) walk the x-th eighth of the groups in order, so the
+/// groups running side by side on an XCD are neighbours in memory.  For stages whose segments do not start on line
+/// boundaries (a row pitch that is no multiple of 128 bytes: 68640 = 104 x 660, 5280-byte rows): every 256-byte segment
+/// straddles three lines instead of two and the line it shares with the neighbour group was fetched twice, by two XCDs
+/// (profiles/r5_pmc_traffic_ref68640.json: stage A read 1.38 x its input).  Speed only: nothing depends on the mapping.
+template <typename Body>
+PFA_DEV void strided_group_walk(const strided_args& a, long long ngroups, Body&& body) {
+  // (ONE loop for the three walks: the body -- a whole transform -- is instantiated once)
+  long long g = blockIdx.x, step = gridDim.x, gend = ngroups;
+  if (a.pair_xcd == 2 && gridDim.x >= 8u) {
+    const unsigned x = blockIdx.x & 7u;
+    step = (gridDim.x - x + 7u) >> 3;  // blocks with this b % 8
+    g = ngroups * x / 8 + (blockIdx.x >> 3);
+    gend = ngroups * (x + 1) / 8;
+  } else if (a.pair_xcd == 1 && (gridDim.x & 15u) == 0u) {
+    g = (g & ~15ll) + 2 * (g & 7) + ((g >> 3) & 1);
+    gend = (ngroups + 15) & ~15ll;
+  }
+  for (; g < gend; g += step) {
+    if (g >= ngroups) continue;  // (uniform: the ragged last run of a paired grid)
+    body(g);
+  }
+}
+
 template <typename Cfg, bool BWD, int STW, int SPLIT = 0, int TIN = 0>
 __global__ __launch_bounds__(Cfg::WG, Cfg::OCC) void stockham_strided_kernel(const strided_args a) {
   using T = typename Cfg::T;
@@ -642,26 +675,14 @@ __global__ __launch_bounds__(Cfg::WG, Cfg::OCC) void stockham_strided_kernel(con
   const long long ngroups = strided_ngroups<Cfg>(a);
   strided_copy_twiddles<Cfg>(lds, tw);
   strided_copy_stw<Cfg, STW>(a);
-  // (a two-tier grid like the headline kernel's was measured here: neutral on C3 / ref65536, 1.2 % slower on C5, and
-  //  the extra loop state alone cost the fp64 n = 256 row-in / column-out shape 15 % -- plain grid-stride loop)
-  // Groups whose input segments are narrower than a 128-byte line share every line with their neighbour group.  Blocks b
-  // and b + 8 run on the same XCD and are dispatched back to back (MI355X_MICROARCH.md, "workgroup dispatch"), so they
-  // take groups 2k and 2k + 1: the two halves of a line are then fetched by one XCD at about the same time -- 64-byte
-  // segments read at 4.1-4.2 instead of 3.5-3.7 TB/s as a plain copy (tools/probes/seg64_pairing.hip; stores do not
-  // gain).  The permutation is a bijection on every aligned run of 16 blocks; the host rounds the grid to 16.
-  const bool pair = a.pair_xcd != 0 && (gridDim.x & 15u) == 0u;
-  long long g0 = blockIdx.x;
-  if (pair) g0 = (g0 & ~15ll) + 2 * (g0 & 7) + ((g0 >> 3) & 1);
-  const long long gend = pair ? ((ngroups + 15) & ~15ll) : ngroups;
-  for (long long g = g0; g < gend; g += gridDim.x) {
-    if (g >= ngroups) continue;  // (uniform: the ragged last run of a paired grid)
+  strided_group_walk(a, ngroups, [&](long long g) PFA_LAMBDA {
     bool live;
     long long c0;
     long long nlive;
     const auto io = strided_group<Cfg, SPLIT>(a, g, f, &live, &c0, &nlive);
     // no barrier needed here: the last pass ends its LDS reads with a barrier before the next group's first write
     strided_passes<Cfg, BWD, STW, 0, decltype(io), false, false, TIN>(io, a, f, tid, live, c0, lds, tw, nlive);
-  }
+  });
 }
 
 }  // namespace pfa

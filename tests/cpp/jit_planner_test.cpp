@@ -170,7 +170,56 @@ int main(int argc, char** argv) {
     EXPECT(pfa::choose_hx_params(0, 32768, max_lds, &p) && p.radices.size() == 3, "fp32 32768 in three passes");
     EXPECT(pfa::choose_hx_params(1, 16384, max_lds, &p) && p.radices.size() <= 4, "fp64 16384");
   }
+  {
+    // register-resident strided plans (strided_hx_candidates): only for groups that would sit alone on their CU, a half
+    // image that lets the planned number of work-groups share the CU's LDS, lanes inside the register budget
+    long long planned[2] = {0, 0};
+    for (int prec = 0; prec < 2; ++prec) {
+      const int es = prec ? 16 : 8;
+      for (long long n : {104LL, 256LL, 512LL, 600LL, 625LL, 660LL, 720LL, 768LL, 800LL, 1000LL, 1024LL, 1100LL, 1536LL, 1944LL, 2000LL, 2048LL}) {
+        pfa::wg_params b;
+        if (!pfa::choose_strided_params(prec, n, 4096, max_lds, &b, false, prec ? 8 : 16)) continue;
+        const std::vector<pfa::wg_params> c = pfa::strided_hx_candidates(b, max_lds);
+        const size_t full = static_cast<size_t>(n) * b.fpw * es;
+        EXPECT(full > 80 * 1024 || c.empty(), "strided hx n=%lld: a group of %zu bytes has two work-groups per CU already", n, full);
+        for (const pfa::wg_params& q : c) {
+          ++planned[prec];
+          long long prod = 1;
+          for (int r : q.radices) prod *= r;
+          EXPECT(prod == n && q.fpw == b.fpw && q.hx_strided >= 2 && q.hx_strided <= 4, "strided hx n=%lld: same group, 2 ... 4 per CU", n);
+          EXPECT(static_cast<size_t>(q.hx_strided) * pfa::strided_hx_lds_bytes(q) <= max_lds, "strided hx n=%lld: LDS of %d work-groups", n, q.hx_strided);
+          EXPECT(pfa::strided_hx_lds_bytes(q) < full * 3 / 4, "strided hx n=%lld: the image is about half of the group", n);
+          const int waves = (q.wg + 63) / 64, wps = (q.hx_strided * waves + 3) / 4;
+          EXPECT(q.wg <= 1024 && q.wg % q.fpw == 0 && q.occ == wps && q.regs * (prec ? 4 : 2) < 512 / wps,
+                 "strided hx n=%lld: %d lanes, %d values per lane", n, q.wg, q.regs);
+          EXPECT(prec == 1 || q.hx_strided * waves >= 14, "strided hx n=%lld: fp32 plans keep 14 waves on the CU", n);
+        }
+      }
+    }
+    std::printf("strided hx planner: %lld fp32 and %lld fp64 candidate plans\n", planned[0], planned[1]);
+    EXPECT(planned[0] >= 4 && planned[1] >= 3, "strided hx coverage");
+    {
+      pfa::wg_params b;
+      EXPECT(pfa::choose_strided_params(0, 1000, 4096, max_lds, &b, false, 16) && pfa::strided_hx_candidates(b, max_lds).empty(),
+             "fp32 1000 x 16: 16000 values do not fit two work-groups' registers beside ~62 of overhead -- LDS-resident");
+    }
+  }
   if (argc > 1 && std::string(argv[1]) == "compile") {
+    for (auto c : std::vector<std::pair<int, long long>>{{0, 660}, {1, 660}, {0, 768}}) {
+      pfa::wg_params b;
+      EXPECT(pfa::choose_strided_params(c.first, c.second, 4096, max_lds, &b, false, c.first ? 8 : 16), "strided plan %lld", c.second);
+      const std::vector<pfa::wg_params> cand = pfa::strided_hx_candidates(b, max_lds);
+      EXPECT(!cand.empty(), "strided hx plan %lld", c.second);
+      for (int kind : {11, 12}) {
+        if (cand.empty()) break;
+        size_t bytes = 0;
+        std::string why;
+        const bool built = pfa::jit_compile_only(cand[0], kind, "gfx950", &bytes, &why);
+        EXPECT(built && bytes > 1000, "hiprtc strided hx n=%lld kind=%d: %s", c.second, kind, why.c_str());
+        std::printf("hiprtc n=%lld kind=%d %s x%d per CU: %zu bytes\n", c.second, kind, pfa::wg_cfg_type_name(cand[0]).c_str(),
+                    cand[0].hx_strided, bytes);
+      }
+    }
     for (auto c : std::vector<std::pair<int, long long>>{{0, 24576}, {0, 30000}, {1, 12000}, {1, 15000}}) {
       pfa::wg_params q;
       EXPECT(pfa::choose_hx_params(c.first, c.second, max_lds, &q), "hx plan %lld", c.second);
