@@ -763,7 +763,8 @@ std::vector<wg_params> strided_hx_candidates(const wg_params& base, size_t max_l
       // Measured with hipcc -Rpass-analysis (tools/jit_strided_hx_dump.cpp + tools/kres.py): beside the values a kernel of
       // this shape needs 60-70 registers in fp32 and ~100 in fp64 -- fp32 11.10.6 x 16 on 480 lanes (30 values) 121 VGPRs,
       // 10.10.10 x 16 on 560 lanes (30 values) 131 unconstrained and 26 spilled at 96, on 320 lanes (50 values) 205
-      const int need = regs * (f64 ? 4 : 2) + (f64 ? 100 : 62) + std::max(0, rmax - 12) * (f64 ? 4 : 2);
+      // (16.8.8 x 16 on 512 lanes, 32 values: 115 without the store modifier, 16 spilled with it -- the compile check decides)
+      const int need = regs * (f64 ? 4 : 2) + (f64 ? 100 : 62) + std::max(0, rmax - 16) * (f64 ? 4 : 2);
       bool forced = false;
       if (const char* e = kn.strided_hx_force) {  // experiments: "tpf:per_cu", whatever the register estimate says
         int ft = 0, fk = 0;

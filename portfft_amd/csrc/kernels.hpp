@@ -85,9 +85,6 @@ struct strided_kernel {
   /// ... and its tiled-input form (stockham_strided_kernel<Cfg, BWD, 0, 3, TIN = true>, jit_strided_ensure_mixed_tin):
   /// stage B behind a group-major intermediate on SPLIT_COMPLEX data
   hipFunction_t mfn_mixed_tin[2];
-  /// row-lanes form (strided_pass TIN = -1, jit_strided_ensure_tin_rows): the four-step stage B of a length without a
-  /// tiled intermediate -- contiguous rows read 64 consecutive elements per wave; [backward]
-  hipFunction_t mfn_tin_rows[2];
   /// tiled-input form (strided_pass TIN): the four-step stage B behind a group-major stage A of the same group
   /// width; fn_tin[backward]; null when not instantiated
   const void* fn_tin[2];

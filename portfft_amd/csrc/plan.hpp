@@ -62,7 +62,7 @@ struct stage {
   int store_modifier = 0;
   int row_mode = 0;  // 0: both sides addressed by the passes, 1: row-shaped input staged, 2: row-shaped output staged
   int tiled_in = 0;  // 1: the kernel's tiled-input form (strided_kernel::launch_tin), 2: ... with tiles twice as wide
-                     // (launch_tin_w), 3: row-lanes form of a runtime-compiled entry (jit_launch_strided_tin_rows)
+                     // (launch_tin_w)
   int gpw = 0;       // > 0: groups per work-group of this stage instead of the kernel's own rule (four-step pairs)
   int in_buf = BUF_IN, out_buf = BUF_OUT;
   long long count = 0;  // number of FFTs
@@ -167,11 +167,12 @@ struct plan_knobs {
   bool no_precompiled = false, xlane = false, no_regres = false, no_ltw = false, no_stw_rowish = false;
   bool jit_spec_radices = false, no_mixed_rows = false, no_three_stage = false, debug_global_set = false;
   bool no_tiled_scratch = false, no_tiled_lanes = false, no_xcd_local = false, global_n1_set = false;
-  bool tin_rows = false;  // PFFT_TIN_ROWS=1: runtime stage B on a row-major intermediate with its lanes along the row
+  bool tin_rows_gone = false;  // (PFFT_TIN_ROWS: round 5's opt-in row-lanes stage B, removed; the slot keeps the mask's bit order)
   bool nd_two_stage_columns = false, no_fs_pairs = false, no_half_pairs = false, no_split_rule = false;
   bool no_split_tiled = false, no_wide_tiles = false, two_pass_2d_off = false, jit_verbose = false;
   bool split_cached = true, pair_xcd = true, stop_event_on_launch = true, xcd_check = false;
   bool xcd_contig = true;  // PFFT_XCD_CONTIG=0: no XCD-contiguous group walk for stages with unaligned row pitches
+  bool hx_over_registered = false;  // PFFT_HX_OVER_REGISTERED=1: a register-resident plan goes before a registered one-per-CU strided entry
   // overrides (unset: -1 / 0 / empty)
   int chunk_overlap = 2, jit_groups_per_wg = -1, groups_per_wg = 0, xcd_slots = 0, xcd_lag = 0;
   int row_in_max_n = 512;  // PFFT_ROW_IN_MAX_N: longest stage whose row-shaped INPUT is staged through LDS

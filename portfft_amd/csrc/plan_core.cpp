@@ -103,7 +103,7 @@ plan_knobs plan_knobs::from_env() {
   flag("PFFT_NO_THREE_STAGE", &k.no_three_stage);
   flag("PFFT_NO_TILED_SCRATCH", &k.no_tiled_scratch);
   flag("PFFT_NO_TILED_LANES", &k.no_tiled_lanes);
-  flag("PFFT_TIN_ROWS", &k.tin_rows);
+  flag("PFFT_TIN_ROWS", &k.tin_rows_gone);  // (no effect any more; keeps the bit order of `mask`)
   flag("PFFT_NO_XCD_LOCAL", &k.no_xcd_local);
   flag("PFFT_ND_TWO_STAGE_COLUMNS", &k.nd_two_stage_columns);
   flag("PFFT_NO_FS_PAIRS", &k.no_fs_pairs);
@@ -167,6 +167,7 @@ plan_knobs plan_knobs::from_env() {
   if (const char* e = set("PFFT_XCD_MAX_ITERS")) k.xcd_max_iters = std::atoll(e);
   mark(k.xcd_max_iters >= 0);
   onoff("PFFT_XCD_CONTIG", &k.xcd_contig);
+  onoff("PFFT_HX_OVER_REGISTERED", &k.hx_over_registered);
   return k;
 }
 
@@ -449,6 +450,19 @@ const strided_kernel* plan_t::get_strided(long long n, long long inner_count, bo
                                           bool column_both, bool row_side, int policy) {
   if (user_split) policy = 0;
   const strided_kernel* k = find_strided(n, column_both, row_side && !user_split, inner_count, policy, store_modifier);
+  // A registered entry that sits alone on its CU (n = 1024 x 16 columns: 128 KiB of LDS) against the register-resident
+  // form of the same group, two work-groups per CU (stockham_strided_hx.hpp) -- column-shaped stages without the store
+  // modifier only: with it the kernels of that size need scratch
+  if (k != nullptr && kn.hx_over_registered && k->lds_bytes > 80 * 1024 && column_both && !store_modifier && !row_side &&
+      !user_split && jit_enabled()) {
+    wg_params p;
+    if (choose_strided_params(desc.precision, n, inner_count, max_lds, &p, column_both, k->fpw) &&
+        !strided_hx_candidates(p, max_lds).empty()) {
+      std::string why;
+      const strided_kernel* j = jit_strided_kernel(desc.precision, n, inner_count, false, 0, max_lds, &why, column_both, policy, k->fpw);
+      if (j != nullptr && j->hx != 0) return j;
+    }
+  }
   if (k != nullptr) return k;
   if (find_strided(n, column_both, row_side && !user_split, inner_count, 0, store_modifier) != nullptr && policy != 0) {
     return find_strided(n, column_both, row_side && !user_split, inner_count, 0, store_modifier);  // no twin registered

@@ -185,10 +185,6 @@ void plan_t::run_stage(const stage& s, const void* in_re, const void* in_im, voi
                 "kernel launch");
       return;
     }
-    if (s.tiled_in == 3) {
-      hip_check(jit_launch_strided_tin_rows(s.strided, stream, grid, a, s.backward), "kernel launch");
-      return;
-    }
     if (s.tiled_in != 0) {
       hip_check(s.tiled_in == 2 ? s.strided->launch_tin_w(stream, grid, a, s.backward)
                                 : s.strided->launch_tin(stream, grid, a, s.backward),

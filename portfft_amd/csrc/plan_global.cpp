@@ -1083,17 +1083,10 @@ int plan_t::plan_1d(std::vector<stage>& out, long long n, long long count, long 
       if (ltw) attach_store_tables(sb, n, true);
     }
   }
-  // No tiled intermediate (n2 or its first pass is not a multiple of stage A's group width: 10^6 = 1000 x 1000, 68640 = 104 x
-  // 660) and too long to stage its rows through LDS: a runtime-specialised stage B can read the row-major intermediate with
-  // its lanes element-fastest along the row (strided_pass TIN = -1) instead of four elements of each of FPW rows per wave.
-  // OPT-IN (PFFT_TIN_ROWS=1): measured on 21 lengths (tools/perf_tin_rows.py, profiles/r5_perf_tin_rows.txt) it is worth
-  // +5 % for 10^6 and -3 ... +2 % everywhere else -- the read pattern of stage B is not what holds these plans at 0.25-0.30
-  if (sb.strided != nullptr && sb.strided->launch == nullptr && sb.row_mode == 0 && sb.tiled_in == 0 &&
-      sb.sa.in_tile_shift == 0 && sb.sa.in_stride == 1 && sb.sa.in_gdist == 0 && interleaved_user && !sb.store_modifier &&
-      kn.tin_rows) {
-    std::string why;
-    if (jit_strided_ensure_tin_rows(sb.strided, &why)) sb.tiled_in = 3;
-  }
+  // (No tiled intermediate -- n2 or its first pass no multiple of stage A's group width: 10^6 = 1000 x 1000, 68640 = 104 x 660 --
+  //  and too long to stage its rows through LDS: stage B reads the row-major intermediate f-fastest, four elements of each of
+  //  FPW rows per wave.  A row-lanes read was built and measured in round 5: +5 % for 10^6, -3 ... +2 % on 20 other lengths,
+  //  profiles/r5_perf_tin_rows.txt -- the read pattern is not what holds these plans; removed in round 6.)
   if (chunk < count || fs_pair) {  // (a pair's stages may carry their own grid rule / the tiled-input form)
     regrid_for_chunk(out.back(), std::min(chunk, count) * n2);
     regrid_for_chunk(sb, std::min(chunk, count) * n1);

@@ -187,18 +187,15 @@ PFA_DEV void strided_store_butterfly(const IO& io, const strided_args& a, unsign
 /// conflicts when TW = 2 * FPW); pass 1 reads through the same permutation, the later passes are unchanged.
 /// Template value: 0 off, 1 square tiles (TW = FPW), any other positive value = TW (a stage A with wider groups: fp32
 /// n2 = 2048 holds 8 columns, its stage A 16).  Needs TW * FPW | WG, (N / R0) % TW == 0 and (N / R0) % TPF == 0.
-/// -1: ROWS -- the input is row-major (in_tile_shift 0, in_stride 1: FFT f is a contiguous row at f * in_fdist, the
-/// four-step stage B of a length without a tiled intermediate): pass 0 takes its lanes element-fastest over the WHOLE
-/// row -- lane = j + TPF * f -- so a wave reads 64 consecutive elements of one row (two rows at a seam) instead of
-/// four elements of each of FPW rows, with the same f ^ (j % FPW) slot permutation behind it.  Any length, ragged
-/// passes included; FPW a power of two.
+/// (Round 5's ROWS form -- TIN = -1: lanes element-fastest over a whole row of a row-major intermediate, +5 % for N = 10^6,
+///  -3 ... +2 % on 20 other lengths, profiles/r5_perf_tin_rows.txt -- left this header in round 6; its source is
+///  stockham_strided.hpp of commit b38555f.)
 template <typename Cfg, int TIN = 1>
 constexpr int tin_width() {
   return TIN == 1 ? Cfg::FPW : TIN;
 }
 template <typename Cfg, int TIN = 1>
 constexpr bool tin_supported() {
-  if (TIN < 0) return Cfg::NP >= 2 && (Cfg::FPW & (Cfg::FPW - 1)) == 0 && Cfg::FPW >= 2;
   constexpr int TW = tin_width<Cfg, TIN>();
   return TIN != 0 && Cfg::NP >= 2 && (Cfg::FPW & (Cfg::FPW - 1)) == 0 && (TW & (TW - 1)) == 0 && TW >= 2 &&
          Cfg::WG % (TW * Cfg::FPW) == 0 && (Cfg::N / Cfg::Seq::r[0]) % TW == 0 &&
@@ -229,15 +226,10 @@ PFA_DEV void strided_pass(const IO& io, const strided_args& a, unsigned f,
   if constexpr (tin0) {
     static_assert(first && tin_supported<Cfg, TIN>(), "TIN: see tin_supported()");
     const unsigned lane = threadIdx.x;
-    if constexpr (TIN < 0) {
-      f = lane / Cfg::TPF;
-      tid = lane % Cfg::TPF;
-    } else {
-      constexpr unsigned TW = tin_width<Cfg, TIN>();
-      tin_jl = lane % TW;
-      f = (lane / TW) % Cfg::FPW;
-      tid = (lane / (TW * Cfg::FPW)) * TW + tin_jl;
-    }
+    constexpr unsigned TW = tin_width<Cfg, TIN>();
+    tin_jl = lane % TW;
+    f = (lane / TW) % Cfg::FPW;
+    tid = (lane / (TW * Cfg::FPW)) * TW + tin_jl;
     live = static_cast<long long>(f) < nlive;
   }
   // LDS copy of the leading twiddle tables: behind the image, unless the launch says otherwise (strided_args::twl_lds_off)
@@ -347,14 +339,9 @@ PFA_DEV void strided_passes_range(const IO& io, const strided_args& a, unsigned 
 template <typename Cfg, int TIN = 1>
 PFA_DEV void tin_lanes(unsigned* f, unsigned* tid, bool* live, long long nlive) {
   const unsigned lane = threadIdx.x;
-  if constexpr (TIN < 0) {
-    *f = lane / Cfg::TPF;
-    *tid = lane % Cfg::TPF;
-  } else {
-    constexpr unsigned TW = tin_width<Cfg, TIN>();
-    *f = (lane / TW) % Cfg::FPW;
-    *tid = (lane / (TW * Cfg::FPW)) * TW + lane % TW;
-  }
+  constexpr unsigned TW = tin_width<Cfg, TIN>();
+  *f = (lane / TW) % Cfg::FPW;
+  *tid = (lane / (TW * Cfg::FPW)) * TW + lane % TW;
   *live = static_cast<long long>(*f) < nlive;
 }
 

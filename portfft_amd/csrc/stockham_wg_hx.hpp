@@ -161,17 +161,16 @@ PFA_DEV void hxw_exchange(cx<typename Cfg::T> (&v)[Cfg::bpt(P)][Cfg::Seq::r[P]],
 
 /// `after_first_exchange(v)`: called once the exchange behind pass 0 has moved pass 0's outputs out of `v` -- the
 /// software-pipelined kernel (PF = 1) issues the NEXT transform's loads into those registers there.
-/// `before_last_pass()`: called behind the last exchange, when the image is idle for the rest of the transform -- the
-/// LDS-DMA form (PF = 2) starts the next transform's first half on its way into the image there.
-template <typename Cfg, bool BWD, int P, typename IO, typename Hook, typename Hook2>
+/// (Round 5's LDS-DMA form -- PF = 2: the next transform's first half on its way into the idle image behind the last
+///  exchange, bit-identical, +0 ... 3 %, profiles/r5_hx_tune_lds_dma.txt -- left this header in round 6; its source is
+///  stockham_wg_hx.hpp:234-288 of commit b38555f.)
+template <typename Cfg, bool BWD, int P, typename IO, typename Hook>
 PFA_DEV void hxw_passes(cx<typename Cfg::T> (&v)[Cfg::bpt(P)][Cfg::Seq::r[P]], const IO& io, unsigned tid,
                         cx<typename Cfg::T>* img, const cx<typename Cfg::T>* twl,
-                        const cx<typename Cfg::T>* __restrict__ tw, typename Cfg::T scale, Hook&& after_first_exchange,
-                        Hook2&& before_last_pass) {
+                        const cx<typename Cfg::T>* __restrict__ tw, typename Cfg::T scale, Hook&& after_first_exchange) {
   using T = typename Cfg::T;
   using Seq = typename Cfg::Seq;
   constexpr int R = Seq::r[P], Ns = Seq::ns(P);
-  if constexpr (P == Cfg::NP - 1) before_last_pass();
   sfor<0, Cfg::bpt(P)>([&](auto i_) PFA_LAMBDA {
     constexpr int i = decltype(i_)::value;
     const unsigned j = tid + i * Cfg::TPF;
@@ -205,7 +204,7 @@ PFA_DEV void hxw_passes(cx<typename Cfg::T> (&v)[Cfg::bpt(P)][Cfg::Seq::r[P]], c
     cx<T> n[Cfg::bpt(P + 1)][Seq::r[P + 1]];
     hxw_exchange<Cfg, P>(v, n, tid, img);
     if constexpr (P == 0) after_first_exchange(v);
-    hxw_passes<Cfg, BWD, P + 1>(n, io, tid, img, twl, tw, scale, after_first_exchange, before_last_pass);
+    hxw_passes<Cfg, BWD, P + 1>(n, io, tid, img, twl, tw, scale, after_first_exchange);
   }
 }
 
@@ -231,68 +230,10 @@ PFA_DEV void hxw_load(const IO& io, unsigned tid, cx<typename Cfg::T> (&v)[Cfg::
   });
 }
 
-/// LDS-DMA form: the legs t < wg_hx_dma_legs of pass 0 (the first D * N / R0 elements of the transform, contiguous in
-/// HBM) travel by `buffer_load_dwordx4 ... lds` into the image, natural order, no registers involved
-template <typename Cfg>
-constexpr int wg_hx_dma_legs() {
-  constexpr int R = Cfg::Seq::r[0], NB = Cfg::N / R;
-  int d = wg_hx_image_elems<Cfg>() / NB;
-  d = d < R ? d : R;
-  // whole 1 KiB wave-instructions only: the last one must not run past the image
-  while (d > 0 && (size_t(d) * NB * sizeof(cx<typename Cfg::T>) + 1023) / 1024 * 1024 >
-                      size_t(wg_hx_image_elems<Cfg>()) * sizeof(cx<typename Cfg::T>))
-    --d;
-  return d;
-}
-template <typename Cfg, typename IO>
-PFA_DEV void hxw_dma_issue(const IO& io, unsigned tid, cx<typename Cfg::T>* img) {
-  constexpr unsigned BYTES = unsigned(wg_hx_dma_legs<Cfg>()) * (Cfg::N / Cfg::Seq::r[0]) * sizeof(cx<typename Cfg::T>);
-  constexpr unsigned NI = (BYTES + 1023) / 1024, NW = Cfg::WG / 64;
-  const unsigned wave = __builtin_amdgcn_readfirstlane(tid / 64u);
-  const unsigned lane = tid % 64u;
-  char* raw = reinterpret_cast<char*>(img);
-  sfor<0, (NI + NW - 1) / NW>([&](auto k_) PFA_LAMBDA {
-    constexpr unsigned k = decltype(k_)::value;
-    const unsigned idx = k * NW + wave;
-    if ((k + 1) * NW <= NI || idx < NI) {
-      // one wave-instruction moves 1 KiB: lane l's 16 bytes land at the uniform LDS address + 16 l; bytes past the
-      // transform's end are out of the buffer's range (zeros)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(io.rin, (__attribute__((address_space(3))) void*)(raw + idx * 1024u), 16,
-                                               idx * 1024u + lane * 16u, 0, 0, aux_of_loads(Cfg::AUX));
-    }
-  });
-}
-/// ... and pass 0 picks them up there (legs D and up come straight from HBM, issued first)
-template <typename Cfg, bool BWD, typename IO>
-PFA_DEV void hxw_load_dma(const IO& io, unsigned tid, cx<typename Cfg::T> (&v)[Cfg::bpt(0)][Cfg::Seq::r[0]],
-                          const cx<typename Cfg::T>* img) {
-  constexpr int R = Cfg::Seq::r[0], NB = Cfg::N / R, D = wg_hx_dma_legs<Cfg>();
-  hxw_load<Cfg, BWD, D>(io, tid, v);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();  // every wave's share of the image has landed
-  sfor<0, Cfg::bpt(0)>([&](auto i_) PFA_LAMBDA {
-    constexpr int i = decltype(i_)::value;
-    constexpr bool none = i * Cfg::TPF >= NB, all = (i + 1) * Cfg::TPF <= NB;
-    if constexpr (!none) {
-      unsigned j = tid + i * Cfg::TPF;
-      if constexpr (!all) j = j < static_cast<unsigned>(NB) ? j : static_cast<unsigned>(NB - 1);
-      sfor<0, D>([&](auto t_) PFA_LAMBDA {
-        constexpr int t = decltype(t_)::value;
-        cx<typename Cfg::T> x = img[j + t * NB];
-        if constexpr (BWD) x.im = -x.im;
-        v[i][t] = x;
-      });
-    }
-  });
-  __syncthreads();  // the image is free for the first exchange
-}
-
 /// Body shared by the interleaved and the split-storage kernels (`make_io(g)`: the transform's I/O object).
 /// PF: software-pipelined -- the next transform's HBM loads are issued behind the first exchange, into the registers
 /// pass 0 has just vacated, and are in flight through the remaining passes (for transforms that leave a lane that many
 /// registers: 2 x the transform + a butterfly's temporaries; fp64 8192 on 512 lanes, fp32 16384 on 1024)
-/// PF = 2: LDS-DMA form (interleaved storage) -- the next transform's first half is on its way into the image, idle
-/// behind the last exchange, while the last pass computes and stores; it needs no registers at all
 template <typename Cfg, bool BWD, int PF = 0, typename MakeIO>
 PFA_DEV void stockham_wg_hx_body(MakeIO&& make_io, const cx<typename Cfg::T>* __restrict__ tw, long long nfft,
                                  typename Cfg::T scale) {
@@ -310,28 +251,18 @@ PFA_DEV void stockham_wg_hx_body(MakeIO&& make_io, const cx<typename Cfg::T>* __
   if constexpr (PF == 1) {
     if (static_cast<long long>(blockIdx.x) < nfft) hxw_load<Cfg, BWD>(make_io(blockIdx.x), tid, v);
   }
-  if constexpr (PF == 2) {
-    if (static_cast<long long>(blockIdx.x) < nfft) hxw_dma_issue<Cfg>(make_io(blockIdx.x), tid, img);
-  }
   for (long long g = blockIdx.x; g < nfft; g += gridDim.x) {
     const auto io = make_io(g);
     if constexpr (PF == 0) hxw_load<Cfg, BWD>(io, tid, v);
-    if constexpr (PF == 2) hxw_load_dma<Cfg, BWD>(io, tid, v, img);
     const cx<T>* twp = tw;
     asm volatile("" : "+s"(twp));  // keep the table reads inside the loop (see stockham_wg_body)
     const long long gn = g + gridDim.x;
-    hxw_passes<Cfg, BWD, 0>(
-        v, io, tid, img, twl, twp, scale,
-        [&](cx<T> (&regs)[Cfg::bpt(0)][Cfg::Seq::r[0]]) PFA_LAMBDA {
-          if constexpr (PF == 1) {
-            if (gn < nfft) hxw_load<Cfg, BWD>(make_io(gn), tid, regs);
-          }
-        },
-        [&]() PFA_LAMBDA {
-          if constexpr (PF == 2) {
-            if (gn < nfft) hxw_dma_issue<Cfg>(make_io(gn), tid, img);
-          }
-        });
+    hxw_passes<Cfg, BWD, 0>(v, io, tid, img, twl, twp, scale,
+                            [&](cx<T> (&regs)[Cfg::bpt(0)][Cfg::Seq::r[0]]) PFA_LAMBDA {
+                              if constexpr (PF == 1) {
+                                if (gn < nfft) hxw_load<Cfg, BWD>(make_io(gn), tid, regs);
+                              }
+                            });
   }
 }
 

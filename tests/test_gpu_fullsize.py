@@ -602,11 +602,14 @@ def test_four_step_half_pairs_and_split_choice():
 
 
 @pytest.mark.gpu
-def test_row_lanes_form_of_a_runtime_stage_b():
-    """PFFT_TIN_ROWS=1 (opt-in, profiles/r5_notes.md section 12): the runtime-specialised stage B of a four-step length
-    without a tiled intermediate reads its row-major input with the lanes along the row (strided_pass TIN = -1, ragged
-    passes included: 1000 points on 52 lanes x 2, 660 on 40 x 3).  Against NumPy, the round trip, and the default plan of
-    the same descriptor."""
+def test_runtime_specialised_stage_b_on_a_row_major_intermediate():
+    """Four-step lengths without a registered stage pair and without a tiled intermediate (n2 or its first pass no multiple
+    of stage A's group width: 10^6 = 1000 x 1000, 68640 = 104 x 660, 250000): both stages are compiled at commit, stage B
+    reads the row-major intermediate f-fastest.  With PFFT_ROW_IN_MAX_N=0 no stage-B length is staged through LDS, so that
+    form runs for every one of them (ragged passes included: 1000 points on 52 lanes x 2, 660 on 30 x 3 -- the latter on the
+    register-resident stage kernel, stockham_strided_hx.hpp), stage A walks its groups XCD-contiguously where its row pitch
+    is no multiple of a line.  Against NumPy, the round trip, and the default plan of the same descriptor.  (Round 5's opt-in
+    row-lanes form of that stage B, PFFT_TIN_ROWS=1, was measured out and removed in round 6: profiles/r5_perf_tin_rows.txt.)"""
     G, pf, torch = _mods()
 
     def commit(n, prec, batch, env):
@@ -627,7 +630,7 @@ def test_row_lanes_form_of_a_runtime_stage_b():
         g = torch.Generator(device="cuda").manual_seed(n % 1000 + batch)
         x = torch.empty(batch * n, dtype=cdt, device="cuda")
         torch.view_as_real(x).uniform_(-1, 1, generator=g)
-        plan = commit(n, prec, batch, {"PFFT_TIN_ROWS": "1", "PFFT_ROW_IN_MAX_N": "0"})
+        plan = commit(n, prec, batch, {"PFFT_ROW_IN_MAX_N": "0"})
         assert plan.info().dims[0].tier == 3 and plan.info().knob_mask != 0, (n, prec)
         y = torch.empty_like(x)
         plan.compute_forward(x, y).wait()

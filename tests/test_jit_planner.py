@@ -24,7 +24,7 @@ def test_planner_invariants_and_hiprtc_compile():
     p = subprocess.run([EXE, "compile"], capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stdout + p.stderr
     assert "jit planner OK" in p.stdout
-    assert p.stdout.count("hiprtc n=") == 26  # (+ 3 lengths x 2 forms of the register-resident strided kernel)
+    assert p.stdout.count("hiprtc n=") == 24  # (round 6: + 3 lengths x 2 forms of the register-resident strided kernel, - 2 row-lanes)
     assert p.stdout.count("hiprtc nd ") == 3
 
 

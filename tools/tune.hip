@@ -144,19 +144,12 @@ int main() {
   add_hx<wg_cfg<f, radix_list<16, 16, 16, 8>, 512, 1, 16, 1, TW_GLOBAL, 2, NT, 0, 1>>("hx 16.16.16.8 wg512 TWL1");
   add_hx<wg_cfg<f, radix_list<8, 16, 16, 16>, 1024, 1, 8, 1, TW_GLOBAL, 4, NT, 0, 2>>("hx 8.16.16.16 wg1024 TWL2");
   add_hx<wg_cfg<f, radix_list<32, 32, 32>, 1024, 1, 32, 1, TW_GLOBAL, 4, NT, 0, 0>>("hx 32.32.32 wg1024 TWL0");
-  add_hx_pf<wg_cfg<f, radix_list<32, 32, 32>, 1024, 1, 32, 1, TW_GLOBAL, 4, NT, 0, 1>, 2>("hx 32.32.32 wg1024 TWL1 DMA");
-  add_hx_pf<wg_cfg<f, radix_list<32, 32, 32>, 1024, 1, 0, 0, TW_GLOBAL, 4, NT, 0, 1>, 2>("hx 32.32.32 wg1024 TWL1 nopad DMA");
-  add_hx_pf<wg_cfg<f, radix_list<32, 32, 32>, 512, 1, 32, 1, TW_GLOBAL, 2, NT, 0, 1>, 2>("hx 32.32.32 wg512 TWL1 DMA");
-  add_hx_pf<wg_cfg<f, radix_list<16, 16, 16, 8>, 1024, 1, 16, 1, TW_GLOBAL, 4, NT, 0, 1>, 2>("hx 16.16.16.8 wg1024 TWL1 DMA");
 #elif TUNE_CASE == 16384064  // fp64 16384: the same 256 KiB
   using T = d; const int N = 16384;
   add_hx<wg_cfg<d, radix_list<16, 32, 32>, 512, 1, 16, 1, TW_GLOBAL, 2, NT, 0, 1>>("f64 hx 16.32.32 wg512 TWL1");
   add_hx<wg_cfg<d, radix_list<16, 16, 8, 8>, 512, 1, 16, 1, TW_GLOBAL, 2, NT, 0, 1>>("f64 hx 16.16.8.8 wg512 TWL1");
   add_hx<wg_cfg<d, radix_list<16, 16, 8, 8>, 1024, 1, 16, 1, TW_GLOBAL, 4, NT, 0, 1>>("f64 hx 16.16.8.8 wg1024 TWL1");
   add_hx<wg_cfg<d, radix_list<8, 8, 16, 16>, 512, 1, 8, 1, TW_GLOBAL, 2, NT, 0, 2>>("f64 hx 8.8.16.16 wg512 TWL2");
-  add_hx_pf<wg_cfg<d, radix_list<16, 32, 32>, 512, 1, 16, 1, TW_GLOBAL, 2, NT, 0, 1>, 2>("f64 hx 16.32.32 wg512 TWL1 DMA");
-  add_hx_pf<wg_cfg<d, radix_list<32, 32, 16>, 512, 1, 32, 1, TW_GLOBAL, 2, NT, 0, 1>, 2>("f64 hx 32.32.16 wg512 TWL1 DMA");
-  add_hx_pf<wg_cfg<d, radix_list<16, 16, 8, 8>, 512, 1, 16, 1, TW_GLOBAL, 2, NT, 0, 1>, 2>("f64 hx 16.16.8.8 wg512 TWL1 DMA");
   add_hx<wg_cfg<d, radix_list<16, 32, 32>, 512, 1, 16, 1, TW_GLOBAL, 2, NT, 0, 1>>("f64 hx 16.32.32 wg512 TWL1 (again)");
 #elif TUNE_CASE == 8192064  // fp64 8192 (reference WorkgroupOrGlobal size): LDS-resident production entry against register-resident forms
   using T = d; const int N = 8192;
@@ -167,8 +160,6 @@ int main() {
   add_hx_pf<wg_cfg<d, radix_list<16, 32, 16>, 512, 1, 16, 1, TW_GLOBAL, 2, NT, 0, 1>>("f64 hx 16.32.16 wg512 PF");
   add_hx_pf<wg_cfg<d, radix_list<16, 16, 32>, 256, 1, 16, 1, TW_GLOBAL, 1, NT, 0, 1>>("f64 hx 16.16.32 wg256 PF");
   add_hx<wg_cfg<d, radix_list<16, 16, 32>, 1024, 1, 16, 1, TW_GLOBAL, 4, NT, 0, 1>>("f64 hx 16.16.32 wg1024");
-  add_hx_pf<wg_cfg<d, radix_list<16, 32, 16>, 512, 1, 16, 1, TW_GLOBAL, 2, NT, 0, 1>, 2>("f64 hx 16.32.16 wg512 DMA");
-  add_hx_pf<wg_cfg<d, radix_list<16, 32, 16>, 1024, 1, 16, 1, TW_GLOBAL, 4, NT, 0, 1>, 2>("f64 hx 16.32.16 wg1024 DMA");
 #elif TUNE_CASE == 16387  // fp32 16384: the TW_REGS production entry against register-resident forms
   using T = f; const int N = 16384;
   add<wg_cfg<f, radix_list<32, 16, 32>, 512, 1, 0, 0, TW_REGS, 2, NT>, false>("r32.16.32 twR wg512 (production)");
@@ -177,9 +168,6 @@ int main() {
   add_hx_pf<wg_cfg<f, radix_list<32, 32, 16>, 512, 1, 32, 1, TW_GLOBAL, 2, NT, 0, 1>>("hx 32.32.16 wg512 PF");
   add_hx_pf<wg_cfg<f, radix_list<32, 16, 32>, 512, 1, 32, 1, TW_GLOBAL, 2, NT, 0, 1>>("hx 32.16.32 wg512 PF");
   add_hx_pf<wg_cfg<f, radix_list<16, 32, 32>, 1024, 1, 16, 1, TW_GLOBAL, 4, NT, 0, 1>>("hx 16.32.32 wg1024 PF");
-  add_hx_pf<wg_cfg<f, radix_list<32, 32, 16>, 1024, 1, 32, 1, TW_GLOBAL, 4, NT, 0, 1>, 2>("hx 32.32.16 wg1024 DMA");
-  add_hx_pf<wg_cfg<f, radix_list<32, 32, 16>, 512, 1, 32, 1, TW_GLOBAL, 2, NT, 0, 1>, 2>("hx 32.32.16 wg512 DMA");
-  add_hx_pf<wg_cfg<f, radix_list<32, 16, 32>, 512, 1, 32, 1, TW_GLOBAL, 2, NT, 0, 1>, 2>("hx 32.16.32 wg512 DMA");
 #elif TUNE_CASE == 16388  // fp32 16384: register-resident forms with TWO work-groups per CU (half images of 64 KiB)
   using T = f; const int N = 16384;
   add<wg_cfg<f, radix_list<32, 16, 32>, 512, 1, 0, 0, TW_REGS, 2, NT>, false>("r32.16.32 twR wg512 (production)");
@@ -188,8 +176,6 @@ int main() {
   add_hx<wg_cfg<f, radix_list<16, 32, 32>, 512, 1, 16, 1, TW_GLOBAL, 4, NT, 0, 1>>("hx 16.32.32 wg512 occ4");
   add_hx<wg_cfg<f, radix_list<32, 32, 16>, 256, 1, 32, 1, TW_GLOBAL, 2, NT, 0, 1>>("hx 32.32.16 wg256 occ2");
   add_hx<wg_cfg<f, radix_list<16, 16, 8, 8>, 512, 1, 16, 1, TW_GLOBAL, 4, NT, 0, 2>>("hx 16.16.8.8 wg512 occ4");
-  add_hx_pf<wg_cfg<f, radix_list<32, 32, 16>, 512, 1, 32, 1, TW_GLOBAL, 4, NT, 0, 1>, 2>("hx 32.32.16 wg512 occ4 DMA");
-  add_hx_pf<wg_cfg<f, radix_list<32, 16, 32>, 512, 1, 32, 1, TW_GLOBAL, 4, NT, 0, 1>, 2>("hx 32.16.32 wg512 occ4 DMA");
   add_hx<wg_cfg<f, radix_list<32, 32, 16>, 1024, 1, 32, 1, TW_GLOBAL, 8, NT, 0, 1>>("hx 32.32.16 wg1024 occ8");
 #elif TUNE_CASE == 8192065  // fp64 8192: ... the same
   using T = d; const int N = 8192;
@@ -198,7 +184,6 @@ int main() {
   add_hx<wg_cfg<d, radix_list<16, 16, 32>, 512, 1, 16, 1, TW_GLOBAL, 4, NT, 0, 1>>("f64 hx 16.16.32 wg512 occ4");
   add_hx<wg_cfg<d, radix_list<32, 16, 16>, 256, 1, 32, 1, TW_GLOBAL, 2, NT, 0, 1>>("f64 hx 32.16.16 wg256 occ2");
   add_hx<wg_cfg<d, radix_list<16, 32, 16>, 256, 1, 16, 1, TW_GLOBAL, 2, NT, 0, 1>>("f64 hx 16.32.16 wg256 occ2");
-  add_hx_pf<wg_cfg<d, radix_list<16, 32, 16>, 512, 1, 16, 1, TW_GLOBAL, 4, NT, 0, 1>, 2>("f64 hx 16.32.16 wg512 occ4 DMA");
 #elif TUNE_CASE == 8192066  // fp64 8192 pair: padding of the 128-bit exchange image (21 % conflict cycles with period 16)
   using T = d; const int N = 8192;
   add_hx<wg_cfg<d, radix_list<16, 32, 16>, 256, 1, 16, 1, TW_GLOBAL, 2, NT, 0, 1>>("f64 hx 16.32.16 wg256 pad 16/1 (production)");
