@@ -168,6 +168,7 @@ plan_knobs plan_knobs::from_env() {
   mark(k.xcd_max_iters >= 0);
   onoff("PFFT_XCD_CONTIG", &k.xcd_contig);
   onoff("PFFT_HX_OVER_REGISTERED", &k.hx_over_registered);
+  onoff("PFFT_GROUP_SCATTER", &k.group_scatter);
   return k;
 }
 
@@ -450,11 +451,13 @@ const strided_kernel* plan_t::get_strided(long long n, long long inner_count, bo
                                           bool column_both, bool row_side, int policy) {
   if (user_split) policy = 0;
   const strided_kernel* k = find_strided(n, column_both, row_side && !user_split, inner_count, policy, store_modifier);
-  // A registered entry that sits alone on its CU (n = 1024 x 16 columns: 128 KiB of LDS) against the register-resident
-  // form of the same group, two work-groups per CU (stockham_strided_hx.hpp) -- column-shaped stages without the store
-  // modifier only: with it the kernels of that size need scratch
-  if (k != nullptr && kn.hx_over_registered && k->lds_bytes > 80 * 1024 && column_both && !store_modifier && !row_side &&
-      !user_split && jit_enabled()) {
+  // A registered entry that sits alone on its CU (n = 1024: 128 KiB of LDS) against the register-resident form of the same
+  // group, two work-groups per CU (stockham_strided_hx.hpp) -- column-shaped stages without the store modifier.  fp64 only:
+  // BI N = 1024 x 8 columns 0.578 -> 0.624, at a batch of 66 000 0.543-0.558 -> 0.586; in fp32 the registered 32.32
+  // software-pipelined kernel holds 0.60-0.64 against 0.54-0.63 (profiles/r6_hx_over_registered.txt).  Costs that length's
+  // first commit one hiprtc compilation (then the disk cache).
+  if (k != nullptr && kn.hx_over_registered && desc.precision == PFFT_PRECISION_F64 && k->lds_bytes > 80 * 1024 &&
+      column_both && !store_modifier && !row_side && !user_split && jit_enabled()) {
     wg_params p;
     if (choose_strided_params(desc.precision, n, inner_count, max_lds, &p, column_both, k->fpw) &&
         !strided_hx_candidates(p, max_lds).empty()) {

@@ -21,8 +21,8 @@ def one(case):
     es = 8 if prec == "f32" else 16
     cdt = torch.complex64 if prec == "f32" else torch.complex128
     if what.startswith("bi"):
-        n = int(what[2:])
-        batch = 4096 * max(1, (1 << 30) // (n * es * 4096))
+        n = int(what[2:].split("@")[0])  # "bi1024@132000": that batch count
+        batch = int(what.split("@")[1]) if "@" in what else 4096 * max(1, (1 << 30) // (n * es * 4096))
         lengths = [n]
         d = pf.descriptor(lengths, prec)
         d.number_of_transforms = batch
