@@ -172,7 +172,6 @@ struct plan_knobs {
   bool no_split_tiled = false, no_wide_tiles = false, two_pass_2d_off = false, jit_verbose = false;
   bool split_cached = true, pair_xcd = true, stop_event_on_launch = true, xcd_check = false;
   bool xcd_contig = true;  // PFFT_XCD_CONTIG=0: no XCD-contiguous group walk for stages with unaligned row pitches
-  bool group_scatter = false;  // PFFT_GROUP_SCATTER=1 (experiment): consecutive blocks of a column-shaped stage take far-apart groups
   bool hx_over_registered = true;  // PFFT_HX_OVER_REGISTERED=0: a registered one-per-CU fp64 strided entry is not replaced by a register-resident plan
   // overrides (unset: -1 / 0 / empty)
   int chunk_overlap = 2, jit_groups_per_wg = -1, groups_per_wg = 0, xcd_slots = 0, xcd_lag = 0;

@@ -168,7 +168,6 @@ plan_knobs plan_knobs::from_env() {
   mark(k.xcd_max_iters >= 0);
   onoff("PFFT_XCD_CONTIG", &k.xcd_contig);
   onoff("PFFT_HX_OVER_REGISTERED", &k.hx_over_registered);
-  onoff("PFFT_GROUP_SCATTER", &k.group_scatter);
   return k;
 }
 

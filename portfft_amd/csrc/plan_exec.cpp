@@ -139,12 +139,6 @@ void plan_t::run_stage(const stage& s, const void* in_re, const void* in_im, voi
           s.strided->fpw > 1 && grid >= 64 && kn.xcd_contig) {
         a.pair_xcd = 2;
       }
-      // (experiment: scattered group order for column-shaped input at a large power-of-two pitch)
-      const long long per_outer = (a.inner + s.strided->fpw - 1) / s.strided->fpw;
-      if (kn.group_scatter && a.pair_xcd == 0 && column_in && a.in_gdist == 0 && a.out_gdist == 0 && per_outer % 64 == 0 &&
-          per_outer >= 512 && s.row_mode == 0) {
-        a.pair_xcd = 3;
-      }
     }
     if (split && (s.in_buf == BUF_SCRATCH) != (s.out_buf == BUF_SCRATCH)) {  // mixed storage (four-step stages)
       const bool in_user = s.in_buf != BUF_SCRATCH;

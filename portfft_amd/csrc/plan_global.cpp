@@ -946,6 +946,9 @@ int plan_t::plan_1d(std::vector<stage>& out, long long n, long long count, long 
              (half_pair || ka->fn[0] != nullptr) && !kn.no_ltw &&
              !kn.debug_global_set &&
              strided_fits(ka, n2, in_buf, addressing{ia.offset, n2, 1, n}, BUF_SCRATCH, addressing{0, n2, 1, n});
+  // (Round 6 measured both extensions of this and adopted neither, profiles/r6_stage_a_hx_and_jit_overlap.txt: the overlap for
+  //  plans whose stage A is compiled at commit LOSES -- 68640 0.307 -> 0.277, 62500 0.278 -> 0.248, 10^6 0.256 -> 0.245 --, and the
+  //  register-resident form of the registered one-per-CU stage A of a pair changes nothing: C3 0.362-0.364 against 0.358-0.360.)
   // Scratch: one chunk -- or two halves that alternate when consecutive chunks overlap (the first launch of chunk
   // c + 1 without the in-order barrier).  Only a pre-compiled interleaved stage A can launch that way (pfa_launch);
   // plans on mixed-storage, runtime-compiled or generic stages keep ONE buffer, and a plan whose chunk is the scratch

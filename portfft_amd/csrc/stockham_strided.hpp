@@ -416,12 +416,6 @@ PFA_DEV strided_io<typename Cfg::T, Cfg::AUX, SPLIT> strided_group(const strided
   constexpr unsigned ES_IN = IO::ES_IN, ES_OUT = IO::ES_OUT;
   const long long per_outer = (a.inner + Cfg::FPW - 1) / Cfg::FPW;
   const long long o = g / per_outer;
-  // pair_xcd 3 ("scatter", experiment PFFT_GROUP_SCATTER=1): consecutive blocks take groups per_outer / 64 apart -- a 64-way
-  // transposition of the group index inside its outer index (the host sets it only when per_outer % 64 == 0)
-  if (a.pair_xcd == 3) {
-    const long long gw0 = g - o * per_outer;
-    g = o * per_outer + (gw0 & 63) * (per_outer >> 6) + (gw0 >> 6);
-  }
   const long long c0 = (g - o * per_outer) * Cfg::FPW;
   const long long t0 = o * a.inner + c0;
   const long long nlive = (a.inner - c0 < a.total - t0) ? a.inner - c0 : a.total - t0;
