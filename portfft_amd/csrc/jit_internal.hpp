@@ -54,7 +54,6 @@ struct jit_knobs {
   bool strided_hx = true;                 ///< PFFT_JIT_STRIDED_HX=0: no register-resident strided kernels
   long strided_hx_min_kib = 80;           ///< PFFT_JIT_STRIDED_HX_MIN_KIB: groups above this take the half-image form
   const char* strided_hx_force = nullptr; ///< PFFT_JIT_STRIDED_HX_FORCE=tpf:per_cu
-  bool strided_pf = false;                ///< PFFT_JIT_STRIDED_PF=1 (experiment): groups alone on their CU software-pipelined
 
   static jit_knobs from_env() {
     jit_knobs k;
@@ -90,7 +89,6 @@ struct jit_knobs {
     if (const char* e = str("PFFT_JIT_STRIDED_HX")) k.strided_hx = e[0] != '0';
     k.strided_hx_min_kib = num("PFFT_JIT_STRIDED_HX_MIN_KIB", 80);
     k.strided_hx_force = str("PFFT_JIT_STRIDED_HX_FORCE");
-    k.strided_pf = num("PFFT_JIT_STRIDED_PF", 0) != 0;
     return k;
   }
 };

@@ -366,6 +366,11 @@ void add_rows2d_entries(std::vector<rows2d_kernel>& v, int groups_per_wg) {
   v.push_back(k);
   rows2d_kernel w = make_rows2d_entry<with_aux_t<Cfg, PFA_AUX_WRITER>>(groups_per_wg);
   w.policy = 1;
+  // (round 6: the split-storage form of the writer twin too -- the two-pass 2-D plan of SPLIT_COMPLEX data in cache-sized chunks)
+  using WCfg = with_aux_t<Cfg, PFA_AUX_WRITER>;
+  w.fn_split[0] = reinterpret_cast<const void*>(&stockham_rows2d_kernel<WCfg, false, true>);
+  w.fn_split[1] = reinterpret_cast<const void*>(&stockham_rows2d_kernel<WCfg, true, true>);
+  w.launch_split = &launch_rows2d_split<WCfg>;
   v.push_back(w);
 }
 
@@ -597,6 +602,12 @@ strided_kernel make_strided_twin(const strided_kernel& base, int policy) {
     }
     if constexpr ((F & SE_TIN) != 0) k = with_tin<Cfg, PF, (F & SE_LTW) != 0 ? 1 : 0>(k);
     if constexpr ((F & SE_TIN_W) != 0) k = with_tin_w<Cfg>(k);
+    // (round 6: the reader twin of a wide entry -- the second pass of the two-pass 2-D plan -- carries its split-storage form)
+    if constexpr ((F & SE_WIDE) != 0 && !PF) {
+      k.fn_split[0] = reinterpret_cast<const void*>(&stockham_strided_kernel<Cfg, false, false, true>);
+      k.fn_split[1] = reinterpret_cast<const void*>(&stockham_strided_kernel<Cfg, true, false, true>);
+      k.launch_split = &launch_strided_split<Cfg>;
+    }
   }
   return k;
 }

@@ -172,12 +172,14 @@ struct plan_knobs {
   bool no_split_tiled = false, no_wide_tiles = false, two_pass_2d_off = false, jit_verbose = false;
   bool split_cached = true, pair_xcd = true, stop_event_on_launch = true, xcd_check = false;
   bool xcd_contig = true;  // PFFT_XCD_CONTIG=0: no XCD-contiguous group walk for stages with unaligned row pitches
+  bool no_split_2d_cached = false;  // PFFT_NO_SPLIT_2D_CACHED=1: the two-pass 2-D plan of SPLIT_COMPLEX data streamed, one launch per pass (round 5)
   bool hx_over_registered = true;  // PFFT_HX_OVER_REGISTERED=0: a registered one-per-CU fp64 strided entry is not replaced by a register-resident plan
   // overrides (unset: -1 / 0 / empty)
   int chunk_overlap = 2, jit_groups_per_wg = -1, groups_per_wg = 0, xcd_slots = 0, xcd_lag = 0;
   int row_in_max_n = 512;  // PFFT_ROW_IN_MAX_N: longest stage whose row-shaped INPUT is staged through LDS
   bool groups_per_wg_set = false, global_chunk_mib_set = false, cache_chunk_mib_set = false;
   long global_chunk_mib = 0, cache_chunk_mib = 0;
+  long long bi_n1 = 0;  // PFFT_BI_N1 (experiment): first factor of the two-stage batch-interleaved plan
   long long global_n1 = 0, three_stage_min = 0, three_stage_n3 = 0, xcd_min_batch = -1, xcd_max_iters = -1;
   std::string debug_global, global_layout;
   static plan_knobs from_env();
@@ -290,6 +292,7 @@ struct plan_t {
   bool strided_fits(const strided_kernel* k, long long inner_count, int in_buf, const addressing& ia, int out_buf,
                     const addressing& oa) const;
   const rows2d_kernel* find_rows2d(long long n1, long long n0, int policy, bool split = false);
+  const rows2d_kernel* find_rows2d_registered(long long n1, long long n0, int policy, bool split) const;
   /// W_n^m for m in [0, n): the inter-pass column twiddles of the two-pass 2-D plan
   const void* upload_unit_roots(long long n);
   stage make_rows2d_stage(const rows2d_kernel* k, long long nmat, long long n0, long long in_off, long long out_off,

@@ -168,6 +168,9 @@ plan_knobs plan_knobs::from_env() {
   mark(k.xcd_max_iters >= 0);
   onoff("PFFT_XCD_CONTIG", &k.xcd_contig);
   onoff("PFFT_HX_OVER_REGISTERED", &k.hx_over_registered);
+  flag("PFFT_NO_SPLIT_2D_CACHED", &k.no_split_2d_cached);
+  if (const char* e = set("PFFT_BI_N1")) k.bi_n1 = std::atoll(e);
+  mark(k.bi_n1 > 0);
   return k;
 }
 
@@ -448,7 +451,12 @@ int plan_t::strided_fpw(long long n, long long inner_count) const {
 /// policy: cache policy of the stage (strided_kernel::policy; 1 writer -- needs store_modifier --, 2 reader)
 const strided_kernel* plan_t::get_strided(long long n, long long inner_count, bool store_modifier, bool user_split,
                                           bool column_both, bool row_side, int policy) {
-  if (user_split) policy = 0;
+  // (split user planes: streamed kernels -- unless a registered policy twin carries its split form: the reader of the
+  //  two-pass 2-D plan's second pass, the only caller that asks for a policy on user planes)
+  if (user_split && policy != 0) {
+    const strided_kernel* t = find_strided(n, column_both, false, inner_count, policy, store_modifier);
+    if (t == nullptr || t->launch_split == nullptr) policy = 0;
+  }
   const strided_kernel* k = find_strided(n, column_both, row_side && !user_split, inner_count, policy, store_modifier);
   // A registered entry that sits alone on its CU (n = 1024: 128 KiB of LDS) against the register-resident form of the same
   // group, two work-groups per CU (stockham_strided_hx.hpp) -- column-shaped stages without the store modifier.  fp64 only:

@@ -229,6 +229,10 @@ bool plan_t::plan_batch_interleaved_two_stage(std::vector<stage>& out, long long
     }
   }
   if (n1 == 0) return false;
+  if (kn.bi_n1 > 0 && n % kn.bi_n1 == 0 && strided_fpw(kn.bi_n1, (n / kn.bi_n1) * B) >= full_fpw &&
+      strided_fpw(n / kn.bi_n1, B) >= full_fpw) {
+    n1 = kn.bi_n1;  // experiments (PFFT_BI_N1): the first factor of the two-stage BI plan
+  }
   const long long n2 = n / n1;
   // the intermediate is written once and read once: keep it in the Infinity Cache when all of it fits
   // (measured with random data, tools/perf_cache.py: +4...13 % from 128 MiB of intermediate up; below that the

@@ -3,7 +3,7 @@
 
 namespace pfa {
 
-const rows2d_kernel* plan_t::find_rows2d(long long n1, long long n0, int policy, bool split) {
+const rows2d_kernel* plan_t::find_rows2d_registered(long long n1, long long n0, int policy, bool split) const {
   if (kn.two_pass_2d_off) return nullptr;  // experiments / parity A-B: rows, then full-length columns
   int count = 0;
   const rows2d_kernel* k = rows2d_kernels(&count);
@@ -13,6 +13,12 @@ const rows2d_kernel* plan_t::find_rows2d(long long n1, long long n0, int policy,
       return &k[i];
     }
   }
+  return nullptr;
+}
+
+const rows2d_kernel* plan_t::find_rows2d(long long n1, long long n0, int policy, bool split) {
+  if (kn.two_pass_2d_off) return nullptr;
+  if (const rows2d_kernel* k = find_rows2d_registered(n1, n0, policy, split)) return k;
   // other row lengths / column counts: the same template instantiated at commit (jit.cpp) -- when the full-length
   // column pass it replaces would move segments below 256 bytes (measured, tools/perf_2d.py: 1080 x 1920 +27 %,
   // 1536^2 +29 %, 3000 x 1000 2.6x, 4096^2 2.1x; with 256-byte column segments available, 384^2 ... 960^2, the
@@ -133,8 +139,18 @@ void plan_t::build_direction(int direction) {
     const size_t matrix_bytes = static_cast<size_t>(n0) * static_cast<size_t>(n1) * elem_bytes();
     // (random data, tools/perf_cache.py: 1024^2 x 16 / 32 / 64 / 256 +6 / +13 / +7 / +2 %, 512^2 x 128 +9 %; a 32 MiB
     //  batch is 18 % faster with the streamed kernels, hence the lower bound)
-    // (SPLIT_COMPLEX storage: the streamed kernels, one launch per pass)
-    const bool cached = !split && cache_chunk_bytes() >= matrix_bytes &&
+    // SPLIT_COMPLEX storage: the same chunks and policies where both passes have a registered twin with its split form
+    // (round 6; rows of 256 ... 2048 points over a column pass of 64 ... 256 points: C5 in split storage ran the streamed kernels in
+    // one launch per pass at 0.34 against the interleaved plan's 0.39 -- profiles/r6_notes.md section 8); else streamed
+    bool split_twins = false;
+    if (split && !kn.no_split_2d_cached) {
+      const rows2d_kernel* w = find_rows2d_registered(n1, n0, 1, true);
+      if (w != nullptr) {
+        const strided_kernel* r = find_strided(n0 / w->rc, true, false, static_cast<long long>(w->rc) * n1, 2, false);
+        split_twins = r != nullptr && r->launch_split != nullptr;
+      }
+    }
+    const bool cached = (!split || split_twins) && cache_chunk_bytes() >= matrix_bytes &&
                         matrix_bytes * static_cast<size_t>(nmat) >= cache_chunk_bytes() / 2;
     const long long chunk_mats = cached ? even_chunks(std::max<long long>(1, std::min<long long>(
                                                           nmat, static_cast<long long>(cache_chunk_bytes() / matrix_bytes))),

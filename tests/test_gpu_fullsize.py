@@ -238,6 +238,62 @@ def test_python_mirror_events_dependencies_and_argument_checks():
     assert torch.equal(out, out2)
 
 
+def test_two_pass_2d_plan_of_split_storage_in_cache_sized_chunks():
+    """BASELINE config 5's shape in SPLIT_COMPLEX storage (round 6): from 128 MiB of data the two-pass 2-D plan of split planes
+    runs chunk by chunk on the writer / reader twins of its two registered kernels like the interleaved plan does
+    (plan_nd.cpp; the reference has one code path for both storages, committed_descriptor_impl.hpp:899-950).  A batch that leaves a
+    ragged last chunk, out of place and in place (a chunk then goes through the scratch's two halves), both directions,
+    against NumPy on sampled matrices and bit for bit against the streamed one-launch-per-pass plan
+    (PFFT_NO_SPLIT_2D_CACHED=1)."""
+    G, pf, torch = _mods()
+
+    def run_case(lengths, batch, prec, placement, env=None):
+        rt = torch.float32 if prec == "f32" else torch.float64
+        n = int(np.prod(lengths))
+        g = torch.Generator(device="cuda").manual_seed(23)
+        xr = torch.empty(batch * n, dtype=rt, device="cuda").uniform_(-1, 1, generator=g)
+        xi = torch.empty(batch * n, dtype=rt, device="cuda").uniform_(-1, 1, generator=g)
+        old = {k: os.environ.get(k) for k in (env or {})}
+        os.environ.update(env or {})
+        try:
+            plan = G.make_descriptor(lengths, prec, batch=batch, placement=placement, storage=1).commit()
+        finally:
+            for k, v in old.items():
+                if v is None:
+                    del os.environ[k]
+                else:
+                    os.environ[k] = v
+        if placement == 0:
+            yr, yi = xr.clone(), xi.clone()
+            plan.compute_forward(yr, yi).wait()
+        else:
+            yr, yi = torch.empty_like(xr), torch.empty_like(xi)
+            plan.compute_forward(xr, xi, yr, yi).wait()
+        return xr, xi, yr, yi, plan
+
+    tol = {"f32": 2e-6, "f64": 5e-15}
+    for lengths, batch, prec in (([1024, 1024], 37, "f32"), ([1024, 1024], 21, "f64")):
+        n = int(np.prod(lengths))
+        for placement in (1, 0):
+            xr, xi, yr, yi, plan = run_case(lengths, batch, prec, placement)
+            assert list(plan.info().launches)[0] > 2, "several chunks of two launches"
+            for b in (0, batch // 2, batch - 1):
+                x = (xr.view(batch, n)[b].cpu().numpy().astype(np.float64) + 1j * xi.view(batch, n)[b].cpu().numpy()).reshape(lengths)
+                ref = np.fft.fftn(x).ravel()
+                got = yr.view(batch, n)[b].cpu().numpy().astype(np.float64) + 1j * yi.view(batch, n)[b].cpu().numpy()
+                assert H.rel_l2(got, ref) <= tol[prec], (lengths, batch, prec, placement, b)
+            _, _, y0r, y0i, plan0 = run_case(lengths, batch, prec, placement, {"PFFT_NO_SPLIT_2D_CACHED": "1"})
+            assert list(plan0.info().launches)[0] == 2, "the streamed twin: one launch per pass"
+            assert torch.equal(yr, y0r) and torch.equal(yi, y0i), (lengths, batch, prec, placement)
+            zr, zi = torch.empty_like(xr), torch.empty_like(xi)
+            plan.compute_backward(yr, yi, zr, zi).wait()
+            err = float((((zr / n - xr).double().pow(2).sum() + (zi / n - xi).double().pow(2).sum()) /
+                         (xr.double().pow(2).sum() + xi.double().pow(2).sum())).sqrt())
+            assert err <= tol[prec], (lengths, batch, prec, placement, err)
+            del yr, yi, y0r, y0i, zr, zi
+        torch.cuda.empty_cache()
+
+
 def test_cache_sized_chunks_and_policy_twins():
     """The two-launch plans run chunk by chunk (256 MiB of intermediate per chunk) on the writer / reader cache-policy
     twins once the intermediate reaches 128 MiB: batch counts that leave a ragged last chunk, both directions, in-place

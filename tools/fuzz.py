@@ -1,5 +1,5 @@
 """Random descriptors against NumPy: rank, lengths (61-smooth), batch, layout (packed / batch-interleaved / unpacked rows /
-strided), storage, placement, offsets, scales, precision, direction.  usage: fuzz.py [seed] [iterations] [big2d|global|regres|pairs]
+strided), storage, placement, offsets, scales, precision, direction.  usage: fuzz.py [seed] [iterations] [big2d|global|regres|pairs|stages]
 With `big2d` the shapes are 2-D / 3-D with a long last dimension (256...2048): the two-pass 2-D plan
 (stockham_rows2d.hpp) and its fall-backs.  With `global` the lengths are four-step (GLOBAL tier) sizes: powers of two
 2^15 ... 2^21 (the registered stage pairs), 3 / 5 / 6 / 10 times powers of two, powers of ten, lengths with a prime factor
@@ -7,7 +7,11 @@ With `big2d` the shapes are 2-D / 3-D with a long last dimension (256...2048): t
 work-group's LDS (fp32 20481 ... 40000, fp64 10241 ... 20000): the register-resident kernel (stockham_wg_hx.hpp) with
 whatever radices and lanes its planner picks, or the four-step plan where it declines.  With `pairs` they are multiples
 of 16 between 80 and 152 KiB (fp32 10241 ... 19000, fp64 5121 ... 9500): the same kernel planned as two work-groups per CU, or
-the LDS-resident kernel where there is no such plan -- both storages, both placements, offsets, scales."""
+the LDS-resident kernel where there is no such plan -- both storages, both placements, offsets, scales.  With `stages` the
+lengths are 31-smooth lengths of 600 ... 1100 points (fp64: to 1100 too) in the batch-interleaved and mixed layouts with 16 ... 200
+transforms, or four-step lengths one of whose factors lies in that band: the register-resident strided stage kernel
+(stockham_strided_hx.hpp: groups that would sit alone on their CU) wherever its planner takes it, ragged passes and partial
+groups included, and the XCD-contiguous walk for the unaligned row pitches these lengths have."""
 import os, sys, random
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
@@ -46,6 +50,7 @@ def main():
     glob = len(sys.argv) > 3 and sys.argv[3] == "global"
     regres = len(sys.argv) > 3 and sys.argv[3] in ("regres", "pairs")
     pairs = len(sys.argv) > 3 and sys.argv[3] == "pairs"
+    stages = len(sys.argv) > 3 and sys.argv[3] == "stages"
     rng = random.Random(seed)
     fails = 0
     for it in range(iters):
@@ -57,6 +62,16 @@ def main():
             last = rng.choice([256, 512, 1024, 2048, 1000, 768])
             mid = rng.choice([8, 16, 24, 40, 64, 96, 128, 250, 256, 512, 1024, 1500, 3000, 2560])
             dims = ([rng.choice([2, 3, 5, 8])] if rank == 3 else []) + [mid, last]
+        elif stages:
+            rank = 1
+            while True:
+                n = 1
+                while n < 600:
+                    n *= rng.choice([2, 2, 2, 3, 3, 5, 5, 7, 11, 13])
+                if n <= 1100:
+                    break
+            four_step = rng.random() < 0.3
+            dims = [n * rng.choice([64, 100, 104, 125, 128, 240])] if four_step else [n]
         elif regres:
             rank = 1
             lo, hi = (20481, 40000) if prec == "f32" else (10241, 20000)
@@ -83,14 +98,16 @@ def main():
             dims = [smooth(rng, 2, rng.choice([12, 40, 200])) for _ in range(rank)]
         n = int(np.prod(dims))
         batch = rng.choice([1, 2, 3, 7, 16, 33, 100])
+        if stages and n <= 1100:
+            batch = rng.choice([16, 17, 33, 48, 100, 133, 200])
         if n * batch > 4_000_000:
-            batch = max(1, (8_000_000 if (big2d or glob or regres) else 4_000_000) // n)
+            batch = max(1, (8_000_000 if (big2d or glob or regres or stages) else 4_000_000) // n)
         storage = rng.choice([0, 0, 1])
         kw = {}
         place = rng.choice([0, 1])
         layout = "P"
-        if rank == 1 and not glob and not regres:
-            layout = rng.choice(["P", "P", "BI", "ROWS", "STR", "PBI", "BIP"])
+        if rank == 1 and not glob and not regres and not (stages and n > 1100):
+            layout = rng.choice(["BI", "BI", "BI", "PBI", "BIP"] if stages else ["P", "P", "BI", "ROWS", "STR", "PBI", "BIP"])
             if layout == "BI":
                 kw = dict(fwd_strides=[batch], fwd_distance=1, bwd_strides=[batch], bwd_distance=1)
             elif layout == "PBI" and place == 1:
