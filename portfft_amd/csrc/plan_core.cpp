@@ -171,6 +171,7 @@ plan_knobs plan_knobs::from_env() {
   flag("PFFT_NO_SPLIT_2D_CACHED", &k.no_split_2d_cached);
   if (const char* e = set("PFFT_BI_N1")) k.bi_n1 = std::atoll(e);
   mark(k.bi_n1 > 0);
+  flag("PFFT_NO_BI_N1_RULE", &k.no_bi_n1_rule);
   return k;
 }
 
@@ -458,12 +459,14 @@ const strided_kernel* plan_t::get_strided(long long n, long long inner_count, bo
     if (t == nullptr || t->launch_split == nullptr) policy = 0;
   }
   const strided_kernel* k = find_strided(n, column_both, row_side && !user_split, inner_count, policy, store_modifier);
-  // A registered entry that sits alone on its CU (n = 1024: 128 KiB of LDS) against the register-resident form of the same
-  // group, two work-groups per CU (stockham_strided_hx.hpp) -- column-shaped stages without the store modifier.  fp64 only:
-  // BI N = 1024 x 8 columns 0.578 -> 0.624, at a batch of 66 000 0.543-0.558 -> 0.586; in fp32 the registered 32.32
-  // software-pipelined kernel holds 0.60-0.64 against 0.54-0.63 (profiles/r6_hx_over_registered.txt).  Costs that length's
-  // first commit one hiprtc compilation (then the disk cache).
-  if (k != nullptr && kn.hx_over_registered && desc.precision == PFFT_PRECISION_F64 && k->lds_bytes > 80 * 1024 &&
+  // A registered entry that sits alone on its CU (128 KiB of LDS) against the register-resident form of the same group, two
+  // work-groups per CU (stockham_strided_hx.hpp) -- column-shaped stages without the store modifier.  Measured
+  // (profiles/r6_hx_over_registered.txt, r6_bi_two_stage_split.txt): fp64 BI N = 1024 x 8 columns 0.578 -> 0.624, at a batch of
+  // 66 000 0.543-0.558 -> 0.586; fp32 BI N = 512 x 32 columns (8.8.8 on 1024 lanes) 0.592 / 0.616 -> 0.660 / 0.685.  NOT fp32 n = 1024:
+  // its registered 32.32 software-pipelined kernel on 512 lanes holds 0.60-0.64 against 0.54-0.63.  Hence: fp64, and fp32 where
+  // the registered entry is one 16-wave work-group.  Costs that length's first commit one hiprtc compilation (then the disk cache).
+  if (k != nullptr && kn.hx_over_registered && (desc.precision == PFFT_PRECISION_F64 || (k->wg >= 1024 && k->n <= 512)) &&
+      k->lds_bytes > 80 * 1024 &&
       column_both && !store_modifier && !row_side && !user_split && jit_enabled()) {
     wg_params p;
     if (choose_strided_params(desc.precision, n, inner_count, max_lds, &p, column_both, k->fpw) &&

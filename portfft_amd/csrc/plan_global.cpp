@@ -229,6 +229,15 @@ bool plan_t::plan_batch_interleaved_two_stage(std::vector<stage>& out, long long
     }
   }
   if (n1 == 0) return false;
+  // Round 6 (PFFT_BI_N1 sweeps, profiles/r6_bi_two_stage_split.txt, fraction of the HBM peak): the balanced split makes stage A of
+  // N = 2048 a 32-point single-pass kernel that carries the store modifier on a radix-32 butterfly -- 32 x 64 0.219, 64 x 32 0.306,
+  // **128 x 16 0.328**; N = 4096: 64 x 64 0.344, 128 x 32 0.352; 8192 / 16384: 128 x 64 / 128 x 128 are the best or tie it; fp64 2048
+  // 0.286 -> 0.318, 4096 0.332 -> 0.353 (32 x 128: 0.368).  A 128-point stage A (8.16 x 64 columns, modifier tables in LDS) in front
+  // of whatever is left: the rule for every length it divides.
+  if (n % 128 == 0 && n / 128 >= 2 && strided_fpw(128, (n / 128) * B) >= full_fpw && strided_fpw(n / 128, B) >= full_fpw &&
+      !kn.no_bi_n1_rule) {
+    n1 = 128;
+  }
   if (kn.bi_n1 > 0 && n % kn.bi_n1 == 0 && strided_fpw(kn.bi_n1, (n / kn.bi_n1) * B) >= full_fpw &&
       strided_fpw(n / kn.bi_n1, B) >= full_fpw) {
     n1 = kn.bi_n1;  // experiments (PFFT_BI_N1): the first factor of the two-stage BI plan
