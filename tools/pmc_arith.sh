@@ -11,11 +11,12 @@ export TMPDIR=/tmp PFFT_JIT_CACHE_DIR=/tmp/pmc_arith_cache
 CTR_GROUPS=("SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM"
         "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_VMEM"
         "GRBM_GUI_ACTIVE")
-run_case() {  # tag n batch prec
-  local tag=$1 n=$2 b=$3 prec=$4 i=0
+run_case() {  # tag n batch prec   (prec "f32bi" / "f64bi": batch-interleaved on both sides)
+  local tag=$1 n=$2 b=$3 prec=${4%bi} i=0 lay=""
+  [ "$4" != "$prec" ] && lay=bi
   for grp in "${CTR_GROUPS[@]}"; do
     i=$((i+1))
-    rocprofv3 --pmc $grp --kernel-trace --output-format csv -d "$out/$tag/g$i" -- python3 tools/probes/one_desc.py $n $b $prec 3 > "$out/$tag.g$i.log" 2>&1
+    rocprofv3 --pmc $grp --kernel-trace --output-format csv -d "$out/$tag/g$i" -- python3 tools/probes/one_desc.py $n $b $prec 3 $lay > "$out/$tag.g$i.log" 2>&1
   done
   python3 tools/summarize_sq.py "$out/$tag" "$tag" > "$out/$tag.txt" 2>&1
   cat "$out/$tag.txt"
