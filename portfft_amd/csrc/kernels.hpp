@@ -120,6 +120,8 @@ struct strided_kernel {
   /// per CU; lds_bytes is its HALF image (+ TWL copy), the interleaved / split / mixed forms are that kernel's, the
   /// row-staged forms stay those of stockham_strided.hpp and there are no tiled-input forms
   int hx;
+  /// 1 (runtime-compiled entries): the BIG forms (strided_io_big: groups that span 4 GiB or more); such an entry serves nothing else
+  int big;
 };
 
 /// First pass of the two-pass 2-D plan (stockham_rows2d.hpp): whole row FFTs of length n + the first radix-rc

@@ -172,6 +172,7 @@ plan_knobs plan_knobs::from_env() {
   if (const char* e = set("PFFT_BI_N1")) k.bi_n1 = std::atoll(e);
   mark(k.bi_n1 > 0);
   flag("PFFT_NO_BI_N1_RULE", &k.no_bi_n1_rule);
+  flag("PFFT_NO_BIG_BI", &k.no_big_bi);
   return k;
 }
 

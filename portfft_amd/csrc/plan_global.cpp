@@ -215,8 +215,16 @@ bool plan_t::plan_batch_interleaved_two_stage(std::vector<stage>& out, long long
                                               double scale, int backward, pfft_dim_info_t* info) {
   const int full_fpw = desc.precision == PFFT_PRECISION_F64 ? 8 : 16;
   if (strided_fpw(n, B) >= full_fpw) return false;
-  if (static_cast<unsigned long long>(n) * static_cast<unsigned long long>(B) * elem_bytes() >= 0xFFFFFFF0ull) {
-    return false;  // a stage's byte offsets must fit the 32-bit buffer addressing
+  // An array of 4 GiB or more: the byte offsets of a stage's butterfly legs no longer fit the 32-bit scalar offset of the
+  // buffer instructions.  Round 6: both stages then run the BIG forms of their kernels (strided_io_big: 64-bit leg offsets,
+  // plain global accesses; compiled at commit whatever the length) -- fp32 N = 4096 x 131 136 fell to the generic tier before,
+  // 0.08 of the HBM peak against 0.33 just below 4 GiB.  What stays 32 bits is a LANE's offset, the span of the first / last
+  // pass's butterflies = 1 / radix of the array: up to 16 GiB with the radices (>= 8) of the stage lengths used here.
+  const unsigned long long array_bytes = static_cast<unsigned long long>(n) * static_cast<unsigned long long>(B) * elem_bytes();
+  const bool big = array_bytes >= 0xFFFFFFF0ull;
+  if (big && (outer != 1 || !jit_enabled() || kn.no_big_bi || array_bytes > (16ull << 30) ||
+              static_cast<unsigned long long>(n) * static_cast<unsigned long long>(B) >= (1ull << 32))) {
+    return false;
   }
   const size_t need = static_cast<size_t>(n) * static_cast<size_t>(B) * static_cast<size_t>(outer) * elem_bytes();
   if (outer > 1 && need > global_chunk_bytes()) return false;  // the intermediate is as large as the data
@@ -247,14 +255,32 @@ bool plan_t::plan_batch_interleaved_two_stage(std::vector<stage>& out, long long
   // (measured with random data, tools/perf_cache.py: +4...13 % from 128 MiB of intermediate up; below that the
   //  streamed kernels are faster -- everything sits in the cache anyway -- so small problems keep them)
   const bool cached = cache_chunk_bytes() > 0 && need <= cache_chunk_bytes() && need >= cache_chunk_bytes() / 2;
-  const strided_kernel* ka = get_strided(n1, n2 * B, true, false, true, false, cached ? 1 : 0);  // column-shaped on
-  const strided_kernel* kb = get_strided(n2, B, false, false, true, false, cached ? 2 : 0);      // both sides: wide
+  const strided_kernel* ka = nullptr;
+  const strided_kernel* kb = nullptr;
+  if (big) {
+    std::string why;
+    ka = jit_strided_kernel(desc.precision, n1, n2 * B, true, 0, max_lds, &why, true, 0, 0, true);
+    kb = jit_strided_kernel(desc.precision, n2, B, false, 0, max_lds, &why, true, 0, 0, true);
+    if (ka == nullptr || kb == nullptr) jit_note("strided (big)", ka == nullptr ? n1 : n2, why);
+  } else {
+    ka = get_strided(n1, n2 * B, true, false, true, false, cached ? 1 : 0);  // column-shaped on
+    kb = get_strided(n2, B, false, false, true, false, cached ? 2 : 0);      // both sides: wide
+  }
   addressing a_in{ia.offset, n2 * B, 1, n * B};
   addressing a_out{0, n2 * B, 1, n * B};
   addressing b_in{0, B, 1, n2 * B};
   addressing b_out{oa.offset, n1 * B, 1, B};
-  if (!strided_fits(ka, n2 * B, in_buf, a_in, BUF_SCRATCH, a_out) || !store_tables_fit(ka, n) ||
-      !strided_fits(kb, B, BUF_SCRATCH, b_in, out_buf, b_out)) {
+  if (big) {
+    // (strided_fits checks the 32-bit byte range of a whole group: what the BIG forms lift.  A lane's offset -- the span
+    //  of one pass's butterflies -- must still fit: first and last radix of either kernel)
+    auto lane_span_ok = [&](const strided_kernel* k) {
+      if (k == nullptr || k->n_radices < 1) return false;
+      const int r = std::min(k->radices[0], k->radices[k->n_radices - 1]);
+      return r >= 2 && array_bytes / static_cast<unsigned long long>(r) + (1ull << 20) < 0xFFFFFFF0ull;
+    };
+    if (!lane_span_ok(ka) || !lane_span_ok(kb) || !store_tables_fit(ka, n)) return false;
+  } else if (!strided_fits(ka, n2 * B, in_buf, a_in, BUF_SCRATCH, a_out) || !store_tables_fit(ka, n) ||
+             !strided_fits(kb, B, BUF_SCRATCH, b_in, out_buf, b_out)) {
     return false;
   }
   scratch_bytes = std::max(scratch_bytes, need);

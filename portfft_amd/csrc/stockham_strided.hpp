@@ -29,6 +29,7 @@ template <typename T, int AUX, int SPLIT>
 struct strided_io {
   static constexpr unsigned ES_IN = split_in(SPLIT) ? sizeof(T) : sizeof(cx<T>);
   static constexpr unsigned ES_OUT = split_out(SPLIT) ? sizeof(T) : sizeof(cx<T>);
+  using off_t = unsigned;  // type of a butterfly leg's uniform byte offset (strided_io_big: 64 bits)
   __amdgpu_buffer_rsrc_t rin, rout, rin_im, rout_im;
   PFA_DEV cx<T> load(unsigned voff, unsigned soff) const {
     if constexpr (split_in(SPLIT)) {
@@ -43,6 +44,57 @@ struct strided_io {
       buf_store_scalar<T, AUX>(v.im, rout_im, voff, soff);
     } else {
       buf_store<T, AUX>(v, rout, voff, soff);
+    }
+  }
+};
+
+/// (no standard library under hiprtc: std::conditional, spelled out)
+template <bool C, typename A, typename B>
+struct pick_type {
+  using type = A;
+};
+template <typename A, typename B>
+struct pick_type<false, A, B> {
+  using type = B;
+};
+
+/// BIG groups (round 6): a group whose elements span 4 GiB or more -- a batch-interleaved array of that size: element i of
+/// a transform sits i * batch elements from element 0 -- cannot be addressed through one buffer descriptor: the uniform
+/// offset of a butterfly leg (the scalar offset of the buffer instructions) no longer fits 32 bits.  This I/O object has the
+/// interface of strided_io with 64-bit leg offsets and plain global accesses: lane offset (32 bits: the span of the first
+/// pass's butterflies, 1 / R0 of the group) + leg offset (64 bits) + the group's base pointer.  Dead lanes (offset
+/// 0xFFFFFFF0, see strided_pass) load zeros and store nothing.  Only the kernels instantiated with BIG use it (compiled at
+/// commit for such arrays: plan_batch_interleaved_two_stage); every other kernel's code is unchanged.
+template <typename T, int AUX, int SPLIT>
+struct strided_io_big {
+  static constexpr unsigned ES_IN = split_in(SPLIT) ? sizeof(T) : sizeof(cx<T>);
+  static constexpr unsigned ES_OUT = split_out(SPLIT) ? sizeof(T) : sizeof(cx<T>);
+  using off_t = unsigned long long;
+  using vec_t = typename pick_type<sizeof(T) == 4, buf_b64_t, buf_b128_t>::type;
+  const char* in;
+  const char* in_im;
+  char* out;
+  char* out_im;
+  PFA_DEV cx<T> load(unsigned voff, off_t soff) const {
+    cx<T> x = {T(0), T(0)};
+    if (voff != 0xFFFFFFF0u) {
+      if constexpr (split_in(SPLIT)) {
+        x.re = __builtin_nontemporal_load(reinterpret_cast<const T*>(in + soff + voff));
+        x.im = __builtin_nontemporal_load(reinterpret_cast<const T*>(in_im + soff + voff));
+      } else {
+        x = __builtin_bit_cast(cx<T>, __builtin_nontemporal_load(reinterpret_cast<const vec_t*>(in + soff + voff)));
+      }
+    }
+    return x;
+  }
+  PFA_DEV void store(cx<T> v, unsigned voff, off_t soff) const {
+    if (voff != 0xFFFFFFF0u) {
+      if constexpr (split_out(SPLIT)) {
+        __builtin_nontemporal_store(v.re, reinterpret_cast<T*>(out + soff + voff));
+        __builtin_nontemporal_store(v.im, reinterpret_cast<T*>(out_im + soff + voff));
+      } else {
+        __builtin_nontemporal_store(__builtin_bit_cast(vec_t, v), reinterpret_cast<vec_t*>(out + soff + voff));
+      }
     }
   }
 };
@@ -173,7 +225,7 @@ PFA_DEV void strided_store_butterfly(const IO& io, const strided_args& a, unsign
     if constexpr (BWD) y.im = -y.im;
     y.re *= scale;
     y.im *= scale;
-    io.store(y, voff, (static_cast<unsigned>(u * Ns) >> osh) * a.out_stride * ES_OUT);
+    io.store(y, voff, static_cast<typename IO::off_t>(static_cast<unsigned>(u * Ns) >> osh) * a.out_stride * ES_OUT);
   });
 }
 
@@ -250,7 +302,7 @@ PFA_DEV void strided_pass(const IO& io, const strided_args& a, unsigned f,
             live ? (f * a.in_fdist + (j >> tsh) * a.in_stride + (j & ((1u << tsh) - 1u))) * ES_IN : 0xFFFFFFF0u;
         sfor<0, R>([&](auto t_) PFA_LAMBDA {
           constexpr int t = decltype(t_)::value;
-          cx<T> x = io.load(voff, (static_cast<unsigned>(t * NB) >> tsh) * a.in_stride * ES_IN);
+          cx<T> x = io.load(voff, static_cast<typename IO::off_t>(static_cast<unsigned>(t * NB) >> tsh) * a.in_stride * ES_IN);
           if constexpr (BWD) x.im = -x.im;
           v[i][t] = x;
         });
@@ -364,7 +416,7 @@ PFA_DEV void strided_pass0_load(const IO& io, const strided_args& a, unsigned f,
           live ? (f * a.in_fdist + (j >> tsh) * a.in_stride + (j & ((1u << tsh) - 1u))) * ES : 0xFFFFFFF0u;
       sfor<0, R>([&](auto t_) PFA_LAMBDA {
         constexpr int t = decltype(t_)::value;
-        cx<T> x = io.load(voff, (static_cast<unsigned>(t * NB) >> tsh) * a.in_stride * ES);
+        cx<T> x = io.load(voff, static_cast<typename IO::off_t>(static_cast<unsigned>(t * NB) >> tsh) * a.in_stride * ES);
         if constexpr (BWD) x.im = -x.im;
         v[i][t] = x;
       });
@@ -406,13 +458,11 @@ PFA_DEV long long strided_ngroups(const strided_args& a) {
   return ((a.total + a.inner - 1) / a.inner) * per_outer;
 }
 
-template <typename Cfg, int SPLIT>
-PFA_DEV strided_io<typename Cfg::T, Cfg::AUX, SPLIT> strided_group(const strided_args& a, long long g, unsigned f,
-                                                                   bool* live, long long* c0_out,
-                                                                   long long* nlive_out = nullptr,
-                                                                   long long in_base = 0, long long out_base = 0) {
+template <typename Cfg, int SPLIT, bool BIG = false>
+PFA_DEV auto strided_group(const strided_args& a, long long g, unsigned f, bool* live, long long* c0_out,
+                           long long* nlive_out = nullptr, long long in_base = 0, long long out_base = 0) {
   using T = typename Cfg::T;
-  using IO = strided_io<T, Cfg::AUX, SPLIT>;
+  using IO = typename pick_type<BIG, strided_io_big<T, Cfg::AUX, SPLIT>, strided_io<T, Cfg::AUX, SPLIT>>::type;
   constexpr unsigned ES_IN = IO::ES_IN, ES_OUT = IO::ES_OUT;
   const long long per_outer = (a.inner + Cfg::FPW - 1) / Cfg::FPW;
   const long long o = g / per_outer;
@@ -446,6 +496,15 @@ PFA_DEV strided_io<typename Cfg::T, Cfg::AUX, SPLIT> strided_group(const strided
   IO io;
   char* ip = const_cast<char*>(static_cast<const char*>(a.in)) + ioff * ES_IN;
   char* op = static_cast<char*>(a.out) + ooff * ES_OUT;
+  if constexpr (BIG) {
+    (void)in_bytes;
+    (void)out_bytes;
+    io.in = ip;
+    io.out = op;
+    io.in_im = split_in(SPLIT) ? static_cast<const char*>(a.in_im) + ioff * ES_IN : ip;
+    io.out_im = split_out(SPLIT) ? static_cast<char*>(a.out_im) + ooff * ES_OUT : op;
+    return io;
+  } else {
   io.rin = __builtin_amdgcn_make_buffer_rsrc(ip, 0, in_bytes, 0x00020000);
   io.rout = __builtin_amdgcn_make_buffer_rsrc(op, 0, out_bytes, 0x00020000);
   if constexpr (split_in(SPLIT)) {
@@ -461,6 +520,7 @@ PFA_DEV strided_io<typename Cfg::T, Cfg::AUX, SPLIT> strided_group(const strided
     io.rout_im = io.rout;
   }
   return io;
+  }
 }
 
 template <typename Cfg>
@@ -650,8 +710,14 @@ PFA_DEV void strided_group_walk(const strided_args& a, long long ngroups, Body&&
   }
 }
 
-template <typename Cfg, bool BWD, int STW, int SPLIT = 0, int TIN = 0>
+/// WALK 0: the grid-stride loop of rounds 1-5 with the XCD pairing of narrow segments (pair_xcd 1) -- every pre-compiled
+/// instantiation: the 1024-lane stage-A kernels with the store modifier lost 7-10 % when their loop went through
+/// strided_group_walk (same registers, another schedule: g32_20 0.349 -> 0.329, g32_22 0.294 -> 0.279 in the first r6 profiles),
+/// so their code stays what it was.  WALK 1: strided_group_walk, i.e. also the XCD-contiguous walk -- the kernels compiled
+/// at commit (the lengths with unaligned row pitches are theirs).
+template <typename Cfg, bool BWD, int STW, int SPLIT = 0, int TIN = 0, bool BIG = false, int WALK = 0>
 __global__ __launch_bounds__(Cfg::WG, Cfg::OCC) void stockham_strided_kernel(const strided_args a) {
+  static_assert(!BIG || TIN == 0, "big groups: the plain form");
   using T = typename Cfg::T;
   // (a single-pass plan -- one lane per FFT, the reference's WORKITEM tier on strided data -- uses no LDS at all)
   extern __shared__ __attribute__((aligned(16))) char pfa_smem_strided[];
@@ -662,14 +728,29 @@ __global__ __launch_bounds__(Cfg::WG, Cfg::OCC) void stockham_strided_kernel(con
   const long long ngroups = strided_ngroups<Cfg>(a);
   strided_copy_twiddles<Cfg>(lds, tw);
   strided_copy_stw<Cfg, STW>(a);
-  strided_group_walk(a, ngroups, [&](long long g) PFA_LAMBDA {
-    bool live;
-    long long c0;
-    long long nlive;
-    const auto io = strided_group<Cfg, SPLIT>(a, g, f, &live, &c0, &nlive);
-    // no barrier needed here: the last pass ends its LDS reads with a barrier before the next group's first write
-    strided_passes<Cfg, BWD, STW, 0, decltype(io), false, false, TIN>(io, a, f, tid, live, c0, lds, tw, nlive);
-  });
+  if constexpr (WALK == 0) {
+    const bool pair = a.pair_xcd != 0 && (gridDim.x & 15u) == 0u;
+    long long g0 = blockIdx.x;
+    if (pair) g0 = (g0 & ~15ll) + 2 * (g0 & 7) + ((g0 >> 3) & 1);
+    const long long gend = pair ? ((ngroups + 15) & ~15ll) : ngroups;
+    for (long long g = g0; g < gend; g += gridDim.x) {
+      if (g >= ngroups) continue;  // (uniform: the ragged last run of a paired grid)
+      bool live;
+      long long c0;
+      long long nlive;
+      const auto io = strided_group<Cfg, SPLIT, BIG>(a, g, f, &live, &c0, &nlive);
+      // no barrier needed here: the last pass ends its LDS reads with a barrier before the next group's first write
+      strided_passes<Cfg, BWD, STW, 0, decltype(io), false, false, TIN>(io, a, f, tid, live, c0, lds, tw, nlive);
+    }
+  } else {
+    strided_group_walk(a, ngroups, [&](long long g) PFA_LAMBDA {
+      bool live;
+      long long c0;
+      long long nlive;
+      const auto io = strided_group<Cfg, SPLIT, BIG>(a, g, f, &live, &c0, &nlive);
+      strided_passes<Cfg, BWD, STW, 0, decltype(io), false, false, TIN>(io, a, f, tid, live, c0, lds, tw, nlive);
+    });
+  }
 }
 
 }  // namespace pfa

@@ -66,7 +66,7 @@ PFA_DEV void shx_load(const IO& io, const strided_args& a, unsigned f, unsigned 
           ok ? (f * a.in_fdist + (j >> tsh) * a.in_stride + (j & ((1u << tsh) - 1u))) * ES : 0xFFFFFFF0u;
       sfor<0, R>([&](auto t_) PFA_LAMBDA {
         constexpr int t = decltype(t_)::value;
-        cx<T> x = io.load(voff, (static_cast<unsigned>(t * NB) >> tsh) * a.in_stride * ES);
+        cx<T> x = io.load(voff, static_cast<typename IO::off_t>(static_cast<unsigned>(t * NB) >> tsh) * a.in_stride * ES);
         if constexpr (BWD) x.im = -x.im;
         v[i][t] = x;
       });
@@ -170,7 +170,7 @@ PFA_DEV void shx_passes(cx<typename Cfg::T> (&v)[Cfg::bpt(P)][Cfg::Seq::r[P]], c
   }
 }
 
-template <typename Cfg, bool BWD, int STW, int SPLIT = 0>
+template <typename Cfg, bool BWD, int STW, int SPLIT = 0, bool BIG = false>
 __global__ __launch_bounds__(Cfg::WG, Cfg::OCC) void stockham_strided_hx_kernel(const strided_args a) {
   using T = typename Cfg::T;
   static_assert(strided_hx_supported<Cfg>(), "see strided_hx_supported()");
@@ -189,7 +189,7 @@ __global__ __launch_bounds__(Cfg::WG, Cfg::OCC) void stockham_strided_hx_kernel(
   strided_group_walk(a, ngroups, [&](long long g) PFA_LAMBDA {
     bool live;
     long long c0;
-    const auto io = strided_group<Cfg, SPLIT>(a, g, f, &live, &c0);
+    const auto io = strided_group<Cfg, SPLIT, BIG>(a, g, f, &live, &c0);
     cx<T> v[Cfg::bpt(0)][Cfg::Seq::r[0]];
     shx_load<Cfg, BWD>(io, a, f, tid, live, v);
     const cx<T>* twp = tw;
