@@ -157,7 +157,20 @@ def test_buffers_beyond_4gib():
     _big_case(4096, 300000)                                       # work-group tier, 9.2 GiB
     _big_case(16, 80000000)                                       # register tier, 9.5 GiB
     _big_case(4096, 300000, split=True)                           # split storage
-    _big_case(4096, 300000, layout_in="BI", layout_out="BI")      # two column-shaped stages through scratch
+    _big_case(4096, 300000, layout_in="BI", layout_out="BI")      # two column-shaped stages through scratch, BIG forms (9.2 GiB)
+    # (round 6: a batch-interleaved array of 4 GiB and more keeps the two-stage plan -- 64-bit butterfly-leg offsets,
+    #  stockham_strided.hpp strided_io_big -- instead of falling to narrow groups / the generic tier: 0.08 -> 0.34 of the HBM peak)
+    G, pf, _ = _mods()
+    d = pf.descriptor([4096], "f32")
+    d.number_of_transforms = 140000
+    d.forward_strides, d.forward_distance, d.backward_strides, d.backward_distance = [140000], 1, [140000], 1
+    dim = d.commit().info().dims[0]
+    assert dim.tier == 3 and list(dim.factors[:2]) == [128, 32], (dim.tier, list(dim.factors[:2]))
+    os.environ["PFFT_NO_BIG_BI"] = "1"
+    try:
+        assert d.commit().info().dims[0].tier != 3, "the round-5 twin: no two-stage plan at 4 GiB and beyond"
+    finally:
+        del os.environ["PFFT_NO_BIG_BI"]
     _big_case(512, 2400000, layout_in="BI")                       # strided tier, row-shaped output
     _big_case(1200, 1000000)                                      # runtime-specialised length
     _big_case(1 << 20, 1200)                                      # GLOBAL tier fp32, chunked scratch
