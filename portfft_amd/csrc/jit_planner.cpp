@@ -751,7 +751,7 @@ std::vector<wg_params> strided_hx_candidates(const wg_params& base, size_t max_l
       }
       const int wps = (per_cu * waves + 3) / 4;
       if (wps > 8) continue;
-      // fp32: only plans that keep 14 or more waves on the CU.  Measured (tools/perf_stage_hx.py, profiles/r6_stage_hx.txt;
+      // fp32: only plans that keep 14 or more waves on the CU.  Measured (tools/perf_stage_hx.py, profiles/r6_stage_hx_first.txt;
       // fraction of the HBM peak, LDS-resident -> register-resident): 768 x 16 on 2 x 512 lanes 0.453 -> 0.541, 660 x 16 on
       // 2 x 480 lanes 0.513 -> 0.551, 68640 = 104 x 660 0.289 -> 0.301 -- but 800 x 16 on 2 x 320 lanes 0.438 -> 0.438 and 1728 x 8
       // on 2 x 384 lanes 0.233 -> 0.215: ten or twelve waves of 160-register kernels hide less than the thirteen of the
