@@ -182,6 +182,18 @@ inline int aux_of_policy(int policy) {
     if (const char* e = getenv("PFFT_JIT_WRITER_AUX")) return static_cast<int>(std::strtol(e, nullptr, 0));
     return PFA_AUX_WRITER;
   }
+  if (policy == 0) {
+    if (const char* e = getenv("PFFT_JIT_NT_AUX")) return static_cast<int>(std::strtol(e, nullptr, 0));  // (experiments)
+  }
+  // policy 3 (round 6, kernels compiled at commit only): default policy on loads AND stores -- for stages whose column-shaped
+  // side has a row pitch that is no multiple of a 128-byte line: every segment shares its first and last line with the
+  // neighbouring group, and only lines that live in the L2 are fetched once and written back whole (with the XCD-contiguous
+  // walk the neighbours run on one L2).  Streamed (nt) accesses left batch-interleaved N = 768 at a batch of 174 769 at 0.225
+  // of the HBM peak against 0.616 at 174 768; with this policy 0.506 (profiles/r6_bi_unaligned_policies.txt).
+  if (policy == 3) return 0;
+  // (NOT for the four-step stages of lengths like 68640 = 104 x 660 or 10^6, whose pitches are unaligned too: on default policies
+  //  -- both sides, or the user's side only -- they lose 10-26 %, profiles/r6_unaligned_policy.txt / r6_fs_unaligned.txt: there the
+  //  streamed user side is what keeps the intermediate in the Infinity Cache)
   return policy == 2 ? PFA_AUX_READER : PFA_AUX_NT;
 }
 

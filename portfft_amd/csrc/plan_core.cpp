@@ -173,6 +173,7 @@ plan_knobs plan_knobs::from_env() {
   mark(k.bi_n1 > 0);
   flag("PFFT_NO_BI_N1_RULE", &k.no_bi_n1_rule);
   flag("PFFT_NO_BIG_BI", &k.no_big_bi);
+  flag("PFFT_NO_UNALIGNED_POLICY", &k.no_unaligned_policy);
   return k;
 }
 
@@ -453,6 +454,16 @@ int plan_t::strided_fpw(long long n, long long inner_count) const {
 /// policy: cache policy of the stage (strided_kernel::policy; 1 writer -- needs store_modifier --, 2 reader)
 const strided_kernel* plan_t::get_strided(long long n, long long inner_count, bool store_modifier, bool user_split,
                                           bool column_both, bool row_side, int policy) {
+  if (policy == 3 && jit_enabled() && !user_split && !row_side) {
+    // an unaligned row pitch (aux_of_policy): the kernel compiled at commit on default cache policies with the shared group
+    // walk, whatever the registry holds for the length
+    std::string why;
+    if (const strided_kernel* k = jit_strided_kernel(desc.precision, n, inner_count, store_modifier, 0, max_lds, &why, column_both, policy)) {
+      return k;
+    }
+    jit_note("strided (unaligned pitch)", n, why);
+  }
+  if (policy == 3) policy = 0;
   // (split user planes: streamed kernels -- unless a registered policy twin carries its split form: the reader of the
   //  two-pass 2-D plan's second pass, the only caller that asks for a policy on user planes)
   if (user_split && policy != 0) {

@@ -135,9 +135,15 @@ void plan_t::run_stage(const stage& s, const void* in_re, const void* in_im, voi
       // matrix): every segment straddles one line more than it fills and shares it with the neighbour group -- the blocks
       // of an XCD walk neighbouring groups (strided_group_walk, pair_xcd 2) so that the shared line is fetched once
       const size_t pitch = static_cast<size_t>(a.in_stride) * (in_user_split ? sb : elem_bytes());
+      // ... or a column-shaped OUTPUT at such a pitch (the four-step stage B of 68640 = 104 x 660 writes 128-byte segments at a
+      // pitch of 832 bytes): the partial lines of two neighbouring groups meet in one L2
+      const bool out_user_split = split && s.out_buf != BUF_SCRATCH;
+      const bool column_out = a.out_fdist == 1 && a.out_gdist == 0 && a.out_stride > 1 && a.out_tile_shift == 0;
+      const size_t opitch = static_cast<size_t>(a.out_stride) * (out_user_split ? sb : elem_bytes());
       // (kernels compiled at commit only: the pre-compiled instantiations keep the loop of rounds 1-5)
-      if (a.pair_xcd == 0 && column_in && a.in_tile_shift == 0 && pitch % 128 != 0 && s.row_mode == 0 && s.tiled_in == 0 &&
-          s.strided->launch == nullptr && s.strided->fpw > 1 && grid >= 64 && kn.xcd_contig) {
+      if (a.pair_xcd == 0 && ((column_in && a.in_tile_shift == 0 && pitch % 128 != 0) || (column_out && opitch % 128 != 0)) &&
+          s.row_mode == 0 && s.tiled_in == 0 && s.strided->launch == nullptr && s.strided->fpw > 1 && grid >= 64 &&
+          kn.xcd_contig) {
         a.pair_xcd = 2;
       }
     }

@@ -257,14 +257,18 @@ bool plan_t::plan_batch_interleaved_two_stage(std::vector<stage>& out, long long
   const bool cached = cache_chunk_bytes() > 0 && need <= cache_chunk_bytes() && need >= cache_chunk_bytes() / 2;
   const strided_kernel* ka = nullptr;
   const strided_kernel* kb = nullptr;
+  // (a batch count that is no multiple of a line -- 16 fp32 / 8 fp64 transforms: every row pitch of both stages is unaligned,
+  //  policy 3 of aux_of_policy)
+  const bool unal = !kn.no_unaligned_policy && (static_cast<unsigned long long>(B) * elem_bytes()) % 128 != 0 &&
+                    array_bytes * static_cast<unsigned long long>(outer) >= (64ull << 20);
   if (big) {
     std::string why;
-    ka = jit_strided_kernel(desc.precision, n1, n2 * B, true, 0, max_lds, &why, true, 0, 0, true);
-    kb = jit_strided_kernel(desc.precision, n2, B, false, 0, max_lds, &why, true, 0, 0, true);
+    ka = jit_strided_kernel(desc.precision, n1, n2 * B, true, 0, max_lds, &why, true, unal ? 3 : 0, 0, true);
+    kb = jit_strided_kernel(desc.precision, n2, B, false, 0, max_lds, &why, true, unal ? 3 : 0, 0, true);
     if (ka == nullptr || kb == nullptr) jit_note("strided (big)", ka == nullptr ? n1 : n2, why);
   } else {
-    ka = get_strided(n1, n2 * B, true, false, true, false, cached ? 1 : 0);  // column-shaped on
-    kb = get_strided(n2, B, false, false, true, false, cached ? 2 : 0);      // both sides: wide
+    ka = get_strided(n1, n2 * B, true, false, true, false, unal ? 3 : (cached ? 1 : 0));  // column-shaped on
+    kb = get_strided(n2, B, false, false, true, false, unal ? 3 : (cached ? 2 : 0));      // both sides: wide
   }
   addressing a_in{ia.offset, n2 * B, 1, n * B};
   addressing a_out{0, n2 * B, 1, n * B};
@@ -726,8 +730,18 @@ int plan_t::plan_1d(std::vector<stage>& out, long long n, long long count, long 
   const bool user_split = !interleaved && in_buf != BUF_SCRATCH;
   const bool column_both = ia.dist_inner == 1 && oa.dist_inner == 1;
   const bool row_side = (ia.stride == 1 && ia.dist_inner != 1) || (oa.stride == 1 && oa.dist_inner != 1);
+  // a column-shaped side whose row pitch is no multiple of a 128-byte line (a batch-interleaved layout with a batch count that
+  // is no multiple of 16 fp32 / 8 fp64 transforms): policy 3, kernels.hpp aux_of_policy
+  auto unaligned = [&](const addressing& a) {
+    return a.dist_inner == 1 && a.stride > 1 && (static_cast<unsigned long long>(a.stride) * elem_bytes()) % 128 != 0;
+  };
+  // (from 64 MiB of data: below that a commit does not pay a compilation for a pre-compiled length, and the data sits in the
+  //  caches whatever the policy)
+  const bool worth = static_cast<unsigned long long>(count) * static_cast<unsigned long long>(n) * elem_bytes() >= (64ull << 20);
+  const int stage_policy =
+      (tail_policy == 0 && interleaved && worth && !kn.no_unaligned_policy && (unaligned(ia) || unaligned(oa))) ? 3 : tail_policy;
   if (const strided_kernel* k =
-          column_shaped ? get_strided(n, inner_count, false, user_split, column_both, row_side, tail_policy) : nullptr;
+          column_shaped ? get_strided(n, inner_count, false, user_split, column_both, row_side, stage_policy) : nullptr;
       strided_fits(k, inner_count, in_buf, ia, out_buf, oa)) {
     out.push_back(make_strided_stage(k, count, inner_count, in_buf, ia, out_buf, oa, scale, backward));
     record(PFFT_TIER_WORKGROUP, std::vector<int>(k->radices, k->radices + k->n_radices), k->wg, k->fpw,

@@ -307,6 +307,55 @@ def test_two_pass_2d_plan_of_split_storage_in_cache_sized_chunks():
         torch.cuda.empty_cache()
 
 
+def test_batch_interleaved_at_batch_counts_that_are_no_multiple_of_a_line():
+    """BATCH_INTERLEAVED with a batch count that is no multiple of 16 fp32 / 8 fp64 transforms (the reference's own test batch,
+    33000, is one: instantiate_fft_tests.hpp) -- every row pitch is unaligned, every 128-byte segment of a group shares its first
+    and last line with the neighbouring group.  From 64 MiB of data such stages run kernels compiled at commit on default
+    cache policies with the XCD-contiguous walk (kernels.hpp aux_of_policy, policy 3; round 6: N = 1024 at a batch of 131 077
+    0.20 -> 0.50 of the HBM peak), pre-compiled lengths included, the two-stage plan of long transforms too.  Against NumPy
+    on sampled transforms, both directions, and against the streamed twin (PFFT_NO_UNALIGNED_POLICY=1)."""
+    G, pf, torch = _mods()
+
+    def run_case(n, batch, prec, env=None):
+        cdt = torch.complex64 if prec == "f32" else torch.complex128
+        g = torch.Generator(device="cuda").manual_seed(n + batch)
+        x = torch.empty(batch * n, dtype=cdt, device="cuda")
+        torch.view_as_real(x).uniform_(-1, 1, generator=g)
+        old = {k: os.environ.get(k) for k in (env or {})}
+        os.environ.update(env or {})
+        try:
+            d = pf.descriptor([n], prec)
+            d.number_of_transforms = batch
+            d.forward_strides, d.forward_distance, d.backward_strides, d.backward_distance = [batch], 1, [batch], 1
+            plan = d.commit()
+        finally:
+            for k, v in old.items():
+                if v is None:
+                    del os.environ[k]
+                else:
+                    os.environ[k] = v
+        y = torch.empty_like(x)
+        plan.compute_forward(x, y).wait()
+        return x, y, plan
+
+    tol = {"f32": 2e-6, "f64": 5e-15}
+    for n, batch, prec in ((1024, 16391, "f32"), (768, 21851, "f32"), (256, 32771, "f64"), (4096, 4099, "f32"), (1000, 16387, "f64")):
+        x, y, plan = run_case(n, batch, prec)
+        for b in (0, 1, batch // 2, batch - 1):
+            ref = np.fft.fft(x[b::batch].cpu().numpy().astype(np.complex128))
+            assert H.rel_l2(y[b::batch].cpu().numpy(), ref) <= tol[prec], (n, batch, prec, b)
+        _, y0, plan0 = run_case(n, batch, prec, {"PFFT_NO_UNALIGNED_POLICY": "1"})
+        assert plan0.info().knob_mask != plan.info().knob_mask
+        diff = float(((y - y0).abs().double().pow(2).sum() / y0.abs().double().pow(2).sum()).sqrt())
+        assert diff <= tol[prec], (n, batch, prec, "against the streamed twin", diff)
+        z = torch.empty_like(x)
+        plan.compute_backward(y, z).wait()
+        err = float(((z / n - x).abs().double().pow(2).sum() / x.abs().double().pow(2).sum()).sqrt())
+        assert err <= tol[prec], (n, batch, prec, "round trip", err)
+        del x, y, y0, z
+    torch.cuda.empty_cache()
+
+
 def test_cache_sized_chunks_and_policy_twins():
     """The two-launch plans run chunk by chunk (256 MiB of intermediate per chunk) on the writer / reader cache-policy
     twins once the intermediate reaches 128 MiB: batch counts that leave a ragged last chunk, both directions, in-place
