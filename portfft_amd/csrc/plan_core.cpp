@@ -454,7 +454,7 @@ int plan_t::strided_fpw(long long n, long long inner_count) const {
 /// policy: cache policy of the stage (strided_kernel::policy; 1 writer -- needs store_modifier --, 2 reader)
 const strided_kernel* plan_t::get_strided(long long n, long long inner_count, bool store_modifier, bool user_split,
                                           bool column_both, bool row_side, int policy) {
-  if (policy == 3 && jit_enabled() && !user_split && !row_side) {
+  if (policy == 3 && jit_enabled() && !user_split) {  // (row-shaped sides too: the row-staged forms are built from this entry)
     // an unaligned row pitch (aux_of_policy): the kernel compiled at commit on default cache policies with the shared group
     // walk, whatever the registry holds for the length
     std::string why;

@@ -141,9 +141,9 @@ void plan_t::run_stage(const stage& s, const void* in_re, const void* in_im, voi
       const bool column_out = a.out_fdist == 1 && a.out_gdist == 0 && a.out_stride > 1 && a.out_tile_shift == 0;
       const size_t opitch = static_cast<size_t>(a.out_stride) * (out_user_split ? sb : elem_bytes());
       // (kernels compiled at commit only: the pre-compiled instantiations keep the loop of rounds 1-5)
+      // (the row-staged forms of such entries walk the same way)
       if (a.pair_xcd == 0 && ((column_in && a.in_tile_shift == 0 && pitch % 128 != 0) || (column_out && opitch % 128 != 0)) &&
-          s.row_mode == 0 && s.tiled_in == 0 && s.strided->launch == nullptr && s.strided->fpw > 1 && grid >= 64 &&
-          kn.xcd_contig) {
+          s.tiled_in == 0 && s.strided->launch == nullptr && s.strided->fpw > 1 && grid >= 64 && kn.xcd_contig) {
         a.pair_xcd = 2;
       }
     }

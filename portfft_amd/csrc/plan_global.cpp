@@ -730,8 +730,10 @@ int plan_t::plan_1d(std::vector<stage>& out, long long n, long long count, long 
   const bool user_split = !interleaved && in_buf != BUF_SCRATCH;
   const bool column_both = ia.dist_inner == 1 && oa.dist_inner == 1;
   const bool row_side = (ia.stride == 1 && ia.dist_inner != 1) || (oa.stride == 1 && oa.dist_inner != 1);
-  // a column-shaped side whose row pitch is no multiple of a 128-byte line (a batch-interleaved layout with a batch count that
-  // is no multiple of 16 fp32 / 8 fp64 transforms): policy 3, kernels.hpp aux_of_policy
+  // a column-shaped OUTPUT whose row pitch is no multiple of a 128-byte line (a batch-interleaved layout with a batch count that
+  // is no multiple of 16 fp32 / 8 fp64 transforms): policy 3, kernels.hpp aux_of_policy.  The partial-line STORES are what
+  // costs -- P -> BI N = 1024 x 131 077 0.232 -> 0.404, N = 256 0.353 -> 0.533, BI -> BI 0.204 -> 0.497; an unaligned INPUT alone (BI -> P) is
+  // -9 ... +16 % either way and keeps the streamed kernels (profiles/r6_pbi_policy.txt)
   auto unaligned = [&](const addressing& a) {
     return a.dist_inner == 1 && a.stride > 1 && (static_cast<unsigned long long>(a.stride) * elem_bytes()) % 128 != 0;
   };
@@ -739,7 +741,7 @@ int plan_t::plan_1d(std::vector<stage>& out, long long n, long long count, long 
   //  caches whatever the policy)
   const bool worth = static_cast<unsigned long long>(count) * static_cast<unsigned long long>(n) * elem_bytes() >= (64ull << 20);
   const int stage_policy =
-      (tail_policy == 0 && interleaved && worth && !kn.no_unaligned_policy && (unaligned(ia) || unaligned(oa))) ? 3 : tail_policy;
+      (tail_policy == 0 && interleaved && worth && !kn.no_unaligned_policy && unaligned(oa)) ? 3 : tail_policy;
   if (const strided_kernel* k =
           column_shaped ? get_strided(n, inner_count, false, user_split, column_both, row_side, stage_policy) : nullptr;
       strided_fits(k, inner_count, in_buf, ia, out_buf, oa)) {

@@ -78,7 +78,14 @@ void plan_t::build_direction(int direction) {
   std::vector<stage>& st = stages[direction];
   const int inv = direction == PFFT_FORWARD ? PFFT_BACKWARD : PFFT_FORWARD;
   const view_t vin = view_of(desc, direction), vout = view_of(desc, inv);
-  const bool packed = layout_of(desc, direction) == PFFT_LAYOUT_PACKED && layout_of(desc, inv) == PFFT_LAYOUT_PACKED;
+  bool packed = layout_of(desc, direction) == PFFT_LAYOUT_PACKED && layout_of(desc, inv) == PFFT_LAYOUT_PACKED;
+  // (ONE 1-D transform with unit element strides is packed data whatever its distances say -- a batch-interleaved descriptor
+  //  with a batch of one: tools/fuzz.py seed 97 found fp32 N = 13038 in that shape `unsupported`, its length beyond the strided
+  //  tier's and the GLOBAL tier packed-only)
+  if (desc.rank == 1 && desc.number_of_transforms == 1 && vin.n_strides == 1 && vout.n_strides == 1 && vin.strides[0] == 1 &&
+      vout.strides[0] == 1) {
+    packed = true;
+  }
   const double scale = direction == PFFT_FORWARD ? desc.forward_scale : desc.backward_scale;
   const int backward = direction == PFFT_BACKWARD ? 1 : 0;
   const long long B = static_cast<long long>(desc.number_of_transforms);

@@ -581,7 +581,10 @@ __global__ __launch_bounds__(Cfg::WG, Cfg::OCC) void stockham_strided_prefetch_k
 /// SPLIT 3 (with ROW_IN): the four-step stage B of SPLIT_COMPLEX data -- interleaved rows of the scratch in, the user's
 /// two planes out (column-shaped stores of the last pass).  Addressed f-fastest that stage read 8 bytes per lane from
 /// FPW different rows (fp32 N = 65536 x 2Ki: 1339 us per GiB); staged it reads whole lines.
-template <typename Cfg, bool BWD, bool ROW_IN, bool ROW_OUT, int SPLIT = 0>
+/// WALK 1 (the kernels compiled at commit): the groups through strided_group_walk -- the XCD-contiguous walk when the
+/// column-shaped side has an unaligned row pitch (P -> BI at a batch count that is no multiple of a line: the output's partial
+/// lines of neighbouring groups meet in one L2; fp32 N = 1024 x 131 077 0.233 of the HBM peak streamed, see aux_of_policy)
+template <typename Cfg, bool BWD, bool ROW_IN, bool ROW_OUT, int SPLIT = 0, int WALK = 0>
 __global__ __launch_bounds__(Cfg::WG, Cfg::OCC) void stockham_strided_row_kernel(const strided_args a) {
   using T = typename Cfg::T;
   static_assert(Cfg::NP >= 2 && (ROW_IN || ROW_OUT));
@@ -596,7 +599,10 @@ __global__ __launch_bounds__(Cfg::WG, Cfg::OCC) void stockham_strided_row_kernel
   const unsigned tid = threadIdx.x / Cfg::FPW;
   const cx<T>* __restrict__ tw = static_cast<const cx<T>*>(a.tw);
   const long long ngroups = strided_ngroups<Cfg>(a);
-  for (long long g = blockIdx.x; g < ngroups; g += gridDim.x) {
+  // (the body stands twice: the pre-compiled instantiations -- WALK 0 -- are instruction for instruction the kernels of round 5,
+  //  which a shared lambda did not guarantee)
+  if constexpr (WALK == 0) {
+    for (long long g = blockIdx.x; g < ngroups; g += gridDim.x) {
     bool live;
     long long c0;
     long long left;
@@ -633,6 +639,46 @@ __global__ __launch_bounds__(Cfg::WG, Cfg::OCC) void stockham_strided_row_kernel
       });
       __syncthreads();
     }
+    }
+  } else {
+    strided_group_walk(a, ngroups, [&](long long g) PFA_LAMBDA {
+    bool live;
+    long long c0;
+    long long left;
+    const auto io = strided_group<Cfg, SPLIT>(a, g, f, &live, &c0, &left);
+    if constexpr (ROW_IN) {
+      sfor<0, EPT>([&](auto k_) PFA_LAMBDA {
+        constexpr int k = decltype(k_)::value;
+        const unsigned e = threadIdx.x + k * Cfg::WG;
+        if (CH % Cfg::WG == 0 || e < CH) {
+          const unsigned ef = e / Cfg::N, ei = e % Cfg::N;
+          const unsigned voff = static_cast<long long>(ef) < left ? (ef * a.in_fdist + ei) * ES : 0xFFFFFFF0u;
+          cx<T> x = io.load(voff, 0);
+          if constexpr (BWD) x.im = -x.im;
+          lds[ei * PITCH + ef] = x;
+        }
+      });
+      __syncthreads();
+    }
+    strided_passes<Cfg, BWD, false, 0, decltype(io), ROW_IN, ROW_OUT>(io, a, f, tid, live, c0, lds, tw);
+    if constexpr (ROW_OUT) {
+      const T scale = static_cast<T>(a.scale);
+      sfor<0, EPT>([&](auto k_) PFA_LAMBDA {
+        constexpr int k = decltype(k_)::value;
+        const unsigned e = threadIdx.x + k * Cfg::WG;
+        if (CH % Cfg::WG == 0 || e < CH) {
+          const unsigned ef = e / Cfg::N, ei = e % Cfg::N;
+          cx<T> y = lds[ei * PITCH + ef];
+          if constexpr (BWD) y.im = -y.im;
+          y.re *= scale;
+          y.im *= scale;
+          const unsigned voff = static_cast<long long>(ef) < left ? (ef * a.out_fdist + ei) * ES : 0xFFFFFFF0u;
+          io.store(y, voff, 0);
+        }
+      });
+      __syncthreads();
+    }
+    });
   }
 }
 
