@@ -54,6 +54,7 @@ struct jit_knobs {
   bool strided_hx = true;                 ///< PFFT_JIT_STRIDED_HX=0: no register-resident strided kernels
   long strided_hx_min_kib = 80;           ///< PFFT_JIT_STRIDED_HX_MIN_KIB: groups above this take the half-image form
   const char* strided_hx_force = nullptr; ///< PFFT_JIT_STRIDED_HX_FORCE=tpf:per_cu
+  bool strided_hx_wide = true;            ///< PFFT_JIT_STRIDED_HX_WIDE=0: no one-per-CU register-resident groups beyond the LDS
 
   static jit_knobs from_env() {
     jit_knobs k;
@@ -89,6 +90,7 @@ struct jit_knobs {
     if (const char* e = str("PFFT_JIT_STRIDED_HX")) k.strided_hx = e[0] != '0';
     k.strided_hx_min_kib = num("PFFT_JIT_STRIDED_HX_MIN_KIB", 80);
     k.strided_hx_force = str("PFFT_JIT_STRIDED_HX_FORCE");
+    if (const char* e = str("PFFT_JIT_STRIDED_HX_WIDE")) k.strided_hx_wide = e[0] != '0';
     return k;
   }
 };

@@ -685,7 +685,26 @@ size_t strided_hx_lds_bytes(const wg_params& p) {
   return (static_cast<size_t>(h) * static_cast<size_t>(p.fpw) + tw) * elem_bytes_of(p.precision);
 }
 
-std::vector<wg_params> strided_hx_candidates(const wg_params& base, size_t max_lds) {
+bool choose_strided_wide_base(int precision, long long n, int fpw, wg_params* out) {
+  if (n < 64 || n > 4096 || fpw < 2) return false;
+  wg_params p;
+  p.precision = precision;
+  p.n = static_cast<int>(n);
+  // (radices up to 16: a radix-32 butterfly holds 32 values beside its temporaries -- the budget of such a group is 32 values and
+  //  ~62 registers of everything else)
+  p.radices = pick_radices(precision, n, 16);
+  if (p.radices.size() < 2 || p.radices.size() > static_cast<size_t>(MAX_PASSES)) return false;
+  p.aux = 2;
+  p.twm = 0;
+  p.fpw = fpw;
+  p.occ = 1;
+  p.wg = 0;
+  p.regs = 0;
+  *out = p;
+  return true;
+}
+
+std::vector<wg_params> strided_hx_candidates(const wg_params& base, size_t max_lds, bool wide) {
   std::vector<wg_params> out;
   const jit_knobs kn = jit_knobs::from_env();
   const int es = elem_bytes_of(base.precision);
@@ -695,6 +714,9 @@ std::vector<wg_params> strided_hx_candidates(const wg_params& base, size_t max_l
       full <= (static_cast<size_t>(kn.strided_hx_min_kib) << 10)) {
     return out;
   }
+  // wide: a group beyond the LDS (choose_strided_wide_base) -- ONE work-group per CU on a half image, or nothing
+  if (wide && (!kn.strided_hx_wide || full <= std::min<size_t>(max_lds, 128 * 1024))) return out;
+  const int per_cu_lo = wide ? 1 : 2, per_cu_hi = wide ? 1 : 4;
   const size_t cu_lds = std::min<size_t>(max_lds, 160 * 1024);
   const size_t tables = f64 ? 8 * 1024 : 4 * 1024;  // store-modifier tables + allocation granularity, per work-group
   // the order of the radices: the planner's own (a small last radix keeps the store modifier cheap) while half an image of
@@ -708,7 +730,7 @@ std::vector<wg_params> strided_hx_candidates(const wg_params& base, size_t max_l
     return h * static_cast<size_t>(base.fpw) * es;
   };
   std::vector<int> rad = base.radices;
-  if (image_of(rad) + tables > cu_lds / 2) {
+  if (image_of(rad) + tables > (wide ? cu_lds : cu_lds / 2)) {
     std::vector<int> order = base.radices;
     std::sort(order.begin(), order.end());
     size_t best_h = image_of(rad);
@@ -732,7 +754,7 @@ std::vector<wg_params> strided_hx_candidates(const wg_params& base, size_t max_l
       slots += static_cast<double>(tpf) * static_cast<double>(bpt) * r / static_cast<double>(base.n);
     }
     const int wg = tpf * base.fpw, waves = (wg + 63) / 64;
-    for (int per_cu = 2; per_cu <= 4; ++per_cu) {
+    for (int per_cu = per_cu_lo; per_cu <= per_cu_hi; ++per_cu) {
       wg_params p = base;
       p.radices = rad;
       p.wg = wg;

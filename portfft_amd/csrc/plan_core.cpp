@@ -173,6 +173,7 @@ plan_knobs plan_knobs::from_env() {
   mark(k.bi_n1 > 0);
   flag("PFFT_NO_BI_N1_RULE", &k.no_bi_n1_rule);
   flag("PFFT_NO_BIG_BI", &k.no_big_bi);
+  flag("PFFT_NO_BI_WIDE", &k.no_bi_wide);
   flag("PFFT_NO_UNALIGNED_POLICY", &k.no_unaligned_policy);
   return k;
 }

@@ -707,21 +707,45 @@ int plan_t::plan_1d(std::vector<stage>& out, long long n, long long count, long 
       }
     }
   }
+  // A batch-interleaved length whose full-width group (16 fp32 / 8 fp64 columns: whole 128-byte lines) does not fit the LDS
+  // but fits the REGISTERS of one work-group -- fp32 1025 ... 2048 points, fp64 alike: up to 256 KiB, half of it as the LDS image --
+  // runs in ONE HBM pass on the register-resident strided kernel, one work-group per CU (stockham_strided_hx.hpp; jit_strided_kernel
+  // with a negative group width: that kernel or nothing -- a plan whose kernel needs scratch hands the length back).  Before
+  // round 6's last day these lengths took the two-stage plan below (two passes) or, in split storage, 8-column groups.
+  auto plan_wide_group = [&](long long inner) {
+    const int full_fpw = desc.precision == PFFT_PRECISION_F64 ? 8 : 16;
+    if (!jit_enabled() || kn.no_bi_wide || inner < full_fpw || strided_fpw(n, inner) >= full_fpw) return false;
+    const bool unal = !kn.no_unaligned_policy && (static_cast<unsigned long long>(inner) * elem_bytes()) % 128 != 0 &&
+                      static_cast<unsigned long long>(n) * static_cast<unsigned long long>(count) * elem_bytes() >= (64ull << 20);
+    std::string why;
+    const strided_kernel* k = jit_strided_kernel(desc.precision, n, inner, false, interleaved ? 0 : 1, max_lds, &why, true,
+                                                 (interleaved && unal) ? 3 : 0, -full_fpw);
+    if (k == nullptr) {
+      jit_note("strided (wide group)", n, why);
+      return false;
+    }
+    if (!strided_fits(k, inner_count, in_buf, ia, out_buf, oa)) return false;
+    out.push_back(make_strided_stage(k, count, inner_count, in_buf, ia, out_buf, oa, scale, backward));
+    record(PFFT_TIER_WORKGROUP, std::vector<int>(k->radices, k->radices + k->n_radices), k->wg, k->fpw, k->lds_bytes);
+    return true;
+  };
   // Long batch-interleaved transforms: one work-group could hold only a few columns (narrow HBM segments), so
   // split N = n1 * n2 and run both four-step stages column shaped with full-width groups, through scratch.
-  if (interleaved && desc.rank == 1 && in_buf == BUF_IN && out_buf == BUF_OUT && ia.dist_inner == 1 &&
+  if (desc.rank == 1 && in_buf == BUF_IN && out_buf == BUF_OUT && ia.dist_inner == 1 &&
       oa.dist_inner == 1 && ia.stride == count && oa.stride == count && inner_count == count) {
-    if (plan_batch_interleaved_two_stage(out, n, count, 1, in_buf, out_buf, ia, oa, scale, backward, info)) {
+    if (plan_wide_group(count)) return PFFT_TIER_WORKGROUP;
+    if (interleaved && plan_batch_interleaved_two_stage(out, n, count, 1, in_buf, out_buf, ia, oa, scale, backward, info)) {
       return PFFT_TIER_GLOBAL;
     }
   }
   // ... and long column dimensions of N-D arrays: `inner_count` adjacent columns per array, arrays n * inner apart
-  if (interleaved && desc.rank > 1 && in_buf != BUF_SCRATCH && out_buf != BUF_SCRATCH && ia.dist_inner == 1 &&
+  if (desc.rank > 1 && in_buf != BUF_SCRATCH && out_buf != BUF_SCRATCH && ia.dist_inner == 1 &&
       oa.dist_inner == 1 && ia.stride == inner_count && oa.stride == inner_count && inner_count > 0 &&
       count % inner_count == 0 && ia.dist_outer == n * inner_count && oa.dist_outer == n * inner_count &&
       !kn.nd_two_stage_columns) {
-    if (plan_batch_interleaved_two_stage(out, n, inner_count, count / inner_count, in_buf, out_buf, ia, oa, scale,
-                                         backward, info)) {
+    if (plan_wide_group(inner_count)) return PFFT_TIER_WORKGROUP;
+    if (interleaved && plan_batch_interleaved_two_stage(out, n, inner_count, count / inner_count, in_buf, out_buf, ia, oa, scale,
+                                                        backward, info)) {
       return PFFT_TIER_GLOBAL;
     }
   }

@@ -204,7 +204,47 @@ int main(int argc, char** argv) {
              "fp32 1000 x 16: 16000 values do not fit two work-groups' registers beside ~62 of overhead -- LDS-resident");
     }
   }
+  {
+    // WIDE groups (choose_strided_wide_base + strided_hx_candidates(..., wide)): a full-width group of a length beyond the LDS, one
+    // work-group per CU on a half image that fits the CU's LDS, values + overhead inside the wave's register budget
+    long long planned[2] = {0, 0};
+    for (int prec = 0; prec < 2; ++prec) {
+      const int es = prec ? 16 : 8, fpw = prec ? 8 : 16;
+      for (long long n : {1024LL, 1280LL, 1536LL, 1944LL, 2000LL, 2048LL, 3072LL, 4096LL}) {
+        pfa::wg_params b;
+        if (!pfa::choose_strided_wide_base(prec, n, fpw, &b)) continue;
+        const std::vector<pfa::wg_params> c = pfa::strided_hx_candidates(b, max_lds, true);
+        const size_t full = static_cast<size_t>(n) * fpw * es;
+        EXPECT(full > 128 * 1024 || c.empty(), "wide strided hx n=%lld: a group of %zu bytes fits the LDS", n, full);
+        EXPECT(n <= 2048 || c.empty(), "wide strided hx n=%lld: more than 32 values per lane on 1024 lanes", n);
+        for (const pfa::wg_params& q : c) {
+          ++planned[prec];
+          long long prod = 1;
+          for (int r : q.radices) prod *= r;
+          EXPECT(prod == n && q.fpw == fpw && q.hx_strided == 1, "wide strided hx n=%lld: the same group, one per CU", n);
+          EXPECT(pfa::strided_hx_lds_bytes(q) + 4096 <= max_lds, "wide strided hx n=%lld: LDS", n);
+          const int waves = (q.wg + 63) / 64, wps = (waves + 3) / 4;
+          EXPECT(q.wg <= 1024 && q.wg % q.fpw == 0 && q.occ == wps && q.regs * (prec ? 4 : 2) < 512 / wps,
+                 "wide strided hx n=%lld: %d lanes, %d values per lane", n, q.wg, q.regs);
+        }
+      }
+    }
+    std::printf("wide strided hx planner: %lld fp32 and %lld fp64 candidate plans\n", planned[0], planned[1]);
+    EXPECT(planned[0] >= 3 && planned[1] >= 4, "wide strided hx coverage");
+  }
   if (argc > 1 && std::string(argv[1]) == "compile") {
+    for (auto c : std::vector<std::pair<int, long long>>{{0, 2048}, {1, 2048}, {0, 1536}}) {
+      pfa::wg_params b;
+      EXPECT(pfa::choose_strided_wide_base(c.first, c.second, c.first ? 8 : 16, &b), "wide base %lld", c.second);
+      const std::vector<pfa::wg_params> cand = pfa::strided_hx_candidates(b, max_lds, true);
+      EXPECT(!cand.empty(), "wide strided hx plan %lld", c.second);
+      if (cand.empty()) continue;
+      size_t bytes = 0;
+      std::string why;
+      const bool built = pfa::jit_compile_only(cand[0], 11, "gfx950", &bytes, &why);
+      EXPECT(built && bytes > 1000, "hiprtc wide strided hx n=%lld: %s", c.second, why.c_str());
+      std::printf("hiprtc wide n=%lld %s: %zu bytes\n", c.second, pfa::wg_cfg_type_name(cand[0]).c_str(), bytes);
+    }
     for (auto c : std::vector<std::pair<int, long long>>{{0, 660}, {1, 660}, {0, 768}}) {
       pfa::wg_params b;
       EXPECT(pfa::choose_strided_params(c.first, c.second, 4096, max_lds, &b, false, c.first ? 8 : 16), "strided plan %lld", c.second);

@@ -350,6 +350,56 @@ def test_register_resident_stage_kernels(prec):
 
 
 @pytest.mark.parametrize("prec", ["f32", "f64"])
+def test_wide_register_resident_groups(prec):
+    """Batch-interleaved lengths whose full-width group (16 fp32 / 8 fp64 columns) is beyond the LDS but fits the registers of
+    ONE work-group (fp32 / fp64 1025 ... 2048 points; the reference's BATCH_INTERLEAVED work-group branch,
+    workgroup_dispatcher.hpp:148-229, at lengths it would hand to the GLOBAL level): one HBM pass on the register-resident
+    strided kernel with a half image, one work-group per CU -- against NumPy (aligned, unaligned and partial-group batch counts,
+    both storages, directions and placements, P <-> BI, offsets + scale, a 2-D array's long columns) and against the
+    two-stage twin of the same descriptor (PFFT_NO_BI_WIDE=1)."""
+    import gpu_utils as G
+    pf = _pf()
+    dtype = np.complex64 if prec == "f32" else np.complex128
+    tol = 2e-6 if prec == "f32" else 5e-15
+    es = 8 if prec == "f32" else 16
+    full = 16 if prec == "f32" else 8
+    for n in (1280, 2048):
+        dim = _layout_desc(G, n, prec, 48, 1, "BI", "BI", F, 0).commit().info().dims[0]
+        assert dim.tier == 1 and dim.ffts_per_workgroup == full and n * full * es > 128 * 1024 and \
+            dim.lds_bytes <= 152 * 1024 and dim.n_factors >= 2, ("one pass, full width, half image", prec, n, dim.lds_bytes)
+        os.environ["PFFT_NO_BI_WIDE"] = "1"
+        try:
+            twin_dim = _layout_desc(G, n, prec, 48, 1, "BI", "BI", F, 0).commit().info().dims[0]
+        finally:
+            del os.environ["PFFT_NO_BI_WIDE"]
+        assert twin_dim.tier == 3 or twin_dim.ffts_per_workgroup < full, (prec, n, twin_dim.tier)
+        for batch, lin, lout, place, storage in ((48, "BI", "BI", 1, 0), (133, "BI", "BI", 0, 0), (37, "BI", "BI", 1, 1),
+                                                 (full, "BI", "BI", 0, 1)):
+            x, y = H.gen_fourier_data(batch, [n], dtype, seed=n + batch)
+            for direction in (F, B):
+                d = _layout_desc(G, n, prec, batch, place, lin, lout, direction, storage)
+                src, ref = (x, y) if direction == F else (y, x.astype(np.complex128) * n)
+                got, _ = G.transform_packed(d, pf.direction(direction), src)
+                _check(got, ref, n, dtype, ("wide hx", prec, n, batch, lin, lout, place, storage, direction))
+        x, y = H.gen_fourier_data(48, [n], dtype, seed=5)
+        d = G.make_descriptor([n], prec, batch=48, placement=1, fwd_strides=[48], fwd_distance=1, bwd_strides=[48],
+                              bwd_distance=1, fwd_offset=7, bwd_offset=11, fwd_scale=0.5)
+        got, _ = G.transform_packed(d, pf.direction.FORWARD, x)
+        _check(got, 0.5 * y, n, dtype, ("wide hx offsets + scale", prec, n))
+        os.environ["PFFT_NO_BI_WIDE"] = "1"
+        try:
+            twin, _ = G.transform_packed(d, pf.direction.FORWARD, x)
+        finally:
+            del os.environ["PFFT_NO_BI_WIDE"]
+        assert H.rel_l2(got, twin.astype(np.complex128)) < tol, ("wide hx vs two-stage twin", prec, n)
+    # the long column dimension of a 2-D array (lengths [2048, 24]: 24 adjacent columns per matrix, 3 matrices)
+    x, y = H.gen_fourier_data(3, [2048, 24], dtype, seed=77)
+    d = G.make_descriptor([2048, 24], prec, batch=3, placement=1)
+    got, _ = G.transform_packed(d, pf.direction.FORWARD, x)
+    _check(got, y, 2048 * 24, dtype, ("wide hx 2-D columns", prec))
+
+
+@pytest.mark.parametrize("prec", ["f32", "f64"])
 def test_every_registered_length(prec):
     """every length that has a specialised kernel (kernels_f32.hip / kernels_f64.hip), plus neighbours that fall to
     the generic tier, packed, ragged batch counts, forward and backward"""

@@ -8,6 +8,12 @@ int main(int argc, char** argv) {
     for (int i = 1; i < argc; ++i) {
       const long long n = atoll(argv[i]);
       pfa::wg_params b;
+      if (pfa::choose_strided_wide_base(prec, n, prec ? 8 : 16, &b)) {  // groups beyond the LDS: one-per-CU plans
+        for (const pfa::wg_params& q : pfa::strided_hx_candidates(b, 160 * 1024, true)) {
+          printf("%s n=%-6lld WIDE hx x%d per CU: %s lds=%zu regs=%d\n", prec ? "f64" : "f32", n, q.hx_strided, pfa::wg_cfg_type_name(q).c_str(), pfa::strided_hx_lds_bytes(q), q.regs);
+          printf("KRES template __global__ void pfa::stockham_strided_hx_kernel<%s, false, 0, 0>(const pfa::strided_args);\n", pfa::wg_cfg_type_name(q).c_str());
+        }
+      }
       if (!pfa::choose_strided_params(prec, n, 1 << 20, 160 * 1024, &b, false, prec ? 8 : 16) &&
           !pfa::choose_strided_params(prec, n, 1 << 20, 160 * 1024, &b)) {
         printf("%s n=%lld: no strided plan\n", prec ? "f64" : "f32", n);
