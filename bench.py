@@ -68,7 +68,13 @@ WORKLOADS = {
     "g64_16": ([65536], 1024, "f64", "fp64 four-step N=65536 batch=1Ki (reference GlobalTest size)", 2),
     "g64_17": ([131072], 512, "f64", "fp64 four-step N=131072 batch=512 (reference GlobalTest size)", 2),
     "g64_18": ([1 << 18], 256, "f64", "fp64 four-step N=2^18 batch=256", 2),
+    # BATCH_INTERLEAVED on both sides (element i of transform b at i * batch + b; the reference's second first-class layout,
+    # workgroup_dispatcher.hpp:148-229), 1 GiB per buffer: lengths whose full-width group is beyond the LDS -- one pass on the
+    # one-per-CU register-resident strided kernel since round 6 (two column-shaped stages before)
+    "bi32_2048": ([2048], 65536, "f32", "fp32 N=2048 batch=64Ki BATCH_INTERLEAVED in and out", 1),
+    "bi64_2048": ([2048], 32768, "f64", "fp64 N=2048 batch=32Ki BATCH_INTERLEAVED in and out", 1),
 }
+BATCH_INTERLEAVED_WORKLOADS = ("bi32_2048", "bi64_2048")
 
 
 def pmc_traffic(config):
@@ -283,6 +289,9 @@ def main():
     else:
         desc = pf.descriptor(lengths, prec)
         desc.number_of_transforms = batch_per_gpu
+        if args.config in BATCH_INTERLEAVED_WORKLOADS:
+            desc.forward_strides, desc.forward_distance = [batch_per_gpu], 1
+            desc.backward_strides, desc.backward_distance = [batch_per_gpu], 1
     split = desc.complex_storage == pf.complex_storage.SPLIT_COMPLEX
     in_place = desc.placement == pf.placement.IN_PLACE
     n_in, n_out = desc.get_input_count(pf.direction.FORWARD), desc.get_output_count(pf.direction.FORWARD)

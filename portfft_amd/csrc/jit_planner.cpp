@@ -11,6 +11,7 @@
 #include <sstream>
 #include <string>
 #include <utility>
+#include <functional>
 #include <vector>
 
 #include "jit_internal.hpp"
@@ -694,6 +695,38 @@ bool choose_strided_wide_base(int precision, long long n, int fpw, wg_params* ou
   //  ~62 registers of everything else)
   p.radices = pick_radices(precision, n, 16);
   if (p.radices.size() < 2 || p.radices.size() > static_cast<size_t>(MAX_PASSES)) return false;
+  {
+    // the planner's radices minimise passes and balance them; what decides here is the widest pass on 64 lanes per transform
+    // (1024 fp32 / 512 fp64 lanes): fp32 2000 as 10.8.5.5 holds 40 values per lane, as 16.5.5.5 it holds 35.  When the planner's
+    // set is beyond the 36 the candidates accept, the set with the narrowest widest pass (fewest passes, then largest first).
+    auto widest = [&](const std::vector<int>& rs) {
+      long long w = 0;
+      for (int r : rs) w = std::max<long long>(w, ((n / r + 63) / 64) * r);
+      return w;
+    };
+    if (widest(p.radices) > 36) {
+      std::vector<int> best, cur;
+      long long best_w = widest(p.radices);
+      std::function<void(long long, int)> go = [&](long long rem, int max_r) {
+        if (rem == 1) {
+          if (cur.size() >= 2 && (widest(cur) < best_w || (widest(cur) == best_w && !best.empty() && cur.size() < best.size()))) {
+            best = cur;
+            best_w = widest(cur);
+          }
+          return;
+        }
+        if (cur.size() >= static_cast<size_t>(MAX_PASSES)) return;
+        for (int r = std::min<long long>(max_r, rem); r >= 2; --r) {
+          if (rem % r != 0) continue;
+          cur.push_back(r);
+          go(rem / r, r);
+          cur.pop_back();
+        }
+      };
+      go(n, 16);
+      if (!best.empty()) p.radices = best;
+    }
+  }
   p.aux = 2;
   p.twm = 0;
   p.fpw = fpw;
@@ -792,7 +825,9 @@ std::vector<wg_params> strided_hx_candidates(const wg_params& base, size_t max_l
         int ft = 0, fk = 0;
         forced = std::sscanf(e, "%d:%d", &ft, &fk) == 2 && ft == tpf && fk == per_cu;
       }
-      if (need > budget && !forced) continue;
+      // (a wide group has no LDS-resident plan to fall back on and may spill a few registers, jit.cpp: up to 36 fp32 values per
+      //  lane are handed to the compiler -- PFFT_JIT_STRIDED_HX_WIDE_SLACK registers beyond the estimate)
+      if (need > budget + (wide ? static_cast<int>(kn.strided_hx_wide_slack) : 0) && !forced) continue;
       p.occ = wps;
       const double idle = slots / static_cast<double>(rad.size()) - 1.0;
       const double lane_waste = static_cast<double>(waves * 64) / static_cast<double>(wg) - 1.0;
