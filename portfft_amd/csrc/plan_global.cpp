@@ -713,7 +713,8 @@ int plan_t::plan_1d(std::vector<stage>& out, long long n, long long count, long 
   // with a negative group width: that kernel or nothing -- a plan whose kernel needs scratch hands the length back).  Before
   // round 6's last day these lengths took the two-stage plan below (two passes) or, in split storage, 8-column groups.
   auto plan_wide_group = [&](long long inner) {
-    const int full_fpw = desc.precision == PFFT_PRECISION_F64 ? 8 : 16;
+    int full_fpw = desc.precision == PFFT_PRECISION_F64 ? 8 : 16;
+    if (kn.bi_wide_fpw > 0) full_fpw = kn.bi_wide_fpw;  // experiments (PFFT_BI_WIDE_FPW): narrower "wide" groups for longer transforms
     if (!jit_enabled() || kn.no_bi_wide || inner < full_fpw || strided_fpw(n, inner) >= full_fpw) return false;
     const bool unal = !kn.no_unaligned_policy && (static_cast<unsigned long long>(inner) * elem_bytes()) % 128 != 0 &&
                       static_cast<unsigned long long>(n) * static_cast<unsigned long long>(count) * elem_bytes() >= (64ull << 20);
