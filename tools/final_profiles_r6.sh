@@ -6,8 +6,8 @@ set -u
 cd "$GRAFT_REPO_ROOT" || exit 1
 export TMPDIR=/tmp
 out=gpurun_out/final_r6; mkdir -p $out
-ALL="c3 c5 ref16 ref256 ref4096 ref65536 ref9800 ref15360 ref68640 g32_14 g32_15 g32_17 g32_18 g32_19 g32_20 g32_21 g32_22 g32_24 g64_13 g64_14 g64_16 g64_17 g64_18"
-PMC="c2 c3 c5 ref16 ref256 ref4096 ref65536 ref9800 ref15360 ref68640 g32_14 g32_15 g32_17 g32_18 g32_19 g32_20 g32_21 g32_22 g32_24 g64_13 g64_14 g64_16 g64_17 g64_18"
+ALL="bi32_2048 bi64_2048 c3 c5 ref16 ref256 ref4096 ref65536 ref9800 ref15360 ref68640 g32_14 g32_15 g32_17 g32_18 g32_19 g32_20 g32_21 g32_22 g32_24 g64_13 g64_14 g64_16 g64_17 g64_18"
+PMC="c2 bi32_2048 bi64_2048 c3 c5 ref16 ref256 ref4096 ref65536 ref9800 ref15360 ref68640 g32_14 g32_15 g32_17 g32_18 g32_19 g32_20 g32_21 g32_22 g32_24 g64_13 g64_14 g64_16 g64_17 g64_18"
 # ONLY_PMC="cfg ...": only the PMC passes and summaries of those configs (bench lines of them are refreshed too)
 if [ -n "${ONLY_PMC:-}" ]; then PMC="$ONLY_PMC"; fi
 if [ -z "${ONLY_PMC:-}" ]; then
@@ -57,6 +57,8 @@ sum ref68640 stockham_strided 2147483648 4 "fp32 N=68640 x 1920: four-step (104 
 sum g64_16 stockham_xcd_fourstep 2147483648 1 "fp64 N=65536 x 1024: XCD-local single launch (256 x 256), slot rings of 16 transforms per XCD"
 sum g64_17 stockham_xcd_fourstep 2147483648 1 "fp64 N=2^17 x 512: XCD-local single launch (256 x 512), slot rings of 16 transforms per XCD"
 sum g64_18 stockham_xcd_fourstep 2147483648 1 "fp64 N=2^18 x 256: XCD-local single launch (512 x 512), slot rings of 4 transforms per XCD"
+sum bi32_2048 stockham_strided_hx 2147483648 1 "fp32 N=2048 x 65536 BATCH_INTERLEAVED: one pass on the one-per-CU register-resident strided kernel (16.16.8 x 16 columns on 1024 lanes, half image 128 KiB)"
+sum bi64_2048 stockham_strided_hx 2147483648 1 "fp64 N=2048 x 32768 BATCH_INTERLEAVED: one pass on the one-per-CU register-resident strided kernel (16.16.8 x 8 columns on 512 lanes, half image 128 KiB)"
 cp $out/r6_pmc_traffic*.json profiles/ 2>/dev/null
 for c in $PMC; do
   if [ $c = c2 ]; then python bench.py > $out/r6_bench_c2.json 2> $out/c2.err; else python bench.py --config $c --no-cpu-baseline > $out/r6_bench_$c.json 2> $out/$c.err; fi
