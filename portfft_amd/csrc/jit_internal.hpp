@@ -53,6 +53,7 @@ struct jit_knobs {
   const char* rows2d_force = nullptr;     ///< PFFT_JIT_ROWS2D_FORCE
   bool strided_hx = true;                 ///< PFFT_JIT_STRIDED_HX=0: no register-resident strided kernels
   long strided_hx_min_kib = 80;           ///< PFFT_JIT_STRIDED_HX_MIN_KIB: groups above this take the half-image form
+  bool strided_hx_column_rule = true;     ///< PFFT_JIT_STRIDED_HX_COLUMN_RULE=0: the 80 KiB threshold also for column-shaped stages without the modifier
   const char* strided_hx_force = nullptr; ///< PFFT_JIT_STRIDED_HX_FORCE=tpf:per_cu
   bool strided_hx_wide = true;            ///< PFFT_JIT_STRIDED_HX_WIDE=0: no one-per-CU register-resident groups beyond the LDS
   long strided_hx_wide_slack = 8;         ///< PFFT_JIT_STRIDED_HX_WIDE_SLACK: registers beyond the estimate a wide plan may be handed to the compiler with
@@ -91,6 +92,7 @@ struct jit_knobs {
     k.rows2d_force = str("PFFT_JIT_ROWS2D_FORCE");
     if (const char* e = str("PFFT_JIT_STRIDED_HX")) k.strided_hx = e[0] != '0';
     k.strided_hx_min_kib = num("PFFT_JIT_STRIDED_HX_MIN_KIB", 80);
+    if (const char* e = str("PFFT_JIT_STRIDED_HX_COLUMN_RULE")) k.strided_hx_column_rule = e[0] != '0';
     k.strided_hx_force = str("PFFT_JIT_STRIDED_HX_FORCE");
     if (const char* e = str("PFFT_JIT_STRIDED_HX_WIDE")) k.strided_hx_wide = e[0] != '0';
     k.strided_hx_wide_scratch = num("PFFT_JIT_STRIDED_HX_WIDE_SCRATCH", 128);

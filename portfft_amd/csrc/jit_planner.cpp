@@ -737,14 +737,14 @@ bool choose_strided_wide_base(int precision, long long n, int fpw, wg_params* ou
   return true;
 }
 
-std::vector<wg_params> strided_hx_candidates(const wg_params& base, size_t max_lds, bool wide) {
+std::vector<wg_params> strided_hx_candidates(const wg_params& base, size_t max_lds, bool wide, size_t min_bytes) {
   std::vector<wg_params> out;
   const jit_knobs kn = jit_knobs::from_env();
   const int es = elem_bytes_of(base.precision);
   const bool f64 = base.precision == PFFT_PRECISION_F64;
   const size_t full = static_cast<size_t>(base.n) * static_cast<size_t>(base.fpw) * es;
   if (!kn.strided_hx || base.radices.size() < 2 || base.fpw < 2 || base.staged != 0 ||
-      full <= (static_cast<size_t>(kn.strided_hx_min_kib) << 10)) {
+      (min_bytes != 0 ? full < min_bytes : full <= (static_cast<size_t>(kn.strided_hx_min_kib) << 10))) {
     return out;
   }
   // wide: a group beyond the LDS (choose_strided_wide_base) -- ONE work-group per CU on a half image, or nothing

@@ -1,5 +1,5 @@
 """Random descriptors against NumPy: rank, lengths (61-smooth), batch, layout (packed / batch-interleaved / unpacked rows /
-strided), storage, placement, offsets, scales, precision, direction.  usage: fuzz.py [seed] [iterations] [big2d|global|regres|pairs|stages]
+strided), storage, placement, offsets, scales, precision, direction.  usage: fuzz.py [seed] [iterations] [big2d|global|regres|pairs|stages|wide]
 With `big2d` the shapes are 2-D / 3-D with a long last dimension (256...2048): the two-pass 2-D plan
 (stockham_rows2d.hpp) and its fall-backs.  With `global` the lengths are four-step (GLOBAL tier) sizes: powers of two
 2^15 ... 2^21 (the registered stage pairs), 3 / 5 / 6 / 10 times powers of two, powers of ten, lengths with a prime factor
@@ -11,7 +11,10 @@ the LDS-resident kernel where there is no such plan -- both storages, both place
 lengths are 31-smooth lengths of 600 ... 1100 points (fp64: to 1100 too) in the batch-interleaved and mixed layouts with 16 ... 200
 transforms, or four-step lengths one of whose factors lies in that band: the register-resident strided stage kernel
 (stockham_strided_hx.hpp: groups that would sit alone on their CU) wherever its planner takes it, ragged passes and partial
-groups included, and the XCD-contiguous walk for the unaligned row pitches these lengths have."""
+groups included, and the XCD-contiguous walk for the unaligned row pitches these lengths have.  With `wide` the lengths are 13-smooth
+lengths of 590 ... 2304 points, batch-interleaved (or the long column dimension of a 2-D array): groups of 74 ... 80 KiB on two
+register-resident work-groups per CU and, from 1025 points, the WIDE groups -- one register-resident work-group per CU, kernels that
+may spill a few registers -- or the two-stage plan where the planner finds none."""
 import os, sys, random
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
@@ -50,7 +53,9 @@ def main():
     glob = len(sys.argv) > 3 and sys.argv[3] == "global"
     regres = len(sys.argv) > 3 and sys.argv[3] in ("regres", "pairs")
     pairs = len(sys.argv) > 3 and sys.argv[3] == "pairs"
-    stages = len(sys.argv) > 3 and sys.argv[3] == "stages"
+    wide = len(sys.argv) > 3 and sys.argv[3] == "wide"
+    stages = len(sys.argv) > 3 and sys.argv[3] in ("stages", "wide")
+    stage_lo, stage_hi = (590, 2304) if wide else (600, 1100)
     rng = random.Random(seed)
     fails = 0
     for it in range(iters):
@@ -66,12 +71,14 @@ def main():
             rank = 1
             while True:
                 n = 1
-                while n < 600:
+                while n < stage_lo:
                     n *= rng.choice([2, 2, 2, 3, 3, 5, 5, 7, 11, 13])
-                if n <= 1100:
+                if n <= stage_hi:
                     break
-            four_step = rng.random() < 0.3
+            four_step = rng.random() < 0.3 and not wide
             dims = [n * rng.choice([64, 100, 104, 125, 128, 240])] if four_step else [n]
+            if wide and rng.random() < 0.25:
+                rank, dims = 2, [n, rng.choice([16, 24, 33, 40])]
         elif regres:
             rank = 1
             lo, hi = (20481, 40000) if prec == "f32" else (10241, 20000)
@@ -98,7 +105,7 @@ def main():
             dims = [smooth(rng, 2, rng.choice([12, 40, 200])) for _ in range(rank)]
         n = int(np.prod(dims))
         batch = rng.choice([1, 2, 3, 7, 16, 33, 100])
-        if stages and n <= 1100:
+        if stages and n <= stage_hi:
             batch = rng.choice([16, 17, 33, 48, 100, 133, 200])
         if n * batch > 4_000_000:
             batch = max(1, (8_000_000 if (big2d or glob or regres or stages) else 4_000_000) // n)
@@ -106,7 +113,7 @@ def main():
         kw = {}
         place = rng.choice([0, 1])
         layout = "P"
-        if rank == 1 and not glob and not regres and not (stages and n > 1100):
+        if rank == 1 and not glob and not regres and not (stages and n > stage_hi):
             layout = rng.choice(["BI", "BI", "BI", "PBI", "BIP"] if stages else ["P", "P", "BI", "ROWS", "STR", "PBI", "BIP"])
             if layout == "BI":
                 kw = dict(fwd_strides=[batch], fwd_distance=1, bwd_strides=[batch], bwd_distance=1)
