@@ -718,14 +718,28 @@ int plan_t::plan_1d(std::vector<stage>& out, long long n, long long count, long 
     if (!jit_enabled() || kn.no_bi_wide || inner < full_fpw || strided_fpw(n, inner) >= full_fpw) return false;
     const bool unal = !kn.no_unaligned_policy && (static_cast<unsigned long long>(inner) * elem_bytes()) % 128 != 0 &&
                       static_cast<unsigned long long>(n) * static_cast<unsigned long long>(count) * elem_bytes() >= (64ull << 20);
+    // an array of 4 GiB and more (a 1-D batch-interleaved descriptor, interleaved storage): the BIG form of the same kernel (64-bit
+    // butterfly-leg offsets, stockham_strided.hpp) under the conditions of the two-stage plan's BIG forms -- what stays 32 bits is a
+    // lane's offset, the span of the first / last pass's butterflies = 1 / radix of the array
+    const unsigned long long array_bytes = static_cast<unsigned long long>(n) * static_cast<unsigned long long>(inner) * elem_bytes();
+    const bool big = array_bytes >= 0xFFFFFFF0ull;
+    if (big && (desc.rank != 1 || !interleaved || kn.no_big_bi || array_bytes > (16ull << 30) ||
+                static_cast<unsigned long long>(n) * static_cast<unsigned long long>(inner) >= (1ull << 32))) {
+      return false;
+    }
     std::string why;
     const strided_kernel* k = jit_strided_kernel(desc.precision, n, inner, false, interleaved ? 0 : 1, max_lds, &why, true,
-                                                 (interleaved && unal) ? 3 : 0, -full_fpw);
+                                                 (interleaved && unal) ? 3 : 0, -full_fpw, big);
     if (k == nullptr) {
       jit_note("strided (wide group)", n, why);
       return false;
     }
-    if (!strided_fits(k, inner_count, in_buf, ia, out_buf, oa)) return false;
+    if (big) {
+      const int r = k->n_radices >= 1 ? std::min(k->radices[0], k->radices[k->n_radices - 1]) : 0;
+      if (r < 2 || array_bytes / static_cast<unsigned long long>(r) + (1ull << 20) >= 0xFFFFFFF0ull) return false;
+    } else if (!strided_fits(k, inner_count, in_buf, ia, out_buf, oa)) {
+      return false;
+    }
     out.push_back(make_strided_stage(k, count, inner_count, in_buf, ia, out_buf, oa, scale, backward));
     record(PFFT_TIER_WORKGROUP, std::vector<int>(k->radices, k->radices + k->n_radices), k->wg, k->fpw, k->lds_bytes);
     return true;

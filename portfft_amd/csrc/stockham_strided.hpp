@@ -75,14 +75,31 @@ struct strided_io_big {
   const char* in_im;
   char* out;
   char* out_im;
+  // (AUX == 0: the default cache policy on both sides -- policy 3 of aux_of_policy, unaligned row pitches; else streamed)
+  template <typename V>
+  static PFA_DEV V ld(const V* p) {
+    if constexpr (AUX == 0) {
+      return *p;
+    } else {
+      return __builtin_nontemporal_load(p);
+    }
+  }
+  template <typename V>
+  static PFA_DEV void st(V v, V* p) {
+    if constexpr (AUX == 0) {
+      *p = v;
+    } else {
+      __builtin_nontemporal_store(v, p);
+    }
+  }
   PFA_DEV cx<T> load(unsigned voff, off_t soff) const {
     cx<T> x = {T(0), T(0)};
     if (voff != 0xFFFFFFF0u) {
       if constexpr (split_in(SPLIT)) {
-        x.re = __builtin_nontemporal_load(reinterpret_cast<const T*>(in + soff + voff));
-        x.im = __builtin_nontemporal_load(reinterpret_cast<const T*>(in_im + soff + voff));
+        x.re = ld(reinterpret_cast<const T*>(in + soff + voff));
+        x.im = ld(reinterpret_cast<const T*>(in_im + soff + voff));
       } else {
-        x = __builtin_bit_cast(cx<T>, __builtin_nontemporal_load(reinterpret_cast<const vec_t*>(in + soff + voff)));
+        x = __builtin_bit_cast(cx<T>, ld(reinterpret_cast<const vec_t*>(in + soff + voff)));
       }
     }
     return x;
@@ -90,10 +107,10 @@ struct strided_io_big {
   PFA_DEV void store(cx<T> v, unsigned voff, off_t soff) const {
     if (voff != 0xFFFFFFF0u) {
       if constexpr (split_out(SPLIT)) {
-        __builtin_nontemporal_store(v.re, reinterpret_cast<T*>(out + soff + voff));
-        __builtin_nontemporal_store(v.im, reinterpret_cast<T*>(out_im + soff + voff));
+        st(v.re, reinterpret_cast<T*>(out + soff + voff));
+        st(v.im, reinterpret_cast<T*>(out_im + soff + voff));
       } else {
-        __builtin_nontemporal_store(__builtin_bit_cast(vec_t, v), reinterpret_cast<vec_t*>(out + soff + voff));
+        st(__builtin_bit_cast(vec_t, v), reinterpret_cast<vec_t*>(out + soff + voff));
       }
     }
   }

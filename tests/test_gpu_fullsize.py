@@ -171,6 +171,15 @@ def test_buffers_beyond_4gib():
         assert d.commit().info().dims[0].tier != 3, "the round-5 twin: no two-stage plan at 4 GiB and beyond"
     finally:
         del os.environ["PFFT_NO_BIG_BI"]
+    # (the round's last session: lengths of 1025 ... 2048 points keep their ONE-pass plan on the wide register-resident group --
+    #  the BIG form of stockham_strided_hx_kernel -- at 4 GiB and beyond too: 0.33 -> 0.47; an unaligned batch count on default policies)
+    _big_case(2048, 300000, layout_in="BI", layout_out="BI")      # 4.9 GiB per buffer
+    d = pf.descriptor([2048], "f32")
+    d.number_of_transforms = 300000
+    d.forward_strides, d.forward_distance, d.backward_strides, d.backward_distance = [300000], 1, [300000], 1
+    dim = d.commit().info().dims[0]
+    assert dim.tier == 1 and dim.ffts_per_workgroup == 16, (dim.tier, dim.ffts_per_workgroup)
+    _big_case(2048, 270003, layout_in="BI", layout_out="BI")
     _big_case(512, 2400000, layout_in="BI")                       # strided tier, row-shaped output
     _big_case(1200, 1000000)                                      # runtime-specialised length
     _big_case(1 << 20, 1200)                                      # GLOBAL tier fp32, chunked scratch

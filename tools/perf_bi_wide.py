@@ -2,7 +2,8 @@
 plan on the one-per-CU register-resident strided kernel (round 6, plan_global.cpp / jit_strided_kernel with a negative group
 width) against its two-stage twin (PFFT_NO_BI_WIDE=1).  Checks the first and the last transforms against NumPy in double, then
 times BI -> BI.  usage: python tools/perf_bi_wide.py [f32|f64|both] [n ...]
-PFFT_PERF_SPLIT=1: SPLIT_COMPLEX storage; PFFT_PERF_QUICK=1: the aligned ~1 GiB batch count only."""
+PFFT_PERF_SPLIT=1: SPLIT_COMPLEX storage; PFFT_PERF_QUICK=1: the aligned ~1 GiB batch count only; PFFT_PERF_BATCH=<b>: that batch
+count (arrays of 4 GiB and more: the BIG forms)."""
 import math, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -23,7 +24,11 @@ for prec in precs:
     dt = torch.complex64 if prec == "f32" else torch.complex128
     for n in lengths:
         b1 = (1 << 30) // (n * esz) // 64 * 64
-        for b in ([b1] if quick else sorted({b1, b1 + 5, 33000})):
+        if os.environ.get("PFFT_PERF_BATCH"):
+            batches = [int(os.environ["PFFT_PERF_BATCH"])]
+        else:
+            batches = [b1] if quick else sorted({b1, b1 + 5, 33000})
+        for b in batches:
             d = pf.descriptor([n], prec)
             d.number_of_transforms = b
             d.forward_strides = [b]; d.forward_distance = 1
@@ -56,7 +61,7 @@ for prec in precs:
                 plan.compute_backward(y, back); torch.cuda.synchronize()
             rt = (torch.linalg.norm(back / n - x) / torch.linalg.norm(x)).item()
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            reps = 8
+            reps = 8 if n * b * esz < (3 << 30) else 3
             s.record()
             for _ in range(reps): fwd()
             e.record(); torch.cuda.synchronize()
