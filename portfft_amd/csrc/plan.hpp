@@ -182,6 +182,7 @@ struct plan_knobs {
   long long bi_n1 = 0;  // PFFT_BI_N1 (experiment): first factor of the two-stage batch-interleaved plan
   bool no_unaligned_policy = false;  // PFFT_NO_UNALIGNED_POLICY=1: streamed accesses also for stages with unaligned row pitches (round 5)
   int bi_wide_fpw = 0;  // PFFT_BI_WIDE_FPW (experiment): group width of the one-pass plan of long batch-interleaved transforms
+  bool no_bi_wide_split2 = false;  // PFFT_NO_BI_WIDE_SPLIT2=1: SPLIT_COMPLEX batch-interleaved N = 513 ... 1024 stay on 16 / 8 columns (the twin of the double-width wide groups)
   bool no_bi_wide = false;  // PFFT_NO_BI_WIDE=1: batch-interleaved lengths beyond the LDS at full group width stay on the two-stage plan (the twin of round 6's one-pass plan)
   bool no_big_bi = false;  // PFFT_NO_BIG_BI=1: batch-interleaved arrays of 4 GiB and more as in round 5 (narrow groups / generic tier)
   bool no_bi_n1_rule = false;  // PFFT_NO_BI_N1_RULE=1: the balanced split of rounds 2-5 for the two-stage batch-interleaved plan

@@ -174,6 +174,7 @@ plan_knobs plan_knobs::from_env() {
   flag("PFFT_NO_BI_N1_RULE", &k.no_bi_n1_rule);
   flag("PFFT_NO_BIG_BI", &k.no_big_bi);
   flag("PFFT_NO_BI_WIDE", &k.no_bi_wide);
+  flag("PFFT_NO_BI_WIDE_SPLIT2", &k.no_bi_wide_split2);
   if (const char* e = set("PFFT_BI_WIDE_FPW")) k.bi_wide_fpw = std::atoi(e);
   mark(k.bi_wide_fpw > 0);
   flag("PFFT_NO_UNALIGNED_POLICY", &k.no_unaligned_policy);

@@ -712,9 +712,7 @@ int plan_t::plan_1d(std::vector<stage>& out, long long n, long long count, long 
   // runs in ONE HBM pass on the register-resident strided kernel, one work-group per CU (stockham_strided_hx.hpp; jit_strided_kernel
   // with a negative group width: that kernel or nothing -- a plan whose kernel needs scratch hands the length back).  Before
   // round 6's last day these lengths took the two-stage plan below (two passes) or, in split storage, 8-column groups.
-  auto plan_wide_group = [&](long long inner) {
-    int full_fpw = desc.precision == PFFT_PRECISION_F64 ? 8 : 16;
-    if (kn.bi_wide_fpw > 0) full_fpw = kn.bi_wide_fpw;  // experiments (PFFT_BI_WIDE_FPW): narrower "wide" groups for longer transforms
+  auto plan_wide_group_of = [&](long long inner, int full_fpw) {
     if (!jit_enabled() || kn.no_bi_wide || inner < full_fpw || strided_fpw(n, inner) >= full_fpw) return false;
     const bool unal = !kn.no_unaligned_policy && (static_cast<unsigned long long>(inner) * elem_bytes()) % 128 != 0 &&
                       static_cast<unsigned long long>(n) * static_cast<unsigned long long>(count) * elem_bytes() >= (64ull << 20);
@@ -743,6 +741,17 @@ int plan_t::plan_1d(std::vector<stage>& out, long long n, long long count, long 
     out.push_back(make_strided_stage(k, count, inner_count, in_buf, ia, out_buf, oa, scale, backward));
     record(PFFT_TIER_WORKGROUP, std::vector<int>(k->radices, k->radices + k->n_radices), k->wg, k->fpw, k->lds_bytes);
     return true;
+  };
+  // SPLIT_COMPLEX planes hold 4 / 8 bytes per element: a whole 128-byte line per plane takes 32 fp32 / 16 fp64 columns, a group the
+  // LDS holds up to N = 512 only.  N = 513 ... 1024 in split storage therefore go to the wide kernel at DOUBLE width first (<= 32 values per
+  // lane on 1024 / 512 lanes; profiles/r6_bi_wide_split32.txt, 16 / 8 columns LDS-resident -> 32 / 16 register-resident, fraction of the HBM
+  // peak): fp32 576 0.357 -> 0.490, 640 0.350 -> 0.528, 768 0.357 -> 0.568, 896 0.355 -> 0.519, 1024 0.369 -> 0.446; fp64 0.336 -> 0.540, 0.332 -> 0.535,
+  // 0.379 -> 0.588, 0.375 -> 0.541, 0.321 -> 0.537.  (Interleaved data at that width: 640 +13 ... 18 %, 768 +2 ... 5 %, 1024 -3 ... -8 % -- not taken.)
+  auto plan_wide_group = [&](long long inner) {
+    const int full_fpw = desc.precision == PFFT_PRECISION_F64 ? 8 : 16;
+    if (kn.bi_wide_fpw > 0) return plan_wide_group_of(inner, kn.bi_wide_fpw);  // experiments (PFFT_BI_WIDE_FPW): that group width
+    if (!interleaved && !kn.no_bi_wide_split2 && plan_wide_group_of(inner, 2 * full_fpw)) return true;
+    return plan_wide_group_of(inner, full_fpw);
   };
   // Long batch-interleaved transforms: one work-group could hold only a few columns (narrow HBM segments), so
   // split N = n1 * n2 and run both four-step stages column shaped with full-width groups, through scratch.

@@ -393,6 +393,23 @@ def test_wide_register_resident_groups(prec):
         finally:
             del os.environ["PFFT_NO_BI_WIDE"]
         assert H.rel_l2(got, twin.astype(np.complex128)) < tol, ("wide hx vs two-stage twin", prec, n)
+    # SPLIT_COMPLEX at N = 513 ... 1024: the same kernel at DOUBLE width (32 fp32 / 16 fp64 columns: whole 128-byte lines per plane)
+    for n in (640, 1024):
+        d0 = _layout_desc(G, n, prec, 2 * full + 5, 1, "BI", "BI", F, 1)
+        dim = d0.commit().info().dims[0]
+        assert dim.tier == 1 and dim.ffts_per_workgroup == 2 * full, ("split storage, double width", prec, n, dim.ffts_per_workgroup)
+        os.environ["PFFT_NO_BI_WIDE_SPLIT2"] = "1"
+        try:
+            assert d0.commit().info().dims[0].ffts_per_workgroup == full, (prec, n)
+        finally:
+            del os.environ["PFFT_NO_BI_WIDE_SPLIT2"]
+        for batch, place in ((2 * full + 5, 1), (133, 0), (2 * full, 1)):
+            x, y = H.gen_fourier_data(batch, [n], dtype, seed=n + batch)
+            for direction in (F, B):
+                d = _layout_desc(G, n, prec, batch, place, "BI", "BI", direction, 1)
+                src, ref = (x, y) if direction == F else (y, x.astype(np.complex128) * n)
+                got, _ = G.transform_packed(d, pf.direction(direction), src)
+                _check(got, ref, n, dtype, ("wide hx split x2", prec, n, batch, place, direction))
     # the long column dimension of a 2-D array (lengths [2048, 24]: 24 adjacent columns per matrix, 3 matrices)
     x, y = H.gen_fourier_data(3, [2048, 24], dtype, seed=77)
     d = G.make_descriptor([2048, 24], prec, batch=3, placement=1)
