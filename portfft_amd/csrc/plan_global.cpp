@@ -714,7 +714,9 @@ int plan_t::plan_1d(std::vector<stage>& out, long long n, long long count, long 
   // round 6's last day these lengths took the two-stage plan below (two passes) or, in split storage, 8-column groups.
   auto plan_wide_group_of = [&](long long inner, int full_fpw) {
     if (!jit_enabled() || kn.no_bi_wide || inner < full_fpw || strided_fpw(n, inner) >= full_fpw) return false;
-    const bool unal = !kn.no_unaligned_policy && (static_cast<unsigned long long>(inner) * elem_bytes()) % 128 != 0 &&
+    // (split storage: a plane's row pitch is inner * sizeof(scalar))
+    const bool unal = !kn.no_unaligned_policy &&
+                      (static_cast<unsigned long long>(inner) * (interleaved ? elem_bytes() : elem_bytes() / 2)) % 128 != 0 &&
                       static_cast<unsigned long long>(n) * static_cast<unsigned long long>(count) * elem_bytes() >= (64ull << 20);
     // an array of 4 GiB and more (a 1-D batch-interleaved descriptor, interleaved storage): the BIG form of the same kernel (64-bit
     // butterfly-leg offsets, stockham_strided.hpp) under the conditions of the two-stage plan's BIG forms -- what stays 32 bits is a
@@ -727,7 +729,7 @@ int plan_t::plan_1d(std::vector<stage>& out, long long n, long long count, long 
     }
     std::string why;
     const strided_kernel* k = jit_strided_kernel(desc.precision, n, inner, false, interleaved ? 0 : 1, max_lds, &why, true,
-                                                 (interleaved && unal) ? 3 : 0, -full_fpw, big);
+                                                 unal ? 3 : 0, -full_fpw, big);
     if (k == nullptr) {
       jit_note("strided (wide group)", n, why);
       return false;

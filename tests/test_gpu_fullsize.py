@@ -348,7 +348,9 @@ def test_batch_interleaved_at_batch_counts_that_are_no_multiple_of_a_line():
         return x, y, plan
 
     tol = {"f32": 2e-6, "f64": 5e-15}
-    for n, batch, prec in ((1024, 16391, "f32"), (768, 21851, "f32"), (256, 32771, "f64"), (4096, 4099, "f32"), (1000, 16387, "f64")):
+    # ((2048, 8195): the wide register-resident group of the round's last session on policy 3)
+    for n, batch, prec in ((1024, 16391, "f32"), (768, 21851, "f32"), (256, 32771, "f64"), (4096, 4099, "f32"), (1000, 16387, "f64"),
+                           (2048, 8195, "f32")):
         x, y, plan = run_case(n, batch, prec)
         for b in (0, 1, batch // 2, batch - 1):
             ref = np.fft.fft(x[b::batch].cpu().numpy().astype(np.complex128))
@@ -362,6 +364,35 @@ def test_batch_interleaved_at_batch_counts_that_are_no_multiple_of_a_line():
         err = float(((z / n - x).abs().double().pow(2).sum() / x.abs().double().pow(2).sum()).sqrt())
         assert err <= tol[prec], (n, batch, prec, "round trip", err)
         del x, y, y0, z
+    # SPLIT_COMPLEX planes at such a batch count (a plane's pitch: batch * sizeof(scalar)): the wide groups of N = 513 ... 2048 take policy 3 too
+    for n, batch, prec in ((768, 21851, "f32"), (2048, 4099, "f64")):
+        rdt = torch.float32 if prec == "f32" else torch.float64
+        g = torch.Generator(device="cuda").manual_seed(n + batch)
+        xr = torch.empty(batch * n, dtype=rdt, device="cuda").uniform_(-1, 1, generator=g)
+        xi = torch.empty(batch * n, dtype=rdt, device="cuda").uniform_(-1, 1, generator=g)
+        outs = []
+        for env in ({}, {"PFFT_NO_UNALIGNED_POLICY": "1"}):
+            os.environ.update(env)
+            try:
+                d = pf.descriptor([n], prec)
+                d.number_of_transforms = batch
+                d.complex_storage = pf.complex_storage.SPLIT_COMPLEX
+                d.forward_strides, d.forward_distance, d.backward_strides, d.backward_distance = [batch], 1, [batch], 1
+                plan = d.commit()
+            finally:
+                for k in env:
+                    del os.environ[k]
+            yr, yi = torch.empty_like(xr), torch.empty_like(xi)
+            plan.compute_forward(xr, xi, yr, yi).wait()
+            outs.append((torch.complex(yr, yi), plan.info().knob_mask))
+        assert outs[0][1] != outs[1][1]
+        y = outs[0][0]
+        for b in (0, 1, batch // 2, batch - 1):
+            ref = np.fft.fft(torch.complex(xr[b::batch], xi[b::batch]).cpu().numpy().astype(np.complex128))
+            assert H.rel_l2(y[b::batch].cpu().numpy(), ref) <= tol[prec], ("split", n, batch, prec, b)
+        diff = float(((y - outs[1][0]).abs().double().pow(2).sum() / y.abs().double().pow(2).sum()).sqrt())
+        assert diff <= tol[prec], ("split", n, batch, prec, "against the streamed twin", diff)
+        del xr, xi, y, outs
     torch.cuda.empty_cache()
 
 
