@@ -180,6 +180,7 @@ struct plan_knobs {
   bool groups_per_wg_set = false, global_chunk_mib_set = false, cache_chunk_mib_set = false;
   long global_chunk_mib = 0, cache_chunk_mib = 0;
   long long bi_n1 = 0;  // PFFT_BI_N1 (experiment): first factor of the two-stage batch-interleaved plan
+  bool no_split_unaligned_policy = false;  // PFFT_NO_SPLIT_UNALIGNED_POLICY=1: policy 3 for interleaved data only (SPLIT_COMPLEX batch-interleaved planes stay streamed, as before the round's last session)
   bool no_unaligned_policy = false;  // PFFT_NO_UNALIGNED_POLICY=1: streamed accesses also for stages with unaligned row pitches (round 5)
   int bi_wide_fpw = 0;  // PFFT_BI_WIDE_FPW (experiment): group width of the one-pass plan of long batch-interleaved transforms
   bool no_bi_wide_split2 = false;  // PFFT_NO_BI_WIDE_SPLIT2=1: SPLIT_COMPLEX batch-interleaved N = 513 ... 1024 stay on 16 / 8 columns (the twin of the double-width wide groups)

@@ -178,6 +178,7 @@ plan_knobs plan_knobs::from_env() {
   if (const char* e = set("PFFT_BI_WIDE_FPW")) k.bi_wide_fpw = std::atoi(e);
   mark(k.bi_wide_fpw > 0);
   flag("PFFT_NO_UNALIGNED_POLICY", &k.no_unaligned_policy);
+  flag("PFFT_NO_SPLIT_UNALIGNED_POLICY", &k.no_split_unaligned_policy);
   return k;
 }
 
@@ -458,11 +459,11 @@ int plan_t::strided_fpw(long long n, long long inner_count) const {
 /// policy: cache policy of the stage (strided_kernel::policy; 1 writer -- needs store_modifier --, 2 reader)
 const strided_kernel* plan_t::get_strided(long long n, long long inner_count, bool store_modifier, bool user_split,
                                           bool column_both, bool row_side, int policy) {
-  if (policy == 3 && jit_enabled() && !user_split) {  // (row-shaped sides too: the row-staged forms are built from this entry)
+  if (policy == 3 && jit_enabled() && (!user_split || (column_both && !store_modifier && !row_side))) {  // (row-shaped sides too: the row-staged forms are built from this entry)
     // an unaligned row pitch (aux_of_policy): the kernel compiled at commit on default cache policies with the shared group
-    // walk, whatever the registry holds for the length
+    // walk, whatever the registry holds for the length (split user planes: batch-interleaved on both sides only)
     std::string why;
-    if (const strided_kernel* k = jit_strided_kernel(desc.precision, n, inner_count, store_modifier, 0, max_lds, &why, column_both, policy)) {
+    if (const strided_kernel* k = jit_strided_kernel(desc.precision, n, inner_count, store_modifier, user_split ? 1 : 0, max_lds, &why, column_both, policy)) {
       return k;
     }
     jit_note("strided (unaligned pitch)", n, why);

@@ -784,14 +784,20 @@ int plan_t::plan_1d(std::vector<stage>& out, long long n, long long count, long 
   // is no multiple of 16 fp32 / 8 fp64 transforms): policy 3, kernels.hpp aux_of_policy.  The partial-line STORES are what
   // costs -- P -> BI N = 1024 x 131 077 0.232 -> 0.404, N = 256 0.353 -> 0.533, BI -> BI 0.204 -> 0.497; an unaligned INPUT alone (BI -> P) is
   // -9 ... +16 % either way and keeps the streamed kernels (profiles/r6_pbi_policy.txt)
+  // (split user planes: a plane's pitch is stride * sizeof(scalar); batch-interleaved on both sides only -- measured on the wide groups,
+  //  profiles/r6_bi_wide_split_unaligned.txt, and on N = 256 / 512, r6_bi_split_unaligned_small.txt)
   auto unaligned = [&](const addressing& a) {
-    return a.dist_inner == 1 && a.stride > 1 && (static_cast<unsigned long long>(a.stride) * elem_bytes()) % 128 != 0;
+    const size_t eb = interleaved ? elem_bytes() : elem_bytes() / 2;
+    return a.dist_inner == 1 && a.stride > 1 && (static_cast<unsigned long long>(a.stride) * eb) % 128 != 0;
   };
   // (from 64 MiB of data: below that a commit does not pay a compilation for a pre-compiled length, and the data sits in the
   //  caches whatever the policy)
   const bool worth = static_cast<unsigned long long>(count) * static_cast<unsigned long long>(n) * elem_bytes() >= (64ull << 20);
   const int stage_policy =
-      (tail_policy == 0 && interleaved && worth && !kn.no_unaligned_policy && unaligned(oa)) ? 3 : tail_policy;
+      (tail_policy == 0 && (interleaved || (user_split && column_both && !kn.no_split_unaligned_policy)) && worth &&
+       !kn.no_unaligned_policy && unaligned(oa))
+          ? 3
+          : tail_policy;
   if (const strided_kernel* k =
           column_shaped ? get_strided(n, inner_count, false, user_split, column_both, row_side, stage_policy) : nullptr;
       strided_fits(k, inner_count, in_buf, ia, out_buf, oa)) {

@@ -365,7 +365,8 @@ def test_batch_interleaved_at_batch_counts_that_are_no_multiple_of_a_line():
         assert err <= tol[prec], (n, batch, prec, "round trip", err)
         del x, y, y0, z
     # SPLIT_COMPLEX planes at such a batch count (a plane's pitch: batch * sizeof(scalar)): the wide groups of N = 513 ... 2048 take policy 3 too
-    for n, batch, prec in ((768, 21851, "f32"), (2048, 4099, "f64")):
+    # (and, N <= 512, the LDS-resident kernels compiled at commit: (256, 32771))
+    for n, batch, prec in ((768, 21851, "f32"), (2048, 4099, "f64"), (256, 32771, "f32")):
         rdt = torch.float32 if prec == "f32" else torch.float64
         g = torch.Generator(device="cuda").manual_seed(n + batch)
         xr = torch.empty(batch * n, dtype=rdt, device="cuda").uniform_(-1, 1, generator=g)
