@@ -715,7 +715,7 @@ int plan_t::plan_1d(std::vector<stage>& out, long long n, long long count, long 
   auto plan_wide_group_of = [&](long long inner, int full_fpw) {
     if (!jit_enabled() || kn.no_bi_wide || inner < full_fpw || strided_fpw(n, inner) >= full_fpw) return false;
     // (split storage: a plane's row pitch is inner * sizeof(scalar))
-    const bool unal = !kn.no_unaligned_policy &&
+    const bool unal = !kn.no_unaligned_policy && (interleaved || !kn.no_split_unaligned_policy) &&
                       (static_cast<unsigned long long>(inner) * (interleaved ? elem_bytes() : elem_bytes() / 2)) % 128 != 0 &&
                       static_cast<unsigned long long>(n) * static_cast<unsigned long long>(count) * elem_bytes() >= (64ull << 20);
     // an array of 4 GiB and more (a 1-D batch-interleaved descriptor, interleaved storage): the BIG form of the same kernel (64-bit
