@@ -57,7 +57,7 @@ struct jit_knobs {
   const char* strided_hx_force = nullptr; ///< PFFT_JIT_STRIDED_HX_FORCE=tpf:per_cu
   bool strided_hx_wide = true;            ///< PFFT_JIT_STRIDED_HX_WIDE=0: no one-per-CU register-resident groups beyond the LDS
   long strided_hx_wide_slack = 8;         ///< PFFT_JIT_STRIDED_HX_WIDE_SLACK: registers beyond the estimate a wide plan may be handed to the compiler with
-  long strided_hx_wide_scratch = 128;      ///< PFFT_JIT_STRIDED_HX_WIDE_SCRATCH: bytes of scratch per lane such a kernel may need (see jit.cpp)
+  long strided_hx_wide_scratch = 192;      ///< PFFT_JIT_STRIDED_HX_WIDE_SCRATCH: bytes of scratch per lane such a kernel may need (see jit.cpp)
 
   static jit_knobs from_env() {
     jit_knobs k;
@@ -95,7 +95,7 @@ struct jit_knobs {
     if (const char* e = str("PFFT_JIT_STRIDED_HX_COLUMN_RULE")) k.strided_hx_column_rule = e[0] != '0';
     k.strided_hx_force = str("PFFT_JIT_STRIDED_HX_FORCE");
     if (const char* e = str("PFFT_JIT_STRIDED_HX_WIDE")) k.strided_hx_wide = e[0] != '0';
-    k.strided_hx_wide_scratch = num("PFFT_JIT_STRIDED_HX_WIDE_SCRATCH", 128);
+    k.strided_hx_wide_scratch = num("PFFT_JIT_STRIDED_HX_WIDE_SCRATCH", 192);
     k.strided_hx_wide_slack = num("PFFT_JIT_STRIDED_HX_WIDE_SLACK", 8);
     return k;
   }
