@@ -229,6 +229,17 @@ int main(int argc, char** argv) {
         }
       }
     }
+    {
+      // the planner's own radices of 2000 (10.8.5.5) hold 40 values per lane on 64 lanes per transform: the base takes the set with the
+      // narrowest widest pass instead (16.5.5.5: 35)
+      pfa::wg_params b;
+      EXPECT(pfa::choose_strided_wide_base(0, 2000, 16, &b) && b.radices == std::vector<int>({16, 5, 5, 5}), "wide base of 2000: 16.5.5.5");
+      const std::vector<pfa::wg_params> c = pfa::strided_hx_candidates(b, max_lds, true);
+      EXPECT(!c.empty() && c[0].regs == 35 && c[0].wg >= 960, "wide plan of 2000: 35 values per lane on ~1000 lanes");
+      // a group that fits the LDS is no wide group; neither is one of more than 36 values per lane
+      EXPECT(pfa::choose_strided_wide_base(0, 1000, 16, &b) && pfa::strided_hx_candidates(b, max_lds, true).empty(), "1000 x 16 fits the LDS");
+      EXPECT(pfa::choose_strided_wide_base(0, 4096, 16, &b) && pfa::strided_hx_candidates(b, max_lds, true).empty(), "4096 x 16: 64 values per lane");
+    }
     std::printf("wide strided hx planner: %lld fp32 and %lld fp64 candidate plans\n", planned[0], planned[1]);
     EXPECT(planned[0] >= 3 && planned[1] >= 4, "wide strided hx coverage");
   }
